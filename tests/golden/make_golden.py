@@ -1,0 +1,649 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE in this container.
+
+    python tests/golden/make_golden.py [group ...]      # groups: xform oct kseq ctx e2e logits swin cdf ac facts
+
+Only data (inputs + expected outputs) is written; no reference source travels.  Every
+fixture records which reference call produced it.  The script needs
+/root/reference and is never run on the GPU box.
+"""
+import hashlib
+import io
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import _ref_env  # noqa: E402
+
+_ref_env.setup()
+
+import torch  # noqa: E402
+
+from scp_amd.synth import synth_frame, write_kitti_bin, ford_like  # noqa: E402
+from scp_amd.weights import fill_weights  # noqa: E402
+
+from data_preproc import Octree as RO  # noqa: E402
+from data_preproc import data_preprocess as RDP  # noqa: E402
+from data_preproc.OctreeCPP.Octreewarpper import gen_octree as so_gen_octree  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} kB")
+
+
+def frame5k(seed):
+    return synth_frame(seed)[::24].copy()
+
+
+# ----------------------------------------------------------------------------- xform
+def quantise_like_proc_pc(ref_pt, qs, mode):
+    """Lines data_preprocess.py:40-68 executed verbatim through the reference functions."""
+    import math
+    points = ref_pt
+    offset = 0
+    bin_num = 0
+    if mode == "cylin":
+        points = RDP.cart2cylin(ref_pt)
+        bin_num = np.round(points[:, 0].max() / qs) + 1
+        qsv = np.array([qs, 2 * math.pi / (bin_num - 1), qs])[True]
+        offset = np.array([0.0, 0.0, min(points[:, 2])])[True]
+    elif mode == "spher":
+        points = RDP.cart2spher(ref_pt)
+        bin_num = np.round(points[:, 0].max() / qs) + 1
+        qsv = np.array([qs, 2 * math.pi / (bin_num - 1), math.pi / (bin_num - 1)])[True]
+        offset = 0
+    else:
+        qsv = qs
+        offset = -200
+    tr = points
+    points = points - offset
+    pt = np.round(points / qsv)
+    return tr, float(bin_num), pt, offset
+
+
+def gen_xform():
+    print("[xform]")
+    for seed in (0, 1):
+        xyz = synth_frame(seed)[:4096].copy()
+        out = {"xyz": xyz}
+        for mode in ("spher", "cylin", "cart"):
+            for L in (12, 14, 16, 18):
+                qs = 400 / (2 ** L - 1)
+                tr, bin_num, pt, offset = quantise_like_proc_pc(xyz, qs, mode)
+                assert np.abs(pt).max() < 2 ** 31
+                out[f"{mode}_L{L}_q"] = pt.astype(np.int32)
+                out[f"{mode}_L{L}_bin"] = np.float64(bin_num)
+                if mode == "cylin":
+                    out[f"{mode}_L{L}_zoff"] = np.float64(offset[0, 2])
+            if mode != "cart":
+                out[f"{mode}_tr"] = tr.astype(np.float32)
+                assert tr.dtype == np.float32
+        save(f"xform_s{seed}", **out)
+
+
+# ----------------------------------------------------------------------------- octree
+def so_tree_tables(pts):
+    """Run the reference's native builder and flatten it to arrays (BFS order)."""
+    tree = so_gen_octree(pts)
+    codes = np.array([tree.code[i] for i in range(len(tree.code))], np.int64)
+    lv, octant, parent, occ, pos = [], [], [], [], []
+    for L in range(len(tree)):
+        level = tree[L]
+        for i in range(len(level)):
+            n = level[i]
+            lv.append(L + 1)
+            octant.append(n.octant)
+            parent.append(n.parent)
+            occ.append(n.oct)
+            pos.append([n.pos[0], n.pos[1], n.pos[2]])
+    return tree, codes, np.array(lv), np.array(octant), np.array(parent), np.array(occ), np.array(pos).reshape(-1, 3)
+
+
+def py_tree_tables(octree):
+    lv, octant, parent, occ, pos = [], [], [], [], []
+    for L, level in enumerate(octree):
+        for n in level.node:
+            lv.append(L + 1)
+            octant.append(n.octant)
+            parent.append(n.parent)
+            occ.append(n.oct)
+            pos.append(np.asarray(n.pos).reshape(-1)[:3])
+    return np.array(lv), np.array(octant), np.array(parent), np.array(occ), np.array(pos).reshape(-1, 3)
+
+
+def rand_clouds():
+    rng = np.random.default_rng(1234)
+    c = {}
+    c["cubic50"] = rng.integers(0, 16, (50, 3))
+    c["cubic1000"] = rng.integers(0, 1024, (1000, 3))
+    c["skew2000"] = np.stack([rng.integers(0, 820, 2000), rng.integers(0, 820, 2000), rng.integers(0, 523, 2000)], 1)
+    c["deep300"] = np.stack([rng.integers(0, 13113, 300), rng.integers(0, 13106, 300), rng.integers(0, 8364, 300)], 1)
+    c["pow2edge"] = np.array([[0, 0, 0], [15, 15, 15], [16, 0, 0], [0, 16, 0], [0, 0, 16], [31, 31, 31], [7, 8, 9]])
+    c["pow2max15"] = np.array([[15, 0, 3], [1, 2, 3], [14, 15, 0]])
+    c["single"] = np.array([[5, 9, 2]])
+    c["single_one"] = np.array([[1, 0, 0]])  # [[0,0,0]] (depth 0) aborts inside the reference .so
+    c["line_x"] = np.stack([np.arange(40), np.zeros(40, int), np.zeros(40, int)], 1)
+    base = rng.integers(0, 200, (400, 3))
+    c["dups_shuffled"] = rng.permutation(np.concatenate([base, base[:150], base[:10]]))
+    c["frame5k_L12"] = None  # filled below from the synthetic frame
+    return c
+
+
+def gen_oct():
+    print("[oct]")
+    clouds = rand_clouds()
+    xyz = frame5k(0)
+    _, _, q, _ = quantise_like_proc_pc(xyz, 400 / (2 ** 12 - 1), "spher")
+    clouds["frame5k_L12"] = np.unique(q, axis=0).astype(int)
+    for name, pts in clouds.items():
+        pts = np.asarray(pts).astype(np.int64)
+        upts = np.unique(pts, axis=0)
+        # the reference .so asserts on duplicate points (Octree.cpp:121); proc_pc always np.unique's first
+        tree, codes, lv, octant, parent, occ, pos = so_tree_tables(upts if name.startswith("dups") else pts)
+        pcodes, ptree, lmax = RO.GenOctree(upts)
+        plv, poctant, pparent, pocc, ppos = py_tree_tables(ptree)
+        assert np.array_equal(codes, np.array(pcodes)), name
+        assert np.array_equal(lv, plv) and np.array_equal(octant, poctant) and np.array_equal(occ, pocc), name
+        assert np.array_equal(pos, ppos), name
+        assert np.array_equal(parent[1:], pparent[1:]), name
+        rec_so = RO.gen_K_parent_seq(tree, 4)
+        rec = np.concatenate((rec_so["Seq"][:, :, True], rec_so["Level"], rec_so["Pos"]), axis=2)
+        rec_py = RO.gen_K_parent_seq(ptree, 4)
+        recp = np.concatenate((rec_py["Seq"][:, :, True], rec_py["Level"], rec_py["Pos"]), axis=2)
+        assert np.array_equal(rec, recp), name
+        save(f"oct_{name}", pts=pts.astype(np.int32), codes=codes.astype(np.uint8), level=lv.astype(np.uint8),
+             octant=octant.astype(np.uint8), parent=pparent.astype(np.int32), occ=occ.astype(np.uint8),
+             pos=pos.astype(np.int32), depth=np.int32(lmax), krec=rec.astype(np.int32))
+
+    # mullevel: shell filter on the rho axis (Octree.py:184-221) + records with the last node dropped
+    print("[oct_mul]")
+    rng = np.random.default_rng(99)
+    mclouds = {
+        "skew": np.stack([rng.integers(0, 1000, 1500), rng.integers(0, 900, 1500), rng.integers(0, 500, 1500)], 1),
+        "near_only": np.stack([rng.integers(0, 200, 300), rng.integers(0, 1000, 300), rng.integers(0, 500, 300)], 1),
+        "frame5k_L14": None,
+    }
+    _, _, q, _ = quantise_like_proc_pc(xyz, 400 / (2 ** 14 - 1), "spher")
+    _, idx = np.unique(q, axis=0, return_index=True)
+    mclouds["frame5k_L14"] = q[np.sort(idx)].astype(int)
+    for name, pts in mclouds.items():
+        pts = np.asarray(pts)
+        _, idx = np.unique(pts, axis=0, return_index=True)
+        pts = pts[np.sort(idx)]
+        out = {"pts": pts.astype(np.int32)}
+        for path in ([0, 0], [0, 1], [1]):
+            tag = "".join(map(str, path))
+            try:
+                codes, tree, lmax, idxs = RO.mullevel_gen_octree(pts.astype(np.float64), morton_path=path)
+            except Exception as e:  # empty shell: the reference itself fails
+                out[f"p{tag}_empty"] = np.int32(1)
+                print(f"    {name} path {path}: reference raises {type(e).__name__} (empty shell)")
+                continue
+            if len(codes) == 0:
+                out[f"p{tag}_empty"] = np.int32(1)
+                continue
+            lv, octant, parent, occ, pos = py_tree_tables(tree)
+            rec_d = RO.gen_K_parent_seq_mullevel(tree, 4)
+            rec = np.concatenate((rec_d["Seq"][:, :, True], rec_d["Level"], rec_d["Pos"]), axis=2)
+            dec = RO.DeOctree(np.array(codes))
+            out[f"p{tag}_codes"] = np.array(codes, np.uint8)
+            out[f"p{tag}_level"] = lv.astype(np.uint8)
+            out[f"p{tag}_octant"] = octant.astype(np.uint8)
+            out[f"p{tag}_parent"] = parent.astype(np.int32)
+            out[f"p{tag}_occ"] = occ.astype(np.uint8)
+            out[f"p{tag}_pos"] = pos.astype(np.int32)
+            out[f"p{tag}_krec"] = rec.astype(np.int32)
+            out[f"p{tag}_outer"] = rec_d["outer"].astype(np.int32)
+            out[f"p{tag}_depth"] = np.int32(lmax)
+            out[f"p{tag}_deoct"] = dec.astype(np.int32)
+        save(f"octmul_{name}", **out)
+
+
+# ----------------------------------------------------------------------------- ctx (dataset logic)
+def _run_dataset_same(xyz, L, mode, tmp):
+    """proc_pc + EncodeEHEMDataset.__getitem__ level split, through the reference classes."""
+    from dataloaders.encode_dataset_ehem import EncodeEHEMDataset
+    binf = os.path.join(tmp, "seq", "f0.bin")
+    os.makedirs(os.path.dirname(binf), exist_ok=True)
+    write_kitti_bin(binf, xyz)
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        res = RDP.proc_pc(binf, os.path.join(tmp, "pp"), "f0", qs=400 / (2 ** L - 1), test=True,
+                          spher=(mode == "spher"), cylin=(mode == "cylin"),
+                          **({} if mode != "cart" else {"offset": -200}))
+        ds = EncodeEHEMDataset([binf], 8192, "kitti", True, L, mode == "cylin", mode == "spher")
+        if mode == "cylin":
+            ds.preproc = lambda f: (res[0], res[2], 0.0, res[3], res[4][0, 2], 0.0)
+        elif mode == "spher":
+            ds.preproc = lambda f: (res[0], res[2], 0.0, res[3], 0.0)
+        else:
+            ds.preproc = lambda f: (res[0], res[2], 0.0, 0.0)
+        item = ds[0]
+    finally:
+        os.chdir(cwd)
+    return res, item
+
+
+def gen_ctx():
+    print("[ctx]")
+    xyz = frame5k(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        for mode, L in (("spher", 12), ("cylin", 12), ("cart", 10)):
+            res, item = _run_dataset_same(xyz, L, mode, tmp)
+            ids, poss, pos_mm, data, oct_seq = item[0], item[1], item[2], item[3], item[4]
+            out = {"xyz": xyz, "n_levels": np.int32(len(data)), "oct_seq": oct_seq.astype(np.int32),
+                   "bin_num": np.float64(item[7]), "z_offset": np.float64(item[8]),
+                   "quant_pc": np.asarray(res[1], np.float32)}
+            for l in range(len(data)):
+                out[f"data{l}"] = data[l].astype(np.int16)
+                out[f"pos{l}"] = poss[l]
+                assert poss[l].dtype == np.float32
+                out[f"ids{l}"] = ids[l].astype(np.int32)
+            if pos_mm:
+                out["pos_mm"] = np.array(pos_mm, np.int64)
+            save(f"ctx_ehem_{mode}_L{L}", **out)
+
+        # OctAttention dataset (a9): padded single sequence
+        from dataloaders.encode_dataset import EncodeDataset
+        binf = os.path.join(tmp, "seq", "f0.bin")
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            res = RDP.proc_pc(binf, os.path.join(tmp, "pp2"), "f0", qs=400 / (2 ** 12 - 1), test=True, spher=True)
+            ds = EncodeDataset([binf], 1024, "kitti", False, 12, True)
+            ds.preproc = lambda f: (res[0], res[2], 0.0, res[3], 0.0)
+            ids, pos, data, oct_seq, npt, bin_num, _, _ = ds[0]
+        finally:
+            os.chdir(cwd)
+        assert len(data) == 1
+        save("ctx_octattn_spher_L12", xyz=xyz, data=data[0].astype(np.int16), pos=pos[0], ids=ids[0].astype(np.int32),
+             oct_seq=oct_seq.astype(np.int32), bin_num=np.float64(bin_num))
+
+        # mullevel EHEM dataset (three shells)
+        from dataloaders.encode_dataset_ehem_mullevel import EncodeEHEMDataset as MulDS
+        os.chdir(tmp)
+        try:
+            L = 14
+            outs = []
+            for qsl, path in ((L, [0, 0]), (L + 1, [0, 1]), (L + 2, [1])):
+                outs.append(RDP.mul_proc_pc(binf, os.path.join(tmp, "ppm"), "f0", qs=400 / (2 ** qsl - 1), test=True,
+                                            spher=True, morton_path=path))
+            ds = MulDS([binf], 8192, "kitti", True, L, False, True)
+            wq = np.vstack([o[1] for o in outs])
+            ds.preproc = lambda f: ([o[0] for o in outs], outs[0][2], 0.0, outs[0][3], outs[0][4], 0.0)
+            item = ds[0]
+        finally:
+            os.chdir(cwd)
+        ids, poss, pos_mm, data, oct_seq = item[:5]
+        out = {"xyz": xyz, "n_levels": np.int32(len(data)), "oct_seq": oct_seq.astype(np.int32),
+               "bin_num": np.float64(item[7]), "z_offset": np.float64(item[8]), "quant_pc": wq.astype(np.float32),
+               "pos_mm": np.array(pos_mm, np.int64)}
+        for l in range(len(data)):
+            out[f"data{l}"] = data[l].astype(np.int16)
+            out[f"pos{l}"] = poss[l]
+            out[f"ids{l}"] = ids[l].astype(np.int32)
+        save(f"ctx_ehem_mul_spher_L{L}", **out)
+
+
+# ----------------------------------------------------------------------------- models
+def build_ref_ehem(seed=0):
+    from models.ehem import EHEM
+    m = EHEM(_ref_env.ehem_cfg()).eval()
+    fill_weights(m, seed)
+    return m
+
+
+def build_ref_octattn(seed=0):
+    from models.oct_attention import OctAttention
+    m = OctAttention(_ref_env.octattn_cfg()).eval()
+    fill_weights(m, seed)
+    return m
+
+
+def level_windows_from_ctx(name):
+    z = np.load(os.path.join(HERE, name + ".npz"))
+    n = int(z["n_levels"])
+    return [(z[f"data{l}"].astype(np.int64), z[f"pos{l}"]) for l in range(n)]
+
+
+def gen_logits():
+    print("[logits]")
+    m = build_ref_ehem(0)
+    levels = level_windows_from_ctx("ctx_ehem_spher_L12")
+    sizes = [len(d) for d, _ in levels]
+    print("   level sizes", sizes)
+    big = max(range(len(levels)), key=lambda i: sizes[i])
+    cases = {}
+    # c = 1 (root), a tiny odd level, a mid level, and slices of the biggest level
+    cases["c1"] = levels[0]
+    for want in (7, 600, 1024):
+        d, p = levels[big]
+        cases[f"c{want}"] = (d[:want], p[:, :want])
+    lv_small = min((i for i in range(len(levels)) if 2 < sizes[i] < 200), key=lambda i: sizes[i])
+    cases[f"lvl{lv_small}_c{sizes[lv_small]}"] = levels[lv_small]
+    with torch.no_grad():
+        for tag, (d, p) in cases.items():
+            o1, o2 = m(torch.from_numpy(d)[None].clone(), torch.from_numpy(p)[None].clone(), enc=True)
+            save(f"logits_ehem_{tag}", data=d.astype(np.int16), pos=p, out1=o1[0].numpy(), out2=o2[0].numpy(),
+                 seed=np.int32(0))
+        # batched call (B=2) pins the batch semantics of knn / windows
+        d, p = levels[big]
+        dd = np.stack([d[:256], d[256:512]])
+        pp = np.stack([p[:, :256], p[:, 256:512]])
+        o1, o2 = m(torch.from_numpy(dd).clone(), torch.from_numpy(pp).clone(), enc=True)
+        save("logits_ehem_b2_c256", data=dd.astype(np.int16), pos=pp, out1=o1.numpy(), out2=o2.numpy(), seed=np.int32(0))
+
+    # full 8192 window from the 120k frame (rows subsampled to keep the fixture small)
+    xyz = synth_frame(0)
+    _, _, q, _ = quantise_like_proc_pc(xyz, 400 / (2 ** 12 - 1), "spher")
+    pt = np.unique(q, axis=0).astype(int)
+    tree = so_gen_octree(pt)
+    # fast K-record construction is NOT available from the reference; use its own (slow) routine once
+    rec_d = RO.gen_K_parent_seq(tree, 4)
+    rec = np.concatenate((rec_d["Seq"][:, :, True], rec_d["Level"], rec_d["Pos"]), axis=2)
+    rec[:, :, 0] -= 1
+    lv = rec[:, -1, 1]
+    last = lv.max()
+    sel = np.where(lv == last)[0]
+    blk = rec[sel]
+    dat = np.concatenate((blk[:, :, 1:3], blk[:, :, :1]), axis=2)
+    cp = blk[:, -1, 3:6]
+    pos = ((cp - cp.min()) / (cp.max() - cp.min() + 1e-9)).astype(np.float32).T
+    d8, p8 = dat[:8192], np.ascontiguousarray(pos[:, :8192])
+    with torch.no_grad():
+        o1, o2 = m(torch.from_numpy(d8)[None].clone(), torch.from_numpy(p8)[None].clone(), enc=True)
+    save("logits_ehem_c8192", data=d8.astype(np.int16), pos=p8, out1_sub=o1[0, ::16].numpy(), out2_sub=o2[0, ::16].numpy(),
+         out1_sha=np.array(sha(o1.numpy())), seed=np.int32(0), stride=np.int32(16))
+
+    mo = build_ref_octattn(0)
+    z = np.load(os.path.join(HERE, "ctx_octattn_spher_L12.npz"))
+    data, pos = z["data"].astype(np.int64), z["pos"]
+    with torch.no_grad():
+        for tag, sl in (("c1", slice(1023, 1024)), ("c300", slice(1023, 1323)), ("c1024", slice(1024, 2048)),
+                        ("c1024pad", slice(0, 1024))):
+            d, p = data[sl], pos[sl]
+            o = mo(torch.from_numpy(d)[None].clone(), torch.from_numpy(p)[None].clone())
+            save(f"logits_octattn_{tag}", data=d.astype(np.int16), pos=p, out=o[0].numpy(), seed=np.int32(0))
+
+
+def gen_swin():
+    print("[swin]")
+    from models.swin_transformer import SwinLayer, SwinConfig, SwinPatchMerging
+    cfg = SwinConfig(num_channels=256, embed_dim=256, depths=[2], num_heads=[4], window_size=512)
+    for cross in (False, True):
+        for shift in (0, 256):
+            layer = SwinLayer(cfg, 256, 8192, 4, shift_size=shift, cross=cross).eval()
+            fill_weights(layer, 7)
+            for L in (2, 3, 511, 512, 513, 1024, 1500):
+                rng = np.random.default_rng(1000 + L)
+                x = rng.standard_normal((1, L, 256), dtype=np.float32)
+                q = rng.standard_normal((1, L, 256), dtype=np.float32)
+                with torch.no_grad():
+                    y = layer(torch.from_numpy(x), L, query=torch.from_numpy(q) if cross else None)[0]
+                stride = 1 if L <= 16 else 7
+                save(f"swin_{'cross' if cross else 'self'}_s{shift}_L{L}", x_seed=np.int32(1000 + L),
+                     x_head=x[0, :2], y=y[0, ::stride].numpy(), stride=np.int32(stride), wseed=np.int32(7))
+    pm = SwinPatchMerging(8192, 256).eval()
+    fill_weights(pm, 8)
+    for L in (2, 3, 513):
+        rng = np.random.default_rng(2000 + L)
+        x = rng.standard_normal((1, L, 256), dtype=np.float32)
+        with torch.no_grad():
+            y = pm(torch.from_numpy(x), L)
+        save(f"swin_merge_L{L}", x_seed=np.int32(2000 + L), y=y[0].numpy(), wseed=np.int32(8))
+
+
+# ----------------------------------------------------------------------------- cdf / ac
+def make_pmfs(rng, n):
+    rows = []
+    for i in range(n):
+        kind = i % 5
+        if kind == 0:
+            lg = rng.standard_normal(255) * 4
+        elif kind == 1:
+            lg = np.zeros(255)
+        elif kind == 2:
+            lg = rng.standard_normal(255) * 0.1
+            lg[rng.integers(0, 255)] += 30
+        elif kind == 3:
+            lg = rng.standard_normal(255) * 12
+        else:
+            lg = rng.standard_normal(255)
+            lg[rng.integers(0, 255, 100)] = -200.0  # exact zeros after softmax
+        p = torch.softmax(torch.from_numpy(lg.astype(np.float32)), 0).numpy()
+        rows.append(p)
+    return np.stack(rows).astype(np.float32)
+
+
+def ref_cdf_int(pdf):
+    import numpyAc.numpyAc as NA
+    cdfF = NA.pdf_convert_to_cdf_and_normalize(pdf)
+    return NA._convert_to_int_and_normalize(cdfF, True)
+
+
+def gen_cdf():
+    print("[cdf]")
+    rng = np.random.default_rng(5)
+    pdf = make_pmfs(rng, 64)
+    cdf = ref_cdf_int(pdf)
+    assert cdf.dtype == np.int16 and cdf.shape == (64, 256)
+    save("cdf_mixed", pdf=pdf, cdf=cdf.view(np.uint16))
+
+
+def gen_ac():
+    print("[ac]")
+    import numpyAc.numpyAc as NA
+    rng = np.random.default_rng(6)
+    out = {}
+    for n in (1, 2, 1000, 100000):
+        base = make_pmfs(rng, min(n, 300))
+        reps = -(-n // len(base))
+        pdf = np.tile(base, (reps, 1))[:n]   # consumers rebuild pdf by tiling `pdfbase` the same way
+        # symbols: mostly sampled from the PMF, with forced 254s and a long run on a ~1/2-probability symbol
+        cdfF = np.cumsum(pdf.astype(np.float64), 1)
+        u = rng.random(n)
+        sym = np.minimum((cdfF < u[:, None] * cdfF[:, -1:]).sum(1), 254).astype(np.int16)
+        sym[:: max(1, n // 7)] = 254
+        sym[0] = 254 if n > 1 else 17
+        codec = NA.arithmeticCoding()
+        bs, bits = codec.encode(pdf, sym, None)
+        cdf = ref_cdf_int(pdf).view(np.uint16)
+        dec = NA.arithmeticDeCoding(bs, n, 255, None)
+        back = [dec.decode(pdf[i:i + 1]) for i in range(min(n, 3000))] if n > 1 else []
+        assert back == sym[: len(back)].tolist()
+        out[f"n{n}_pdfbase"] = base
+        if n <= 1000:
+            out[f"n{n}_cdfbase"] = cdf[:300]
+            out[f"n{n}_bytes"] = np.frombuffer(bs, np.uint8)
+        else:
+            out[f"n{n}_sha"] = np.array(hashlib.sha256(bs).hexdigest())
+            out[f"n{n}_head"] = np.frombuffer(bs[:64], np.uint8)
+            out[f"n{n}_tail"] = np.frombuffer(bs[-64:], np.uint8)
+            out[f"n{n}_len"] = np.int64(len(bs))
+        out[f"n{n}_sym"] = sym
+    # pending-bit stress: two symbols with probability ~1/2 each straddling the midpoint
+    n = 4000
+    pdf = np.full((n, 255), 1e-9, np.float32)
+    pdf[:, 100] = 0.5
+    pdf[:, 101] = 0.5
+    sym = np.where(np.arange(n) % 2 == 0, 100, 101).astype(np.int16)
+    bs, _ = NA.arithmeticCoding().encode(pdf, sym, None)
+    out["pend_pdf_row"] = pdf[0]
+    out["pend_sym"] = sym
+    out["pend_bytes"] = np.frombuffer(bs, np.uint8)
+    save("ac_streams", **out)
+
+
+# ----------------------------------------------------------------------------- end-to-end (reference driver)
+def gen_e2e():
+    """Run the reference's own compress_ehem / compress drivers on CPU (Tensor.cuda patched to identity)."""
+    print("[e2e]")
+    import types
+    hy = types.ModuleType("hydra")
+    hy.initialize = lambda **k: None
+    hy.compose = lambda **k: None
+    sys.modules.setdefault("hydra", hy)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    import numpyAc.numpyAc as NA
+    sys.modules["numpyAc"].arithmeticCoding = NA.arithmeticCoding
+    sys.path.insert(0, _ref_env.REF)
+    import importlib
+    enc = importlib.import_module("encode")
+    encm = importlib.import_module("encode_mullevel")
+    from torch.utils.data import DataLoader
+
+    captured = {}
+    orig_encode = NA.arithmeticCoding.encode
+
+    def spy(self, pdf, sym, binfile=None):
+        captured["pdf"] = pdf.copy()
+        captured["sym"] = sym.copy()
+        return orig_encode(self, pdf, sym, binfile)
+
+    NA.arithmeticCoding.encode = spy
+
+    class A:
+        spher = True
+        cylin = False
+        sequential = False
+
+    xyz = frame5k(0)
+    model = build_ref_ehem(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        binf = os.path.join(tmp, "seq", "f0.bin")
+        os.makedirs(os.path.dirname(binf))
+        write_kitti_bin(binf, xyz)
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            # ---- same-level EHEM, L12 --spher
+            from dataloaders.encode_dataset_ehem import EncodeEHEMDataset
+            res = RDP.proc_pc(binf, os.path.join(tmp, "pp"), "f0", qs=400 / (2 ** 12 - 1), test=True, spher=True)
+            ds = EncodeEHEMDataset([binf], 8192, "kitti", True, 12, False, True)
+            ds.preproc = lambda f: (res[0], res[2], 0.25, res[3], 33.0)
+            batch = next(iter(DataLoader(ds, batch_size=1, shuffle=False)))
+            bpp, _ = enc.compress_ehem(batch[:-2], os.path.join(tmp, "out", "seqf0"), model, A)
+            outs = [f for f in os.listdir(os.path.join(tmp, "out")) if f.endswith(".bin")]
+            assert len(outs) == 1
+            bs = open(os.path.join(tmp, "out", outs[0]), "rb").read()
+            dat = torch.load(os.path.join(tmp, "out", outs[0] + ".dat")).numpy()
+            pdf = captured["pdf"]
+            save("e2e_ehem_spher_L12", xyz=xyz, fname=np.array(outs[0]), bytes=np.frombuffer(bs, np.uint8),
+                 dat=dat, sym_coded=captured["sym"], pdf_sub=pdf[::37], pdf_stride=np.int32(37),
+                 bpp=np.float64(bpp), n_nodes=np.int64(len(pdf)),
+                 cdf_sha=np.array(sha(ref_cdf_int(pdf))), pdf_sha=np.array(sha(pdf)), wseed=np.int32(0))
+            print("   same-level bpp", bpp, "bytes", len(bs), outs[0])
+
+            # ---- mullevel EHEM, L14 --spher
+            from dataloaders.encode_dataset_ehem_mullevel import EncodeEHEMDataset as MulDS
+            L = 14
+            outs3 = []
+            for qsl, path in ((L, [0, 0]), (L + 1, [0, 1]), (L + 2, [1])):
+                outs3.append(RDP.mul_proc_pc(binf, os.path.join(tmp, "ppm"), "f0", qs=400 / (2 ** qsl - 1), test=True,
+                                             spher=True, morton_path=path))
+            ds = MulDS([binf], 8192, "kitti", True, L, False, True)
+            ds.preproc = lambda f: ([o[0] for o in outs3], outs3[0][2], 0.25, outs3[0][3], outs3[0][4], 33.0)
+            batch = next(iter(DataLoader(ds, batch_size=1, shuffle=False)))
+            bpp, _ = encm.compress_ehem(batch[:-2], os.path.join(tmp, "outm", "seqf0"), model, A)
+            outs = [f for f in os.listdir(os.path.join(tmp, "outm")) if f.endswith(".bin")]
+            bs = open(os.path.join(tmp, "outm", outs[0]), "rb").read()
+            dat = torch.load(os.path.join(tmp, "outm", outs[0] + ".dat")).numpy()
+            pdf = captured["pdf"]
+            save("e2e_ehem_mul_spher_L14", xyz=xyz, fname=np.array(outs[0]), bytes=np.frombuffer(bs, np.uint8),
+                 dat=dat, sym_coded=captured["sym"], pdf_sub=pdf[::37], pdf_stride=np.int32(37),
+                 bpp=np.float64(bpp), n_nodes=np.int64(len(pdf)),
+                 cdf_sha=np.array(sha(ref_cdf_int(pdf))), pdf_sha=np.array(sha(pdf)), wseed=np.int32(0))
+            print("   mullevel bpp", bpp, "bytes", len(bs), outs[0])
+
+            # ---- OctAttention, L12 --spher (reference `compress`)
+            from dataloaders.encode_dataset import EncodeDataset
+            mo = build_ref_octattn(0)
+            res = RDP.proc_pc(binf, os.path.join(tmp, "pp3"), "f0", qs=400 / (2 ** 12 - 1), test=True, spher=True)
+            ds = EncodeDataset([binf], 1024, "kitti", False, 12, True)
+            ds.preproc = lambda f: (res[0], res[2], 0.25, res[3], 33.0)
+            batch = next(iter(DataLoader(ds, batch_size=1, shuffle=False)))
+            bpp, _ = enc.compress(batch[:-2], os.path.join(tmp, "outo", "f0"), mo, A)
+            bs = open(os.path.join(tmp, "outo", "f0.bin"), "rb").read()
+            pdf = captured["pdf"]
+            save("e2e_octattn_spher_L12", xyz=xyz, bytes=np.frombuffer(bs, np.uint8), sym_coded=captured["sym"],
+                 pdf_sub=pdf[::37], pdf_stride=np.int32(37), bpp=np.float64(bpp), n_nodes=np.int64(len(pdf)),
+                 cdf_sha=np.array(sha(ref_cdf_int(pdf))), wseed=np.int32(0))
+            print("   octattn bpp", bpp, "bytes", len(bs))
+        finally:
+            os.chdir(cwd)
+            NA.arithmeticCoding.encode = orig_encode
+
+
+# ----------------------------------------------------------------------------- full-frame facts
+def gen_facts():
+    """Full 120k-point frame structure facts + checksums, from the reference."""
+    print("[facts]")
+    facts = {}
+    xyz = synth_frame(0)
+
+    def same(mode, L, key, cloud=xyz, qs=None):
+        qs = 400 / (2 ** L - 1) if qs is None else qs
+        _, bin_num, q, off = quantise_like_proc_pc(cloud, qs, mode)
+        pt = np.unique(q, axis=0).astype(int)
+        tree = so_gen_octree(pt)
+        codes = np.array([tree.code[i] for i in range(len(tree.code))], np.uint8)
+        per = [len(tree[i]) for i in range(len(tree))]
+        facts[key] = dict(bin_num=bin_num, U=int(len(pt)), D=len(tree), N=int(len(codes)), per_level=per,
+                          max_ints=[int(v) for v in pt.max(0)], codes_sha=sha(codes), pts_sha=sha(pt.astype(np.int32)))
+        print("   ", key, facts[key]["N"], per)
+        return tree
+
+    tree = same("spher", 12, "L12-s")
+    rec_d = RO.gen_K_parent_seq(tree, 4)
+    rec = np.concatenate((rec_d["Seq"][:, :, True], rec_d["Level"], rec_d["Pos"]), axis=2)
+    facts["L12-s"]["krec_sha_i32"] = sha(rec.astype(np.int32))
+    same("spher", 16, "L16-s")
+    same("cylin", 14, "C14")
+    same("cart", 12, "L12-c")
+    with open(os.path.join(HERE, "frame_facts.json"), "w") as f:
+        json.dump(facts, f, indent=1)
+
+    # mullevel: pure-Python reference octree is slow (~50 s) - run once
+    for key, cloud, qss in (("L16-m", xyz, [400 / (2 ** l - 1) for l in (16, 17, 18)]),):
+        shells = []
+        for qs, path in zip(qss, ([0, 0], [0, 1], [1])):
+            _, bin_num, q, off = quantise_like_proc_pc(cloud, qs, "spher")
+            _, idx = np.unique(q, axis=0, return_index=True)
+            pt = q[np.sort(idx)]
+            codes, tree, lmax, idxs = RO.mullevel_gen_octree(pt, morton_path=path)
+            rec_d = RO.gen_K_parent_seq_mullevel(tree, 4)
+            rec = np.concatenate((rec_d["Seq"][:, :, True], rec_d["Level"], rec_d["Pos"]), axis=2)
+            shells.append(dict(bin_num=float(bin_num), leaves=int(len(idxs)), D=int(lmax), records=int(len(rec)),
+                               codes_sha=sha(np.array(codes, np.uint8)), krec_sha_i32=sha(rec.astype(np.int32)),
+                               per_level=[len(l.node) for l in tree]))
+            print("   ", key, path, shells[-1]["records"])
+        facts[key] = shells
+        with open(os.path.join(HERE, "frame_facts.json"), "w") as f:
+            json.dump(facts, f, indent=1)
+
+
+GROUPS = {"xform": gen_xform, "oct": gen_oct, "ctx": gen_ctx, "logits": gen_logits, "swin": gen_swin,
+          "cdf": gen_cdf, "ac": gen_ac, "e2e": gen_e2e, "facts": gen_facts}
+
+if __name__ == "__main__":
+    want = sys.argv[1:] or list(GROUPS)
+    for g in want:
+        GROUPS[g]()
