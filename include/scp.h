@@ -1,0 +1,206 @@
+/*
+ * scp.h - C ABI of libscp_hip.so, the MI355X-native SCP encode hot path.
+ *
+ * Every entry point is plain C (pointers + sizes, no torch / pybind types).  Device pointers are
+ * HIP device addresses; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * All functions return 0 on success or a negative SCP_E* code; nothing aborts the process.
+ *
+ * Each block names the reference interface it replaces (paths relative to luoao-kddi/SCP).
+ * INTEGRATION.md shows the binding a reference maintainer would add for each.
+ */
+#ifndef SCP_H
+#define SCP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCP_API __attribute__((visibility("default")))
+
+#define SCP_OK 0
+#define SCP_EINVAL (-1)   /* bad argument (NULL, negative size, depth 0, coordinate < 0 ...) */
+#define SCP_ENOMEM (-2)   /* host or device allocation failed                               */
+#define SCP_ESMALL (-3)   /* caller-provided output buffer too small                        */
+#define SCP_EHIP (-4)     /* a HIP runtime call failed (scp_last_hip_error() has the code)   */
+#define SCP_ESTATE (-5)   /* calls made out of order on a handle                            */
+
+#define SCP_MAX_DEPTH 21      /* 3*21 = 63 Morton bits                     */
+#define SCP_MAX_SEGMENTS 62   /* trees built by one scp_geom_build call    */
+
+SCP_API int scp_version(void);
+SCP_API int scp_last_hip_error(void);
+/* number of HIP devices visible / name of device 0 (for bench reports) */
+SCP_API int scp_device_count(void);
+SCP_API int scp_device_name(char *buf, int cap);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage G1 - coordinate transform + quantiser
+ * replaces: data_preproc/data_preprocess.py:40-68 (proc_pc) / :107-137 (mul_proc_pc),
+ *           cart2spher :200-207, cart2cylin :171-177
+ * ---------------------------------------------------------------------------------------------- */
+enum { SCP_CART = 0, SCP_SPHER = 1, SCP_CYLIN = 2 };
+
+typedef struct scp_quant_info {
+    double bin_num;      /* round(rho_max/qs)+1 (0 for SCP_CART)            */
+    double qs[3];        /* per-axis step actually used                      */
+    double offset[3];    /* per-axis offset subtracted before dividing       */
+    int32_t max_coord;   /* max over all points and axes of the integers     */
+    int32_t min_coord;   /* min (negative => the cloud does not fit: error)  */
+} scp_quant_info;
+
+/* xyz: device float32 [n][3].  q_out: device int32 [n][3].  tr_out (optional, may be NULL): device
+ * float32 [n][3] transformed coordinates (rho,phi,theta | rho,phi,z).  Synchronises `stream`
+ * internally once (rho_max feeds the step sizes) and fills *info on the host. */
+SCP_API int scp_quantize(const float *xyz, int64_t n, int32_t mode, double qs, double cart_offset,
+                 int32_t *q_out, float *tr_out, scp_quant_info *info, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage G2 - octree serialisation (Morton keys -> radix sort -> per-level nodes -> occupancy)
+ * replaces: data_preproc/OctreeCPP/Octree_python_lib.so `genOctreeInterface`
+ *           (Octreewarpper.py:17-39,67-71), data_preproc/Octree.py:148-181 (GenOctree),
+ *           :184-221 (mullevel_gen_octree), :102-137 / :224-272 (gen_K_parent_seq[_mullevel])
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct scp_geom scp_geom; /* opaque: owns device workspace, reusable across frames */
+
+typedef struct scp_segment {
+    int64_t point_begin;  /* slice [begin, begin+count) of the q array                        */
+    int64_t point_count;
+    int32_t path_len;     /* rho-shell filter (Octree.py:188): 0 = keep all                   */
+    int32_t path_bits;    /* path[0] is the MOST significant of the path_len low bits         */
+    int32_t drop_last;    /* 1: the context tables omit the last BFS node (Octree.py:259-262) */
+    int32_t reserved;
+} scp_segment;
+
+typedef struct scp_segment_info {
+    int32_t depth;        /* D = ceil(log2(max+1)) over the unfiltered slice (Octree.py:58)   */
+    int32_t max_coord;
+    int64_t n_leaves;     /* distinct points kept                                             */
+    int64_t n_nodes;      /* all tree nodes (= length of the occupancy code list)             */
+    int64_t node_base;    /* first node of this segment in the concatenated tables            */
+    int64_t level_count[SCP_MAX_DEPTH + 1]; /* [l] = nodes at tree level l+1                   */
+} scp_segment_info;
+
+SCP_API int scp_geom_create(scp_geom **out);
+SCP_API int scp_geom_destroy(scp_geom *g);
+
+/* q: device int32 [n][3], non-negative.  Builds every segment's tree structure (sort + counting)
+ * and reports sizes; synchronises `stream` internally.  info: host array [nseg]. */
+SCP_API int scp_geom_build(scp_geom *g, const int32_t *q, int64_t n, const scp_segment *segs, int32_t nseg,
+                   scp_segment_info *info, void *stream);
+
+/* Node tables of the last build, all segments concatenated (segment s starts at node_base[s];
+ * inside a segment nodes are in BFS order = level by level, Morton order inside a level).
+ * Every pointer is a device buffer of total_nodes elements and may be NULL to skip that column.
+ *   occ    uint8  1..255  child-occupancy byte (= the code stream, Octreewarpper.py:71)
+ *   level  uint8  1..D
+ *   octant uint8  1..8
+ *   parent int32  index of the parent node in the concatenated table, -1 for a root
+ *   pos    int32 [total][3] node origin in leaf units (Octree.py:140-145)                      */
+SCP_API int scp_geom_emit_nodes(scp_geom *g, uint8_t *occ, uint8_t *level, uint8_t *octant, int32_t *parent,
+                        int32_t *pos, void *stream);
+
+/* leaves (distinct quantised points) of segment `seg` in Morton order: device int32 [n_leaves][3] */
+SCP_API int scp_geom_emit_leaves(scp_geom *g, int32_t seg, int32_t *pts, void *stream);
+
+/* The reference's on-disk record (data_preprocess.py:74,81): int64 [rows][4][6] with channels
+ * (occ 1..256, level, octant, x, y, z) for (great-grandparent, grandparent, parent, self).
+ * rows = n_nodes - drop_last of segment `seg`.  out: device int64. */
+SCP_API int scp_geom_krecords_i64(scp_geom *g, int32_t seg, int64_t *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage G3 - per-node context for the models
+ * replaces: dataloaders/encode_dataset_ehem.py:52-105, encode_dataset_ehem_mullevel.py:47-85 (EHEM),
+ *           dataloaders/encode_dataset.py:32-55 (OctAttention)
+ * ---------------------------------------------------------------------------------------------- */
+enum { SCP_POS_MINMAX = 0,       /* (p-min)/(max-min+1e-9), scalar min/max per level (spher/cylin) */
+       SCP_POS_MINMAX_MUL = 1,   /* same, but the LAST level divides by (max-min) (mul:80)        */
+       SCP_POS_POW2 = 2 };       /* p / 2^max_level (Cartesian, ehem:74)                           */
+
+/* For segment `seg`, rows = n_nodes - drop_last:
+ *   ctx    uint8 [rows][12]  (level, octant, occ-1 | 255) x (ggp, gp, p, self); levels of the LAST
+ *                            tree level are clipped to lidar_level (ehem:86)
+ *   pos    float32 [rows][3] normalised self position (row-major; the model API transposes)
+ *   sym    uint8 [rows]      occ-1 = the symbol the arithmetic coder encodes
+ *   pos_mm int64 [D][2]      (min,max) per level - DEVICE pointer, may be NULL                   */
+SCP_API int scp_geom_context_ehem(scp_geom *g, int32_t seg, int32_t pos_mode, int32_t lidar_level,
+                          uint8_t *ctx, float *pos, uint8_t *sym, int64_t *pos_mm, void *stream);
+
+/* OctAttention: ctx uint8 [rows][12] = (occ-1|255, level, octant) x 4; pos float32 [rows][4][3] =
+ * xyz / 2^D for all four rows (no front padding - the window kernel pads on the fly). */
+SCP_API int scp_geom_context_octattn(scp_geom *g, int32_t seg, uint8_t *ctx, float *pos, uint8_t *sym, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage M - context-model kernels (fp32).  Layouts are row-major, "tokens x channels".
+ * replaces the op sequences of models/dgcnn.py:10-71, models/swin_transformer.py:443-501,625-697,
+ * models/attention_model.py:58-95 (see DESIGN.md for the mapping)
+ * ---------------------------------------------------------------------------------------------- */
+/* k nearest neighbours in feature space, per batch item: x [B][n][C] -> idx int32 [B][n][k],
+ * the k largest of  2*xi.xj - |xj|^2 - |xi|^2  (dgcnn.py:18-20), ties -> lower index. */
+SCP_API int scp_knn_topk(const float *x, int32_t B, int32_t n, int32_t C, int32_t k, int32_t *idx, void *stream);
+
+/* edge-conv tail: out[b][i][c] = lrelu_0.2( scale[c] * (sel_j u[b][idx[b][i][j]][c] + v[b][i][c]) + shift[c] ),
+ * sel = max when scale[c] >= 0 else min  (== max over j of BN(conv(edge feature)), dgcnn.py:62-71,132-134) */
+SCP_API int scp_edge_gather_max(const float *u, const float *v, const int32_t *idx, const float *scale, const float *shift,
+                        int32_t B, int32_t n, int32_t Cout, int32_t k, float *out, int32_t out_stride, void *stream);
+
+/* 1-D Swin window attention (window 512, 4 heads x 64): q [B][Lp][ldq], k,v [B][Lp][ldkv] already projected
+ * (row strides in floats, >= 256: the operands may be column slices of a fused QKV buffer), Lp a
+ * multiple of 512 (zero rows beyond L were padded AFTER LayerNorm, so their q/k/v equal the biases);
+ * `shift` in {0,256}: the kernel applies the cyclic roll, the -100 mask of the last window and the
+ * relative-position bias table [1023][4]; out [B][Lp][256] in un-rolled token order. */
+SCP_API int scp_swin_attention(const float *q, const float *k, const float *v, const float *bias_table,
+                       int32_t B, int32_t Lp, int32_t shift, int32_t ldq, int32_t ldkv, float *out, void *stream);
+
+/* OctAttention dual-stream causal attention (attention_model.py:58-95): heads of width hd,
+ * q_u,k,k_u,v,v_u [B][c][H*hd] -> out, out_u [B][c][H*hd] */
+SCP_API int scp_octattn_attention(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
+                          int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage C - softmax -> integer CDF, on device
+ * replaces: torch.softmax at encode.py:126-127 + numpyAc/numpyAc.py:109-114,80-107
+ * ---------------------------------------------------------------------------------------------- */
+/* logits [n][nsym] (row stride `ld` floats) -> pmf [n][nsym] (may be NULL) and, if sym != NULL,
+ * lohi [n]: low 16 bits = cdf[sym], high 16 bits = cdf[sym+1] (0 encodes 65536 for the top symbol).
+ * cdf_full (may be NULL): uint16 [n][nsym+1] complete table (decoder / tests). */
+SCP_API int scp_softmax_cdf(const float *logits, int64_t ld, int64_t n, int32_t nsym, const uint8_t *sym,
+                    float *pmf, uint32_t *lohi, uint16_t *cdf_full, void *stream);
+/* same, starting from a float32 PMF table (bit-exact numpyAc integer CDF) */
+SCP_API int scp_pmf_cdf(const float *pmf, int64_t n, int32_t nsym, const uint8_t *sym, uint32_t *lohi,
+                uint16_t *cdf_full, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Range coder (host, serial) - replaces numpyAc/backend/numpyAc_backend.cpp
+ *   encode_cdf :327-334 / encode :245-323  ->  scp_ac_encode_cdf, scp_ac_encode_lohi
+ *   class decode :134-217                  ->  scp_ac_dec_*
+ * ---------------------------------------------------------------------------------------------- */
+SCP_API int scp_ac_encode_cdf(const uint16_t *cdf, const int16_t *sym, int64_t n, int32_t Lp, uint8_t *out, size_t cap,
+                      size_t *out_len);
+SCP_API int scp_ac_encode_lohi(const uint32_t *lohi, int64_t n, uint8_t *out, size_t cap, size_t *out_len);
+typedef struct scp_ac_dec scp_ac_dec;
+SCP_API int scp_ac_dec_new(scp_ac_dec **d, const uint8_t *stream, size_t len, int32_t Lp);
+SCP_API int scp_ac_dec_next(scp_ac_dec *d, const uint16_t *cdf_row); /* returns the symbol (>= 0) */
+SCP_API int scp_ac_dec_free(scp_ac_dec *d);
+
+/* ------------------------------------------------------------------------------------------------
+ * Legacy octree ABI - the ten symbols data_preproc/OctreeCPP/Octreewarpper.py:17-39 binds, so the
+ * reference's own wrapper can load libscp_hip.so in place of Octree_python_lib.so.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct scp_legacy_node { uint32_t nodeid, octant, parent; uint8_t oct; uint32_t pos[3]; } scp_legacy_node;
+SCP_API void *new_vector(void);
+SCP_API void delete_vector(void *v);
+SCP_API int vector_size(void *v);
+SCP_API void *vector_get(void *v, int level);
+SCP_API void vector_push_back(void *v, int i);
+SCP_API void *genOctreeInterface(void *v, const double *xyz, int n);
+SCP_API int Nodes_size(void *level);
+SCP_API scp_legacy_node *Nodes_get(void *level, int i);
+SCP_API int int_size(void *codes);
+SCP_API int int_get(void *codes, int i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCP_H */

@@ -1,0 +1,49 @@
+"""Build recipe for libscp_hip.so (hipcc, gfx950 only, in-tree so the .so travels with the snapshot)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libscp_hip.so")
+SOURCES = ["api.cpp", "geom.hip", "sort_u64.hip", "cdf.hip", "rangecoder.cpp", "legacy_octree.cpp",
+           "knn.hip", "edge.hip", "attn.hip", "octattn.hip", "gemm.hip", "fused.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-result", "-fvisibility=hidden", "-x", "hip"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "scp.h")]
+    objs = []
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    procs = []
+    for s in srcs:
+        o = os.path.join(CSRC, "build", os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((s, subprocess.Popen(cmd)))
+    bad = [s for s, p in procs if p.wait() != 0]
+    if bad:
+        raise RuntimeError("hipcc failed for: " + ", ".join(bad))
+    if force or procs or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

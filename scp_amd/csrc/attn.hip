@@ -1,0 +1,148 @@
+// 1-D Swin window attention, flash-style, float32 MFMA (gfx950 / CDNA4, wave64).
+//
+// Replaces models/swin_transformer.py:443-501 (Attention.forward) together with the roll / window partition /
+// -100 shift mask / relative-position-bias plumbing of SwinLayer (:603-652, :684-697):
+//   scores[i][j] = q_i.k_j / 8 + table[i - j + 511][head] (+ -100 where the last shifted window mixes its two halves)
+//   out_i        = softmax_j(scores) . v_j          window = 512 tokens, 4 heads x 64
+// q/k/v come already projected, [B][Lp][>=256] with row strides ldq / ldkv (so they may be column slices of one fused
+// QKV GEMM output); Lp % 512 == 0 (rows beyond the sequence hold the projection biases,
+// exactly what the reference's zero padding AFTER LayerNorm produces).  The cyclic shift is index arithmetic.
+//
+// Work decomposition: one workgroup (4 waves) = 128 queries of one (window, head); a wave owns 32 queries.
+// Both products run on v_mfma_f32_32x32x2_f32 with the QUERY on the MFMA column (= lane & 31):
+//   S^T[key][q] = sum_d K[key][d] Q[q][d]      A = K tile from LDS, B = Q fragment held in 32 registers
+//   O^T[d][q]   = sum_key V[key][d] P[q][key]  A = V tile from LDS, B = the S^T accumulator registers themselves
+// so the softmax statistics and the O rescale are lane-local and P never leaves the register file.  The k index of
+// each product is permuted consistently on both operands (sums are order-free): lane half h covers head dims
+// 32h..32h+31 in QK^T and the keys its own accumulator rows hold in PV.
+#include "scp_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WIN 512
+#define HD 64
+#define NH 4
+#define QT 128   // queries per workgroup
+#define KT 64    // keys per staged tile
+#define LDK 68   // K tile row stride (floats): conflict-free ds_read_b128, 16-B aligned rows
+
+__global__ __launch_bounds__(256, 2) void swin_attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                          const float *__restrict__ v, const float *__restrict__ table,
+                                                          int Lp, int shift, int ldq, int ldkv, float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float Ks[KT * LDK];
+    __shared__ __attribute__((aligned(16))) float Vs[KT * HD];
+    __shared__ float tab[2 * WIN - 1];
+
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, col = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    const int qtile = bid & 3; bid >>= 2;
+    const int head = bid & 3; bid >>= 2;
+    const int nW = Lp / WIN;
+    const int wnd = bid % nW, b = bid / nW;
+    const size_t base = (size_t)b * Lp * (NH * HD) + head * HD;        // output (dense [B][Lp][256])
+    const size_t qbase = (size_t)b * Lp * ldq + head * HD, kbase = (size_t)b * Lp * ldkv + head * HD;
+    const bool masked = (shift > 0) && (wnd == nW - 1);
+
+    for (int i = tid; i < 2 * WIN - 1; i += 256) tab[i] = table[i * NH + head];
+
+    // Q fragment: query qi (position in window), head dims 32h .. 32h+31, pre-scaled by 1/8 (exact)
+    const int qi = qtile * QT + w * 32 + col;
+    const int qtok = (wnd * WIN + qi + shift) % Lp;
+    float qf[32];
+    {
+        const float4 *src = (const float4 *)(q + qbase + (size_t)qtok * ldq + 32 * h);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 t = src[g];
+            qf[4 * g] = t.x * 0.125f; qf[4 * g + 1] = t.y * 0.125f; qf[4 * g + 2] = t.z * 0.125f; qf[4 * g + 3] = t.w * 0.125f;
+        }
+    }
+    f32x16 o0, o1;   // O^T rows d = 0..31 and 32..63 (row = (r&3) + 8*(r>>2) + 4h), column = query
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const int qreg = qi >> 8;  // half of the window the query sits in (mask region)
+
+    for (int kt = 0; kt < WIN / KT; ++kt) {
+        __syncthreads();  // previous tile consumed (also orders the `tab` fill before first use)
+        // stage K and V rows of keys kt*64 .. +63 : 64 rows x 16 float4 each
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = tid + it * 256;
+            const int r = e >> 4, c4 = e & 15;
+            const int ktok = (wnd * WIN + kt * KT + r + shift) % Lp;
+            const size_t g = kbase + (size_t)ktok * ldkv + 4 * c4;
+            const float4 kv = *(const float4 *)(k + g);
+            const float4 vv = *(const float4 *)(v + g);
+            *(float4 *)(Ks + r * LDK + 4 * c4) = kv;
+            *(float4 *)(Vs + r * HD + 4 * c4) = vv;
+        }
+        __syncthreads();
+        const float madd = (masked && ((kt * KT) >> 8) != qreg) ? -100.f : 0.f;
+
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            // ---- S^T = K . Q^T for 32 keys -----------------------------------------------------------------
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const float *krow = Ks + (sub * 32 + col) * LDK + 32 * h;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 kk = *(const float4 *)(krow + 4 * g);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qf[4 * g], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qf[4 * g + 1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qf[4 * g + 2], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qf[4 * g + 3], s, 0, 0, 0);
+            }
+            // ---- bias, mask, online softmax (lane-local: this lane's 16 keys + partner half's 16) -----------
+            const int j0 = kt * KT + sub * 32 + 4 * h;  // key position of accumulator row 0 of this lane
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + (r & 3) + 8 * (r >> 2);
+                s[r] = s[r] + tab[qi - j + (WIN - 1)] + madd;
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_new); ps += s[r]; }
+            ps += __shfl_xor(ps, 32);
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            // ---- O^T += V^T . P^T : step r pairs key (r&3)+8(r>>2)+4h of both operands -----------------------
+            const float *vbase = Vs + (sub * 32 + 4 * h) * HD + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float *vr = vbase + ((r & 3) + 8 * (r >> 2)) * HD;
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], s[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], s[r], o1, 0, 0, 0);
+            }
+        }
+    }
+    // ---- normalise and store: lane = query, accumulator rows = head dims -----------------------------------
+    const float inv = 1.0f / l_run;
+    float *dst = out + base + (size_t)qtok * (NH * HD);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int d = 8 * g + 4 * h;
+        *(float4 *)(dst + d) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        *(float4 *)(dst + 32 + d) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+}
+
+extern "C" int scp_swin_attention(const float *q, const float *k, const float *v, const float *bias_table, int32_t B, int32_t Lp,
+                                  int32_t shift, int32_t ldq, int32_t ldkv, float *out, void *stream) {
+    if (!q || !k || !v || !bias_table || !out || B <= 0 || Lp <= 0 || (Lp % WIN) != 0 || (shift != 0 && shift != WIN / 2) ||
+        ldq < NH * HD || ldkv < NH * HD || (ldq & 3) || (ldkv & 3) || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15))
+        return SCP_EINVAL;
+    const int nblk = B * (Lp / WIN) * NH * (WIN / QT);
+    hipLaunchKernelGGL(swin_attn_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, q, k, v, bias_table, Lp, shift, ldq, ldkv, out);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}

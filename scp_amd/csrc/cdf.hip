@@ -1,0 +1,105 @@
+// Stage C: softmax -> numpyAc integer CDF on device (gfx950).
+//
+// numpyAc defines the integer CDF through a SERIAL float32 cumsum (numpyAc/numpyAc.py:111), so the prefix
+// sums cannot be re-associated: one lane walks one row.  A wavefront stages 64 rows in LDS with coalesced
+// loads (row stride 255 dwords is odd -> conflict-free for ds_read_b32), each lane then makes its serial
+// passes out of LDS.  Only (cdf[sym], cdf[sym+1]) leave the chip on the encode path: 4 B/node instead of the
+// reference's 1020 B PMF row + 512 B CDF row over PCIe.
+#include "scp_internal.h"
+
+#define ROWS 64
+#define MAXSYM 255
+
+template <bool FROM_LOGITS>
+__global__ __launch_bounds__(64) void cdf_kernel(const float *__restrict__ in, int64_t ld, int64_t n, int nsym,
+                                                 const uint8_t *__restrict__ sym, float *__restrict__ pmf_out,
+                                                 uint32_t *__restrict__ lohi, uint16_t *__restrict__ cdf_full) {
+    __shared__ float tile[ROWS * MAXSYM];
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    const int nrow = (int)((n - row0) < ROWS ? (n - row0) : ROWS);
+    const int total = nrow * nsym;
+    // coalesced stage-in
+    if (ld == nsym) {
+        const float *src = in + row0 * ld;
+        for (int i = lane; i < total; i += 64) tile[i] = src[i];
+    } else {
+        for (int i = lane; i < total; i += 64) { const int r = i / nsym, c = i - r * nsym; tile[i] = in[(row0 + r) * ld + c]; }
+    }
+    __syncthreads();
+    float *row = tile + lane * nsym;
+    float c_lo = 0.f, c_hi = 0.f, c_last = 1.f;
+    int s = 0;
+    if (lane < nrow) {
+        if (FROM_LOGITS) {
+            float m = row[0];
+            for (int j = 1; j < nsym; ++j) m = fmaxf(m, row[j]);
+            float sum = 0.f;
+            for (int j = 0; j < nsym; ++j) { const float e = expf(row[j] - m); row[j] = e; sum += e; }
+            for (int j = 0; j < nsym; ++j) row[j] = (float)((double)row[j] / (double)sum);  // the PMF this library defines (float32)
+        }
+    }
+    __syncthreads();
+    if (FROM_LOGITS && pmf_out) {
+        float *dst = pmf_out + row0 * nsym;
+        for (int i = lane; i < total; i += 64) dst[i] = tile[i];
+        __syncthreads();
+    }
+    if (lane < nrow) {
+        s = sym ? (int)sym[row0 + lane] : 0;
+        // numpyAc.py:111 serial float32 cumsum; keep F[s] and F[s+1] (F[0] = 0, F[k] = c[k-1])
+        float c = 0.f;
+        for (int j = 0; j < nsym; ++j) {
+            c = __fadd_rn(c, row[j]);
+            if (cdf_full) row[j] = c;
+            if (j == s - 1) c_lo = c;
+            if (j == s) c_hi = c;
+        }
+        c_last = c;
+        if (lohi) {
+            // :112 c / c[-1] in float32, :113 -> float64, :101-103 * 65281, rint, wrap, :106 + arange
+            const double scale = (double)(65536 - nsym);
+            const uint32_t lo = (s == 0) ? 0u : ((uint32_t)(int64_t)rint((double)(float)((double)c_lo / (double)c_last) * scale) + (uint32_t)s) & 0xFFFFu;
+            uint32_t hi = ((uint32_t)(int64_t)rint((double)(float)((double)c_hi / (double)c_last) * scale) + (uint32_t)(s + 1)) & 0xFFFFu;
+            if (s == nsym - 1) hi = 0u;  // 0 encodes 0x10000 (numpyAc_backend.cpp:277)
+            lohi[row0 + lane] = lo | (hi << 16);
+        }
+    }
+    if (cdf_full) {
+        __syncthreads();
+        const double scale = (double)(65536 - nsym);
+        const int Lp = nsym + 1;
+        for (int i = lane; i < nrow * Lp; i += 64) {
+            const int r = i / Lp, k = i - r * Lp;
+            uint32_t v = 0;
+            if (k > 0) {
+                const float last = tile[r * nsym + nsym - 1];
+                v = ((uint32_t)(int64_t)rint((double)(float)((double)tile[r * nsym + k - 1] / (double)last) * scale) + (uint32_t)k) & 0xFFFFu;
+            }
+            cdf_full[(row0 + r) * Lp + k] = (uint16_t)v;
+        }
+    }
+}
+
+static int launch(bool from_logits, const float *in, int64_t ld, int64_t n, int32_t nsym, const uint8_t *sym, float *pmf,
+                  uint32_t *lohi, uint16_t *cdf_full, void *stream) {
+    if (n == 0) return SCP_OK;
+    if (!in || n < 0 || nsym < 2 || nsym > MAXSYM || ld < nsym) return SCP_EINVAL;
+    if (lohi && !sym) return SCP_EINVAL;
+    const int nb = (int)cdiv64(n, ROWS);
+    hipStream_t st = (hipStream_t)stream;
+    if (from_logits) hipLaunchKernelGGL(cdf_kernel<true>, dim3(nb), dim3(64), 0, st, in, ld, n, nsym, sym, pmf, lohi, cdf_full);
+    else hipLaunchKernelGGL(cdf_kernel<false>, dim3(nb), dim3(64), 0, st, in, ld, n, nsym, sym, pmf, lohi, cdf_full);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+extern "C" int scp_softmax_cdf(const float *logits, int64_t ld, int64_t n, int32_t nsym, const uint8_t *sym, float *pmf,
+                               uint32_t *lohi, uint16_t *cdf_full, void *stream) {
+    return launch(true, logits, ld, n, nsym, sym, pmf, lohi, cdf_full, stream);
+}
+
+extern "C" int scp_pmf_cdf(const float *pmf, int64_t n, int32_t nsym, const uint8_t *sym, uint32_t *lohi, uint16_t *cdf_full,
+                           void *stream) {
+    return launch(false, pmf, nsym, n, nsym, sym, nullptr, lohi, cdf_full, stream);
+}

@@ -1,0 +1,49 @@
+// Edge-conv tail: neighbour gather + max, fused with BatchNorm(eval) and LeakyReLU(0.2) (gfx950).
+//
+// Reference (models/dgcnn.py:48-71,132-134): feature[i][j] = cat(f_j - f_i, f_i) for the k neighbours j, 1x1 conv W,
+// BatchNorm, LeakyReLU(0.2), max over j.  With W = [W1 | W2]:  W.cat(f_j - f_i, f_i) = W1 f_j + (W2 - W1) f_i, so
+// the conv is two [n x C] x [C x C'] GEMMs (u = F W1^T, v = F (W2-W1)^T, done once per point instead of k = 20
+// times) and BN/LeakyReLU are monotone per channel, hence
+//     max_j act(scale*(u_j + v_i) + shift) = act(scale * (sel_j u_j + v_i) + shift),  sel = max if scale >= 0 else min.
+// This kernel is the gather: k rows of C' floats per point, 16 B per lane, rows served from L2 / Infinity Cache.
+#include "scp_internal.h"
+
+__global__ __launch_bounds__(256) void edge_gather_max_kernel(const float *__restrict__ u, const float *__restrict__ v,
+                                                             const int *__restrict__ idx, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, int n, int Cout, int k,
+                                                             float *__restrict__ out, int out_stride, int64_t total /* B*n*Cout/4 */) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const int c4 = Cout >> 2;
+    const int64_t pt = g / c4;          // global point index b*n + i
+    const int c = (int)(g - pt * c4) * 4;
+    const int64_t b = pt / n;
+    const float *ub = u + b * (int64_t)n * Cout;
+    const int *nb = idx + pt * k;
+    float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    for (int j = 0; j < k; ++j) {
+        const float4 a = *(const float4 *)(ub + (int64_t)nb[j] * Cout + c);
+        mx.x = fmaxf(mx.x, a.x); mx.y = fmaxf(mx.y, a.y); mx.z = fmaxf(mx.z, a.z); mx.w = fmaxf(mx.w, a.w);
+        mn.x = fminf(mn.x, a.x); mn.y = fminf(mn.y, a.y); mn.z = fminf(mn.z, a.z); mn.w = fminf(mn.w, a.w);
+    }
+    const float4 vi = *(const float4 *)(v + pt * Cout + c);
+    const float4 sc = *(const float4 *)(scale + c), sh = *(const float4 *)(shift + c);
+    float4 r;
+#define FIN(f) { const float y = __fadd_rn(__fmul_rn(sc.f, __fadd_rn(sc.f >= 0.f ? mx.f : mn.f, vi.f)), sh.f); r.f = y > 0.f ? y : __fmul_rn(0.2f, y); }
+    FIN(x) FIN(y) FIN(z) FIN(w)
+#undef FIN
+    *(float4 *)(out + pt * out_stride + c) = r;
+}
+
+extern "C" int scp_edge_gather_max(const float *u, const float *v, const int32_t *idx, const float *scale, const float *shift,
+                                   int32_t B, int32_t n, int32_t Cout, int32_t k, float *out, int32_t out_stride, void *stream) {
+    if (!u || !v || !idx || !scale || !shift || !out || B <= 0 || n <= 0 || Cout <= 0 || (Cout & 3) || k <= 0 || out_stride < Cout ||
+        (out_stride & 3) || ((uintptr_t)out & 15))
+        return SCP_EINVAL;
+    const int64_t total = (int64_t)B * n * (Cout / 4);
+    hipLaunchKernelGGL(edge_gather_max_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, u, v, idx, scale,
+                       shift, n, Cout, k, out, out_stride, total);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}

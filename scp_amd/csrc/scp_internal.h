@@ -1,0 +1,46 @@
+// Internal helpers shared by the libscp_hip translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/scp.h"
+
+#define SCP_WAVE 64
+
+extern int g_scp_last_hip_error;
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) {                        \
+            g_scp_last_hip_error = (int)_e;            \
+            return SCP_EHIP;                           \
+        }                                              \
+    } while (0)
+
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// growable device buffer owned by a handle
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return SCP_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { g_scp_last_hip_error = (int)e; p = nullptr; return SCP_ENOMEM; }
+        cap = want;
+        return SCP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+// sort_u64.hip: stable LSD radix sort of 64-bit keys on the bit ranges [lo, lo+nb) listed in passes.
+// keys_in is overwritten (ping-pong); *result points at whichever buffer holds the sorted keys.
+struct RadixWorkspace { DevBuf counts; };
+int scp_radix_sort_u64(uint64_t *keys_a, uint64_t *keys_b, int64_t n, const int *pass_lo, const int *pass_bits,
+                       int npass, RadixWorkspace *ws, hipStream_t st, uint64_t **result);

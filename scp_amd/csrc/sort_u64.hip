@@ -1,0 +1,138 @@
+// Stable LSD radix sort of 64-bit Morton keys (gfx950, wave64).
+//
+// One pass = histogram -> exclusive scan of the [digit][tile] table -> scatter.  A tile is 4096
+// consecutive keys owned by one 256-thread workgroup; wave w of the workgroup owns the contiguous
+// quarter [w*1024, (w+1)*1024) and walks it in 16 rounds of 64 keys, so a key's stable rank inside its
+// (tile, digit) bucket is   sum over lower waves of their digit count  +  its rank inside its wave,
+// and the rank inside a wave comes from a wavefront match-any built out of `__ballot` (64-bit masks)
+// and per-wave LDS digit counters.  No inter-workgroup communication inside a launch.
+#include "scp_internal.h"
+
+#define TILE 4096
+#define WG 256
+#define ROUNDS 16  // TILE / WG * (WG/64) / 4 waves = 1024 keys per wave / 64
+
+__global__ __launch_bounds__(WG) void radix_hist_kernel(const uint64_t *__restrict__ keys, int64_t n, int lo,
+                                                       uint32_t mask, uint32_t *__restrict__ counts, int ntiles) {
+    __shared__ uint32_t hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * TILE;
+#pragma unroll 4
+    for (int r = 0; r < TILE / WG; ++r) {
+        int64_t i = base + r * WG + threadIdx.x;
+        if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> lo) & mask], 1u);
+    }
+    __syncthreads();
+    counts[(int64_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+// exclusive scan of `m` uint32 counters, single workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *__restrict__ counts, int64_t m) {
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int64_t chunk = (m + 1023) / 1024;
+    const int64_t b = (int64_t)t * chunk, e = (b + chunk < m) ? b + chunk : m;
+    uint32_t s = 0;
+    for (int64_t i = b; i < e; ++i) s += counts[i];
+    part[t] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (t >= off) ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (int64_t i = b; i < e; ++i) {
+        uint32_t c = counts[i];
+        counts[i] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(WG) void radix_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                          int64_t n, int lo, int nb, const uint32_t *__restrict__ offs,
+                                                          int ntiles) {
+    __shared__ uint32_t wcnt[4][256];
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const uint32_t mask = (1u << nb) - 1u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wcnt[i][t] = 0;
+    __syncthreads();
+
+    const int64_t wbase = (int64_t)blockIdx.x * TILE + (int64_t)w * (TILE / 4);
+    uint64_t key[ROUNDS];
+    uint32_t rank[ROUNDS];
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int64_t i = wbase + r * 64 + lane;
+        const bool valid = i < n;
+        key[r] = valid ? in[i] : 0ull;
+        const uint32_t d = (uint32_t)(key[r] >> lo) & mask;
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < nb; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t vote = __ballot(bit);
+            peers &= bit ? vote : ~vote;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & lt);
+        const uint32_t cnt = (uint32_t)__popcll(peers);
+        uint32_t prev = 0;
+        if (valid) prev = ((volatile uint32_t *)wcnt[w])[d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0) ((volatile uint32_t *)wcnt[w])[d] = prev + cnt;
+        __builtin_amdgcn_wave_barrier();
+        rank[r] = prev + before;
+    }
+    __syncthreads();
+    // digit t: turn the four per-wave totals into start offsets (global bucket start + lower waves)
+    {
+        uint32_t g = offs[(int64_t)t * ntiles + blockIdx.x];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t c = wcnt[i][t];
+            wcnt[i][t] = g;
+            g += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int64_t i = wbase + r * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(key[r] >> lo) & mask;
+            out[(int64_t)wcnt[w][d] + rank[r]] = key[r];
+        }
+    }
+}
+
+void scp_launch_scan_u32(uint32_t *counts, int64_t m, hipStream_t st) {
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, counts, m);
+}
+
+int scp_radix_sort_u64(uint64_t *keys_a, uint64_t *keys_b, int64_t n, const int *pass_lo, const int *pass_bits,
+                       int npass, RadixWorkspace *ws, hipStream_t st, uint64_t **result) {
+    *result = keys_a;
+    if (n <= 1 || npass == 0) return SCP_OK;
+    const int ntiles = (int)cdiv64(n, TILE);
+    int rc = ws->counts.reserve((size_t)256 * ntiles * sizeof(uint32_t));
+    if (rc) return rc;
+    uint32_t *counts = ws->counts.as<uint32_t>();
+    uint64_t *src = keys_a, *dst = keys_b;
+    for (int p = 0; p < npass; ++p) {
+        const int lo = pass_lo[p], nb = pass_bits[p];
+        if (nb < 1 || nb > 8) return SCP_EINVAL;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(WG), 0, st, src, n, lo, (1u << nb) - 1u, counts, ntiles);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, counts, (int64_t)256 * ntiles);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(WG), 0, st, src, dst, n, lo, nb, counts, ntiles);
+        LAUNCH_CHECK();
+        uint64_t *tmp = src; src = dst; dst = tmp;
+    }
+    *result = src;
+    return SCP_OK;
+}

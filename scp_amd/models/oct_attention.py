@@ -1,0 +1,120 @@
+"""OctAttention context model on MI355X (drop-in for models/oct_attention.py + models/attention_model.py).
+
+`OctAttention(cfg).forward(data, pos)` with data int64 [B,c,4,3] = (occ, level, octant) x (ggp, gp, p, self) and
+pos float32 [B,c,4,3] returns logits [B,c,255].  state_dict keys match the reference.
+The dual-stream causal attention of attention_model.py:58-95 runs in one HIP kernel (csrc/octattn.hip); unlike
+the reference, forward() is a pure function (it does not edit `data` in place, Appendix B-13).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import native
+from ..ops import linear
+
+
+class _PosEnc(nn.Module):
+    def __init__(self, d_model, max_len):
+        super().__init__()
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe)
+
+
+class _Attn(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.mlp_key = nn.Linear(d, d)
+        self.mlp_query = nn.Linear(d, d)
+        self.mlp_value = nn.Linear(d, d)
+
+
+class _Layer(nn.Module):
+    def __init__(self, d, hid):
+        super().__init__()
+        self.attn = _Attn(d)
+        self.linear1 = nn.Linear(d, hid)
+        self.linear2 = nn.Linear(hid, d)
+        self.norm1 = nn.LayerNorm(d, eps=1e-5)
+        self.norm2 = nn.LayerNorm(d, eps=1e-5)
+
+
+class _Transformer(nn.Module):
+    def __init__(self, d, hid, n_layers, ctx):
+        super().__init__()
+        self.layers = nn.ModuleList([_Layer(d, hid) for _ in range(n_layers)])
+        self.position_enc = _PosEnc(d, ctx)
+
+
+class OctAttention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        m = cfg.model
+        self.heads = m.head_num
+        self.embed_dimension = 4 * (m.occ_embed_dim + m.level_embed_dim + m.octant_embed_dim + m.abs_pos_embed_dim)
+        self.transformer_encoder = _Transformer(self.embed_dimension, m.hidden_dimension, m.layer_num, m.context_size)
+        self.occ_enc = nn.Embedding(m.token_num + 1, m.occ_embed_dim)
+        self.level_enc = nn.Embedding(m.max_octree_level + 1, m.level_embed_dim)
+        self.octant_enc = nn.Embedding(9, m.octant_embed_dim)
+        self.abs_pos_embed_dim = m.abs_pos_embed_dim
+        if self.abs_pos_embed_dim:
+            self.abs_pos_enc = nn.Linear(3, self.abs_pos_embed_dim)
+        self.decoder0 = nn.Linear(self.embed_dimension, self.embed_dimension)
+        self.decoder1 = nn.Linear(self.embed_dimension, m.token_num)
+        mask = (torch.triu(torch.ones(m.context_size, m.context_size)) == 1).transpose(0, 1)
+        self.register_buffer("mask", mask.float().masked_fill(mask == 0, float("-inf")).masked_fill(mask == 1, 0.0))
+        self.eval()
+
+    @classmethod
+    def load_from_checkpoint(cls, path, cfg=None, map_location="cpu"):
+        m = cls(cfg)
+        sd = torch.load(path, map_location=map_location)
+        m.load_state_dict(sd["state_dict"] if "state_dict" in sd else sd, strict=True)
+        return m
+
+    @torch.no_grad()
+    def forward(self, data, pos=None):
+        if not data.is_cuda:
+            raise native.ScpError("OctAttention runs on the MI355X only (no CPU fallback)")
+        B, c = data.shape[:2]
+        data = data.long()
+        occ, level, octant = data[..., 0], data[..., 1], data[..., 2]
+        cap = 10 if self.cfg.train.type == "obj" else 12
+        level = level - torch.clip(level[:, :, -1:] - cap, 0, None)           # oct_attention.py:57-61, out of place
+        level = torch.clip(level, 0, self.cfg.model.max_octree_level)
+        oe = F.embedding(occ, self.occ_enc.weight)
+        ue = oe.clone()
+        ue[:, :, -1] = self.occ_enc.weight[255]
+        le = F.embedding(level, self.level_enc.weight)
+        te = F.embedding(octant, self.octant_enc.weight)
+        parts, parts_u = [oe, le, te], [ue, le, te]
+        if self.abs_pos_embed_dim:
+            pe = linear(pos, self.abs_pos_enc.weight, self.abs_pos_enc.bias)
+            parts.append(pe)
+            parts_u.append(pe)
+        D = self.embed_dimension
+        emb = torch.cat(parts, 3).reshape(B, c, D) * math.sqrt(D)
+        emu = torch.cat(parts_u, 3).reshape(B, c, D) * math.sqrt(D)
+        tab = self.transformer_encoder.position_enc.pe[:c]
+        emb, emu = emb + tab, emu + tab
+        for lyr in self.transformer_encoder.layers:
+            a = lyr.attn
+            key, key_u = linear(emb, a.mlp_key.weight, a.mlp_key.bias), linear(emu, a.mlp_key.weight, a.mlp_key.bias)
+            q_u = linear(emu, a.mlp_query.weight, a.mlp_query.bias)
+            val, val_u = linear(emb, a.mlp_value.weight, a.mlp_value.bias), linear(emu, a.mlp_value.weight, a.mlp_value.bias)
+            out, out_u = native.octattn_attention(q_u.contiguous(), key.contiguous(), key_u.contiguous(), val.contiguous(),
+                                                  val_u.contiguous(), self.heads)
+            emb = F.layer_norm(out + emb, (D,), lyr.norm1.weight, lyr.norm1.bias, 1e-5)
+            emu = F.layer_norm(out_u + emu, (D,), lyr.norm1.weight, lyr.norm1.bias, 1e-5)
+            emb = F.layer_norm(emb + linear(torch.relu(linear(emb, lyr.linear1.weight, lyr.linear1.bias)),
+                                            lyr.linear2.weight, lyr.linear2.bias), (D,), lyr.norm2.weight, lyr.norm2.bias, 1e-5)
+            emu = F.layer_norm(emu + linear(torch.relu(linear(emu, lyr.linear1.weight, lyr.linear1.bias)),
+                                            lyr.linear2.weight, lyr.linear2.bias), (D,), lyr.norm2.weight, lyr.norm2.bias, 1e-5)
+        return linear(torch.relu(linear(emu, self.decoder0.weight, self.decoder0.bias)), self.decoder1.weight,
+                      self.decoder1.bias)

@@ -1,0 +1,346 @@
+"""ctypes binding of libscp_hip.so (include/scp.h).
+
+PyTorch appears here only as the owner of device memory and of the HIP stream; every call below goes
+through the C ABI with raw device pointers.  There is NO fallback: if the library is missing or a
+call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libscp_hip.so")
+MAX_DEPTH = 21
+
+CART, SPHER, CYLIN = 0, 1, 2
+POS_MINMAX, POS_MINMAX_MUL, POS_POW2 = 0, 1, 2
+_ERR = {-1: "SCP_EINVAL", -2: "SCP_ENOMEM", -3: "SCP_ESMALL", -4: "SCP_EHIP", -5: "SCP_ESTATE"}
+
+
+class ScpError(RuntimeError):
+    pass
+
+
+class QuantInfo(C.Structure):
+    _fields_ = [("bin_num", C.c_double), ("qs", C.c_double * 3), ("offset", C.c_double * 3),
+                ("max_coord", C.c_int32), ("min_coord", C.c_int32)]
+
+
+class Segment(C.Structure):
+    _fields_ = [("point_begin", C.c_int64), ("point_count", C.c_int64), ("path_len", C.c_int32),
+                ("path_bits", C.c_int32), ("drop_last", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SegmentInfo(C.Structure):
+    _fields_ = [("depth", C.c_int32), ("max_coord", C.c_int32), ("n_leaves", C.c_int64), ("n_nodes", C.c_int64),
+                ("node_base", C.c_int64), ("level_count", C.c_int64 * (MAX_DEPTH + 1))]
+
+
+_lib = None
+_vp = C.c_void_p
+
+
+def lib():
+    """Load libscp_hip.so; raises if it has not been built (python -m scp_amd.build / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ScpError(f"{LIB_PATH} is missing: run `python scp_amd/build.py` (hipcc, gfx950). "
+                       "The SCP hot path has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    i32, i64 = C.c_int32, C.c_int64
+    sig = {
+        "scp_version": (C.c_int, []),
+        "scp_last_hip_error": (C.c_int, []),
+        "scp_device_count": (C.c_int, []),
+        "scp_device_name": (C.c_int, [C.c_char_p, C.c_int]),
+        "scp_quantize": (C.c_int, [_vp, i64, i32, C.c_double, C.c_double, _vp, _vp, C.POINTER(QuantInfo), _vp]),
+        "scp_geom_create": (C.c_int, [C.POINTER(_vp)]),
+        "scp_geom_destroy": (C.c_int, [_vp]),
+        "scp_geom_build": (C.c_int, [_vp, _vp, i64, C.POINTER(Segment), i32, C.POINTER(SegmentInfo), _vp]),
+        "scp_geom_emit_nodes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+        "scp_geom_emit_leaves": (C.c_int, [_vp, i32, _vp, _vp]),
+        "scp_geom_krecords_i64": (C.c_int, [_vp, i32, _vp, _vp]),
+        "scp_geom_context_ehem": (C.c_int, [_vp, i32, i32, i32, _vp, _vp, _vp, _vp, _vp]),
+        "scp_geom_context_octattn": (C.c_int, [_vp, i32, _vp, _vp, _vp, _vp]),
+        "scp_knn_topk": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp]),
+        "scp_edge_gather_max": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
+        "scp_swin_attention": (C.c_int, [_vp, _vp, _vp, _vp, i32, i32, i32, i32, i32, _vp, _vp]),
+        "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
+        "scp_softmax_cdf": (C.c_int, [_vp, i64, i64, i32, _vp, _vp, _vp, _vp, _vp]),
+        "scp_pmf_cdf": (C.c_int, [_vp, i64, i32, _vp, _vp, _vp, _vp]),
+        "scp_ac_encode_cdf": (C.c_int, [_vp, _vp, i64, i32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "scp_ac_encode_lohi": (C.c_int, [_vp, i64, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "scp_ac_dec_new": (C.c_int, [C.POINTER(_vp), _vp, C.c_size_t, i32]),
+        "scp_ac_dec_next": (C.c_int, [_vp, _vp]),
+        "scp_ac_dec_free": (C.c_int, [_vp]),
+    }
+    for name, (res, args) in sig.items():
+        if hasattr(L, name):
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc < 0:
+        extra = f" (hipError {lib().scp_last_hip_error()})" if rc == -4 else ""
+        raise ScpError(f"{what} failed: {_ERR.get(rc, rc)}{extra}")
+    return rc
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, dtype=None):
+    if not t.is_cuda:
+        raise ScpError("device tensor expected (the SCP hot path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise ScpError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ScpError("contiguous tensor expected")
+    return t.data_ptr()
+
+
+def _opt(t):
+    return None if t is None else _dev(t)
+
+
+# ------------------------------------------------------------------------------------------------- stage G1
+def quantize(xyz, mode, qs, cart_offset=-200.0, want_transformed=False):
+    """xyz cuda float32 [n,3] -> (q cuda int32 [n,3], QuantInfo, transformed or None)."""
+    n = xyz.shape[0]
+    q = torch.empty((n, 3), dtype=torch.int32, device=xyz.device)
+    tr = torch.empty((n, 3), dtype=torch.float32, device=xyz.device) if want_transformed else None
+    info = QuantInfo()
+    rc = lib().scp_quantize(_dev(xyz, torch.float32), n, mode, float(qs), float(cart_offset), _dev(q), _opt(tr),
+                            C.byref(info), _stream())
+    _check(rc, "scp_quantize")
+    return q, info, tr
+
+
+# ------------------------------------------------------------------------------------------------- stage G2/G3
+class Geom:
+    """Owns one scp_geom workspace (reusable across frames)."""
+
+    def __init__(self):
+        self._h = _vp()
+        _check(lib().scp_geom_create(C.byref(self._h)), "scp_geom_create")
+        self.info = []
+        self.device = None
+
+    def close(self):
+        if self._h:
+            lib().scp_geom_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build(self, q, segments):
+        """q cuda int32 [n,3]; segments: list of (begin, count, path(list of bits) or None, drop_last)."""
+        nseg = len(segments)
+        segs = (Segment * nseg)()
+        for i, (b, c, path, drop) in enumerate(segments):
+            path = list(path or [])
+            bits = 0
+            for p in path:
+                bits = (bits << 1) | int(p)
+            segs[i] = Segment(int(b), int(c), len(path), bits, int(bool(drop)), 0)
+        infos = (SegmentInfo * nseg)()
+        rc = lib().scp_geom_build(self._h, _dev(q, torch.int32), q.shape[0], segs, nseg, infos, _stream())
+        _check(rc, "scp_geom_build")
+        self.info = list(infos)
+        self.segments = segments
+        self.device = q.device
+        self.total_nodes = sum(i.n_nodes for i in self.info)
+        return self.info
+
+    def level_counts(self, seg):
+        i = self.info[seg]
+        return [int(i.level_count[l]) for l in range(i.depth)]
+
+    def nodes(self, want=("occ", "level", "octant", "parent", "pos")):
+        N, dev = self.total_nodes, self.device
+        out = {}
+        if "occ" in want:
+            out["occ"] = torch.empty(N, dtype=torch.uint8, device=dev)
+        if "level" in want:
+            out["level"] = torch.empty(N, dtype=torch.uint8, device=dev)
+        if "octant" in want:
+            out["octant"] = torch.empty(N, dtype=torch.uint8, device=dev)
+        if "parent" in want:
+            out["parent"] = torch.empty(N, dtype=torch.int32, device=dev)
+        if "pos" in want:
+            out["pos"] = torch.empty((N, 3), dtype=torch.int32, device=dev)
+        rc = lib().scp_geom_emit_nodes(self._h, _opt(out.get("occ")), _opt(out.get("level")), _opt(out.get("octant")),
+                                       _opt(out.get("parent")), _opt(out.get("pos")), _stream())
+        _check(rc, "scp_geom_emit_nodes")
+        return out
+
+    def leaves(self, seg):
+        pts = torch.empty((self.info[seg].n_leaves, 3), dtype=torch.int32, device=self.device)
+        _check(lib().scp_geom_emit_leaves(self._h, seg, _dev(pts), _stream()), "scp_geom_emit_leaves")
+        return pts
+
+    def rows(self, seg):
+        return int(self.info[seg].n_nodes) - int(bool(self.segments[seg][3]))
+
+    def krecords(self, seg):
+        out = torch.empty((self.rows(seg), 4, 6), dtype=torch.int64, device=self.device)
+        _check(lib().scp_geom_krecords_i64(self._h, seg, _dev(out), _stream()), "scp_geom_krecords_i64")
+        return out
+
+    def context_ehem(self, seg, pos_mode, lidar_level):
+        r, dev = self.rows(seg), self.device
+        ctx = torch.empty((r, 12), dtype=torch.uint8, device=dev)
+        pos = torch.empty((r, 3), dtype=torch.float32, device=dev)
+        sym = torch.empty(r, dtype=torch.uint8, device=dev)
+        mm = torch.empty((self.info[seg].depth, 2), dtype=torch.int64, device=dev)
+        rc = lib().scp_geom_context_ehem(self._h, seg, pos_mode, lidar_level, _dev(ctx), _dev(pos), _dev(sym), _dev(mm),
+                                         _stream())
+        _check(rc, "scp_geom_context_ehem")
+        return ctx, pos, sym, mm
+
+    def context_octattn(self, seg):
+        r, dev = self.rows(seg), self.device
+        ctx = torch.empty((r, 12), dtype=torch.uint8, device=dev)
+        pos = torch.empty((r, 4, 3), dtype=torch.float32, device=dev)
+        sym = torch.empty(r, dtype=torch.uint8, device=dev)
+        _check(lib().scp_geom_context_octattn(self._h, seg, _dev(ctx), _dev(pos), _dev(sym), _stream()),
+               "scp_geom_context_octattn")
+        return ctx, pos, sym
+
+
+# ------------------------------------------------------------------------------------------------- stage M
+def knn_topk(x, k):
+    """x cuda f32 [B,n,C] -> idx int32 [B,n,k]."""
+    B, n, Cc = x.shape
+    idx = torch.empty((B, n, k), dtype=torch.int32, device=x.device)
+    _check(lib().scp_knn_topk(_dev(x, torch.float32), B, n, Cc, k, _dev(idx), _stream()), "scp_knn_topk")
+    return idx
+
+
+def edge_gather_max(u, v, idx, scale, shift, out=None):
+    """u,v [B,n,C'] f32, idx [B,n,k] i32, scale/shift [C'] -> out [B,n,C'] (may be a column slice of a wider tensor)."""
+    B, n, Co = u.shape
+    k = idx.shape[2]
+    if out is None:
+        out = torch.empty((B, n, Co), dtype=torch.float32, device=u.device)
+    stride = out.stride(1)
+    if out.stride(2) != 1 or out.stride(0) != n * stride:
+        raise ScpError("edge_gather_max: out must be row-major with unit channel stride")
+    rc = lib().scp_edge_gather_max(_dev(u, torch.float32), _dev(v, torch.float32), _dev(idx, torch.int32), _dev(scale),
+                                   _dev(shift), B, n, Co, k, out.data_ptr(), stride, _stream())
+    _check(rc, "scp_edge_gather_max")
+    return out
+
+
+def swin_attention(q, k, v, bias_table, shift):
+    """q,k,v cuda f32 [B,Lp,256] views (unit channel stride, Lp % 512 == 0), bias_table [1023,4] -> out [B,Lp,256]."""
+    B, Lp, _ = q.shape
+    for t in (q, k, v):
+        if t.stride(2) != 1 or t.stride(0) != Lp * t.stride(1) or not t.is_cuda or t.dtype != torch.float32:
+            raise ScpError("swin_attention: operands must be [B,Lp,256] views with unit channel stride")
+    if k.stride(1) != v.stride(1):
+        raise ScpError("swin_attention: k and v must share a row stride")
+    out = torch.empty((B, Lp, 256), dtype=torch.float32, device=q.device)
+    rc = lib().scp_swin_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), _dev(bias_table, torch.float32), B, Lp, shift,
+                                  q.stride(1), k.stride(1), _dev(out), _stream())
+    _check(rc, "scp_swin_attention")
+    return out
+
+
+def octattn_attention(q_u, k, k_u, v, v_u, heads):
+    B, c, D = q_u.shape
+    out, out_u = torch.empty_like(q_u), torch.empty_like(q_u)
+    rc = lib().scp_octattn_attention(_dev(q_u), _dev(k), _dev(k_u), _dev(v), _dev(v_u), B, c, heads, D // heads,
+                                     _dev(out), _dev(out_u), _stream())
+    _check(rc, "scp_octattn_attention")
+    return out, out_u
+
+
+# ------------------------------------------------------------------------------------------------- stage C
+def softmax_cdf(logits, sym=None, want_pmf=False, want_lohi=True, want_cdf=False):
+    """logits cuda f32 [n,nsym] (row stride allowed) -> dict(pmf, lohi, cdf)."""
+    n, nsym = logits.shape
+    if logits.stride(1) != 1:
+        raise ScpError("softmax_cdf: unit column stride expected")
+    dev = logits.device
+    pmf = torch.empty((n, nsym), dtype=torch.float32, device=dev) if want_pmf else None
+    lohi = torch.empty(n, dtype=torch.int32, device=dev) if (want_lohi and sym is not None) else None
+    cdf = torch.empty((n, nsym + 1), dtype=torch.int16, device=dev) if want_cdf else None
+    rc = lib().scp_softmax_cdf(logits.data_ptr(), logits.stride(0), n, nsym, _opt(sym), _opt(pmf), _opt(lohi), _opt(cdf),
+                               _stream())
+    _check(rc, "scp_softmax_cdf")
+    return dict(pmf=pmf, lohi=lohi, cdf=cdf)
+
+
+def pmf_cdf(pmf, sym=None, want_cdf=False):
+    n, nsym = pmf.shape
+    dev = pmf.device
+    lohi = torch.empty(n, dtype=torch.int32, device=dev) if sym is not None else None
+    cdf = torch.empty((n, nsym + 1), dtype=torch.int16, device=dev) if want_cdf else None
+    rc = lib().scp_pmf_cdf(_dev(pmf, torch.float32), n, nsym, _opt(sym), _opt(lohi), _opt(cdf), _stream())
+    _check(rc, "scp_pmf_cdf")
+    return dict(lohi=lohi, cdf=cdf)
+
+
+# ------------------------------------------------------------------------------------------------- range coder (host)
+def ac_encode_cdf(cdf, sym):
+    """cdf uint16/int16 numpy [n,Lp], sym int16 numpy [n] -> bytes."""
+    cdf = np.ascontiguousarray(cdf).view(np.uint16)
+    sym = np.ascontiguousarray(sym, np.int16)
+    cap = len(sym) * 4 + 64
+    while True:
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t(0)
+        rc = lib().scp_ac_encode_cdf(cdf.ctypes.data, sym.ctypes.data, len(sym), cdf.shape[1], out.ctypes.data, cap,
+                                     C.byref(n))
+        if rc == -3:
+            cap *= 4
+            continue
+        _check(rc, "scp_ac_encode_cdf")
+        return out[: n.value].tobytes()
+
+
+def ac_encode_lohi(lohi):
+    """lohi uint32/int32 numpy [n] (low 16 = c_low, high 16 = c_high, 0 => 65536) -> bytes."""
+    lohi = np.ascontiguousarray(lohi).view(np.uint32)
+    cap = len(lohi) * 4 + 64
+    while True:
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t(0)
+        rc = lib().scp_ac_encode_lohi(lohi.ctypes.data, len(lohi), out.ctypes.data, cap, C.byref(n))
+        if rc == -3:
+            cap *= 4
+            continue
+        _check(rc, "scp_ac_encode_lohi")
+        return out[: n.value].tobytes()
+
+
+class AcDecoder:
+    def __init__(self, byte_stream, Lp=256):
+        self._buf = np.frombuffer(byte_stream, np.uint8).copy()
+        self._h = _vp()
+        _check(lib().scp_ac_dec_new(C.byref(self._h), self._buf.ctypes.data, len(self._buf), Lp), "scp_ac_dec_new")
+
+    def next(self, cdf_row):
+        row = np.ascontiguousarray(cdf_row).view(np.uint16)
+        return _check(lib().scp_ac_dec_next(self._h, row.ctypes.data), "scp_ac_dec_next")
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().scp_ac_dec_free(self._h)
+        except Exception:
+            pass

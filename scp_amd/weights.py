@@ -1,8 +1,9 @@
 """Deterministic synthetic weights (no trained checkpoint is available offline).
 
-`fill_weights(module, seed)` walks `module.state_dict()` in key order and overwrites every
-floating-point entry from a numpy PCG64 stream, so the reference model (in the build
-container) and this repo's modules (anywhere) get bit-identical parameters from one seed.
+`fill_weights(module, seed)` overwrites every floating-point entry of `module.state_dict()`
+from a numpy PCG64 stream seeded by (seed, crc32(key)), so the reference model (in the build
+container) and this repo's modules (anywhere) get bit-identical parameters from one seed,
+independent of the order in which the two implementations register their parameters.
 Scales keep activations O(1) so that the 1e-3 logit tolerance is a real test:
   * matrices / conv kernels : N(0, 1/fan_in)
   * embeddings              : N(0, 1)
@@ -12,6 +13,8 @@ Scales keep activations O(1) so that the 1e-3 logit tolerance is a real test:
 Integer buffers (relative_position_index, num_batches_tracked) and the fixed
 `mask` / `position_enc.pe` buffers are left untouched.
 """
+import zlib
+
 import numpy as np
 import torch
 
@@ -38,10 +41,17 @@ def _is_embedding(key):
 
 @torch.no_grad()
 def fill_weights(module, seed=0):
-    rng = np.random.default_rng(seed)
-    sd = module.state_dict()
+    """Overwrite the floating-point entries of a module's state_dict in place."""
+    fill_state_dict(module.state_dict(), seed)
+    return module
+
+
+@torch.no_grad()
+def fill_state_dict(sd, seed=0):
+    """Same, for a plain {key: tensor} mapping (tensors are modified in place)."""
     for key in sd.keys():
         t = sd[key]
+        rng = np.random.default_rng([int(seed), zlib.crc32(key.encode())])
         if key in _SKIP_EXACT or key.endswith(_SKIP_SUFFIX) or key.endswith("position_enc.pe"):
             continue
         if not torch.is_floating_point(t):
@@ -64,4 +74,4 @@ def fill_weights(module, seed=0):
         else:
             v = 0.1 * g
         t.copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(t.device))
-    return module
+    return sd

@@ -640,7 +640,18 @@ def gen_facts():
             json.dump(facts, f, indent=1)
 
 
-GROUPS = {"xform": gen_xform, "oct": gen_oct, "ctx": gen_ctx, "logits": gen_logits, "swin": gen_swin,
+def gen_keys():
+    """state_dict key/shape/dtype inventory of the reference modules (drop-in checkpoint contract, Appendix D)."""
+    print("[keys]")
+    out = {}
+    for name, m in (("EHEM", build_ref_ehem(0)), ("OctAttention", build_ref_octattn(0))):
+        out[name] = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+        print("   ", name, len(out[name]), "entries")
+    with open(os.path.join(HERE, "state_keys.json"), "w") as f:
+        json.dump(out, f)
+
+
+GROUPS = {"keys": gen_keys, "xform": gen_xform, "oct": gen_oct, "ctx": gen_ctx, "logits": gen_logits, "swin": gen_swin,
           "cdf": gen_cdf, "ac": gen_ac, "e2e": gen_e2e, "facts": gen_facts}
 
 if __name__ == "__main__":

@@ -1,0 +1,69 @@
+"""C-ABI library: loads without a GPU, exports every symbol include/scp.h declares; host-side range coder parity."""
+import hashlib
+import os
+import re
+
+import numpy as np
+
+from conftest import ROOT, golden
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "scp.h")).read()
+    return re.findall(r"SCP_API\s+[A-Za-z_0-9 \*]+?\b([A-Za-z_0-9]+)\s*\(", src)
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from scp_amd import native
+    L = native.lib()
+    names = declared_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.scp_version() >= 100
+    assert isinstance(L, ctypes.CDLL)
+
+
+def _tile(base, n):
+    return np.tile(base, (-(-n // len(base)), 1))[:n]
+
+
+def test_range_coder_matches_reference_streams(orc):
+    from scp_amd import native
+    z = golden("ac_streams")
+    for n in (1, 2, 1000):
+        pdf = _tile(z[f"n{n}_pdfbase"], n)
+        cdf = orc.pmf_to_cdf(pdf)
+        sym = z[f"n{n}_sym"]
+        want = z[f"n{n}_bytes"].tobytes()
+        assert native.ac_encode_cdf(cdf, sym) == want
+        s = sym.astype(np.int64)
+        lo = cdf[np.arange(n), s].astype(np.uint32)
+        hi = np.where(s == 254, 0, cdf[np.arange(n), np.minimum(s + 1, 255)]).astype(np.uint32)
+        assert native.ac_encode_lohi(lo | (hi << 16)) == want
+    n = 100000
+    pdf = _tile(z[f"n{n}_pdfbase"], n)
+    cdf = orc.pmf_to_cdf(pdf)
+    bs = native.ac_encode_cdf(cdf, z[f"n{n}_sym"])
+    assert hashlib.sha256(bs).hexdigest() == str(z[f"n{n}_sha"])
+    dec = native.AcDecoder(bs)
+    assert [dec.next(cdf[i]) for i in range(4000)] == z[f"n{n}_sym"][:4000].tolist()
+    pdf = np.tile(z["pend_pdf_row"], (len(z["pend_sym"]), 1))
+    assert native.ac_encode_cdf(orc.pmf_to_cdf(pdf), z["pend_sym"]) == z["pend_bytes"].tobytes()
+
+
+def test_range_coder_argument_errors():
+    from scp_amd import native
+    import ctypes as C
+    L = native.lib()
+    n = C.c_size_t(0)
+    out = np.zeros(16, np.uint8)
+    cdf = np.zeros((1, 256), np.uint16)
+    sym = np.array([300], np.int16)   # out of range symbol
+    assert L.scp_ac_encode_cdf(cdf.ctypes.data, sym.ctypes.data, 1, 256, out.ctypes.data, 16, C.byref(n)) == -1
+    assert L.scp_ac_encode_cdf(None, sym.ctypes.data, 1, 256, out.ctypes.data, 16, C.byref(n)) == -1
+    # too-small output buffer
+    cdf = np.tile(np.arange(256, dtype=np.uint16) * 255, (64, 1))
+    sym = np.full(64, 3, np.int16)
+    assert L.scp_ac_encode_cdf(cdf.ctypes.data, sym.ctypes.data, 64, 256, out.ctypes.data, 2, C.byref(n)) == -3
