@@ -13,6 +13,12 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
          "-Wno-unused-result", "-fvisibility=hidden", "-x", "hip"]
 
 
+# bit-exact kernels: numpy / torch evaluate a*a + b*b as two roundings, so FMA contraction must be off there
+# (HIP's __fmul_rn / __fadd_rn are plain operators and do NOT stop the contraction).
+EXTRA = {"geom.hip": ["-ffp-contract=off"], "knn.hip": ["-ffp-contract=off"], "cdf.hip": ["-ffp-contract=off"],
+         "edge.hip": ["-ffp-contract=off"]}
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -30,7 +36,7 @@ def build(force=False, verbose=False):
         o = os.path.join(CSRC, "build", os.path.basename(s) + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(s), []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((s, subprocess.Popen(cmd)))

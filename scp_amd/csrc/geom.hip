@@ -53,6 +53,17 @@ __device__ __forceinline__ uint32_t compact3(uint64_t v) {
 __device__ __forceinline__ uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 static inline float ord2f_host(uint32_t u) { uint32_t v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &v, 4); return f; }
 
+// correctly rounded float32 square root: hipcc folds (float)sqrt((double)s) back to the 1-ulp v_sqrt_f32 sequence, so
+// refine in float64 by hand (two Newton steps from the hardware estimate, IEEE float64 division) and round once.
+__device__ __forceinline__ float sqrt_cr(float s) {
+    if (!(s > 0.f)) return s == 0.f ? 0.f : __builtin_nanf("");
+    const double d = (double)s;
+    double r = (double)__builtin_sqrtf(s);
+    r = 0.5 * (r + d / r);
+    r = 0.5 * (r + d / r);
+    return (float)r;
+}
+
 // data_preprocess.py:200-207 / :171-177, float32 arithmetic in numpy's evaluation order (no FMA contraction);
 // atan2/acos are evaluated in float64 and rounded once (numpy's SIMD float32 routines are not reproducible
 // across CPUs - DESIGN.md "float -> integer boundary").
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(WG) void transform_kernel(const float *__restrict__
             const float xx = __fmul_rn(x, x), yy = __fmul_rn(y, y);
             float s = __fadd_rn(xx, yy);
             if (mode == SCP_SPHER) s = __fadd_rn(s, __fmul_rn(z, z));
-            a = (float)sqrt((double)s);  // correctly rounded (v_sqrt_f32 alone is 1 ulp)
+            a = sqrt_cr(s);
             const float xe = __fadd_rn(x, 1e-9f);
             float phi = (float)atan2((double)y, (double)xe);
             if (phi < 0.f) phi = __fadd_rn(phi, 6.2831855f);

@@ -1,0 +1,166 @@
+"""Frame encoder: LiDAR frame -> range-coded occupancy bitstream, everything between on the MI355X.
+
+This is the hot path of encode.py:85-160 (compress_ehem) / encode_mullevel.py:88-154 and of the datasets feeding it
+(dataloaders/encode_dataset_ehem*.py), restructured for the device:
+
+  xyz (H2D once) -> scp_quantize (1 or 3 shells) -> scp_geom_build (one launch sequence for all shells)
+     -> scp_geom_context_ehem (ctx u8 [N,12], pos f32 [N,3], sym u8 [N])
+     -> EHEM windows (<= 8192 nodes, equal-length windows batched) -> logits scattered straight into CODING ORDER
+     -> scp_softmax_cdf over all N rows -> (c_low, c_high) pairs (4 B/node D2H) -> scp_ac_encode_lohi (host)
+
+Per-window softmax, the [N,255] PMF table on the host, the int64 [N,4,6] records and the per-level Python loops of
+the reference do not exist here.  The returned dict carries the same scalars the reference prints.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import native
+
+KITTI, FORD = "kitti", "ford"
+
+
+def level_qs(data_type, level):
+    """encode_dataset_ehem.py:164 / encode_dataset_ehem_mullevel.py:162-185."""
+    return 400 / (2 ** level - 1) if data_type == KITTI else 2 ** (18 - level)
+
+
+class EncodePlan:
+    """Window list + coding order for one frame (encode.py:109-136): pure host bookkeeping on level sizes."""
+
+    def __init__(self, level_sizes, context_size):
+        self.level_sizes = list(level_sizes)
+        self.windows = []          # (row_start, length, coded_start)
+        row = 0
+        for n in self.level_sizes:
+            for i in range(0, n, context_size):
+                c = min(context_size, n - i)
+                self.windows.append((row + i, c, row + i))   # inside a window: evens first, then odds
+            row += n
+        self.n_rows = row
+
+    def groups(self, max_batch):
+        """Windows of equal length, chunked to at most max_batch per model call."""
+        by_len = {}
+        for w in self.windows:
+            by_len.setdefault(w[1], []).append(w)
+        out = []
+        for c in sorted(by_len, reverse=True):
+            ws = by_len[c]
+            for i in range(0, len(ws), max_batch):
+                out.append((c, ws[i:i + max_batch]))
+        return out
+
+    def coding_order(self):
+        """Row index (frame order) of every coded position - for tests and for the reference-compatible view."""
+        order = np.empty(self.n_rows, np.int64)
+        for start, c, coded in self.windows:
+            ne = (c + 1) // 2
+            order[coded:coded + ne] = start + np.arange(0, c, 2)
+            order[coded + ne:coded + c] = start + np.arange(1, c, 2)
+        return order
+
+
+class FrameEncoder:
+    def __init__(self, model, data_type=KITTI, lidar_level=12, spher=True, cylin=False, mullevel=False, max_batch=8,
+                 device=None):
+        self.model = model
+        self.data_type = data_type
+        self.lidar_level = lidar_level
+        self.mode = native.CYLIN if cylin else (native.SPHER if spher else native.CART)
+        self.spher, self.cylin = spher and not cylin, cylin
+        self.mullevel = mullevel
+        self.max_batch = max_batch
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.context_size = model.cfg.model.context_size
+        self.geom = native.Geom()
+        self.cart_offset = -200.0 if data_type == KITTI else -float(2 ** 17)
+
+    # ------------------------------------------------------------------------------------------ stage G
+    def preprocess(self, xyz_dev):
+        """-> dict with ctx/pos/sym device tensors for the whole frame (all shells concatenated), level sizes, meta."""
+        L = self.lidar_level
+        n = xyz_dev.shape[0]
+        if self.mullevel:
+            shells = [([0, 0], L), ([0, 1], L + 1), ([1], L + 2)]
+        else:
+            shells = [(None, L)]
+        qs, infos = [], []
+        for path, lv in shells:
+            q, qi, _ = native.quantize(xyz_dev, self.mode, level_qs(self.data_type, lv),
+                                       0.0 if self.mullevel else self.cart_offset)
+            qs.append(q)
+            infos.append(qi)
+        q = torch.cat(qs) if len(qs) > 1 else qs[0]
+        segs = [(k * n, n, path, self.mullevel) for k, (path, _) in enumerate(shells)]
+        self.geom.build(q, segs)
+        pos_mode = native.POS_MINMAX_MUL if self.mullevel else (native.POS_POW2 if self.mode == native.CART else native.POS_MINMAX)
+        ctxs, poss, syms, mms, sizes = [], [], [], [], []
+        for s in range(len(segs)):
+            ctx, pos, sym, mm = self.geom.context_ehem(s, pos_mode, L)
+            ctxs.append(ctx); poss.append(pos); syms.append(sym); mms.append(mm)
+            counts = self.geom.level_counts(s)
+            if self.mullevel:
+                counts[-1] -= 1          # Octree.py:259-262: the records drop the last BFS node
+            sizes += counts
+        return dict(ctx=torch.cat(ctxs), pos=torch.cat(poss), sym=torch.cat(syms), pos_mm=torch.cat(mms),
+                    level_sizes=sizes, bin_num=infos[0].bin_num, z_offset=infos[0].offset[2] if self.cylin else 0.0,
+                    n_points=n)
+
+    # ------------------------------------------------------------------------------------------ stage M + C
+    def logits_in_coding_order(self, pre, plan):
+        N = plan.n_rows
+        table = torch.empty((N, 255), dtype=torch.float32, device=self.device)
+        ctx, pos = pre["ctx"], pre["pos"]
+        for c, ws in plan.groups(self.max_batch):
+            starts = [w[0] for w in ws]
+            if len(ws) == 1:
+                bctx, bpos = ctx[starts[0]:starts[0] + c][None], pos[starts[0]:starts[0] + c][None]
+            else:
+                bctx = torch.stack([ctx[s:s + c] for s in starts])
+                bpos = torch.stack([pos[s:s + c] for s in starts])
+            o1, o2 = self.model.forward_ctx(bctx, bpos)
+            ne = (c + 1) // 2
+            for b, (start, _, coded) in enumerate(ws):
+                table[coded:coded + ne] = o1[b]
+                if c > 1:
+                    table[coded + ne:coded + c] = o2[b]
+        return table
+
+    def encode(self, xyz, timing=False):
+        """xyz: numpy / torch float32 [P,3].  Returns dict(bytes, bits, bpp, n_nodes, n_points, bin_num, z_offset,
+        n_levels, pos_mm (numpy [n_levels,2]), times)."""
+        t0 = time.perf_counter()
+        if isinstance(xyz, np.ndarray):
+            xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
+        xyz_dev = xyz.to(self.device, non_blocking=True)
+        pre = self.preprocess(xyz_dev)
+        if timing:
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        plan = EncodePlan(pre["level_sizes"], self.context_size)
+        table = self.logits_in_coding_order(pre, plan)
+        order = torch.from_numpy(plan.coding_order()).to(self.device)
+        sym_coded = pre["sym"][order].contiguous()
+        if timing:
+            torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        lohi = native.softmax_cdf(table, sym_coded)["lohi"].cpu().numpy()
+        t3 = time.perf_counter()
+        stream = native.ac_encode_lohi(lohi)
+        t4 = time.perf_counter()
+        bits = 8 * len(stream)
+        return dict(bytes=stream, bits=bits, bpp=bits / pre["n_points"], n_nodes=plan.n_rows, n_points=pre["n_points"],
+                    bin_num=pre["bin_num"], z_offset=pre["z_offset"], n_levels=len(pre["level_sizes"]),
+                    pos_mm=pre["pos_mm"].cpu().numpy(), level_sizes=pre["level_sizes"],
+                    times=dict(geom=t1 - t0, model=t2 - t1, cdf=t3 - t2, coder=t4 - t3, total=t4 - t0),
+                    _debug=dict(table=table, sym_coded=sym_coded, order=order, pre=pre))
+
+    def outfile(self, base, res):
+        """encode.py:140-144 file name."""
+        if self.spher:
+            base += "_spher"
+        elif self.cylin:
+            base += "_cylin"
+        return base + "_" + str(res["n_levels"]) + "_" + str(int(res["bin_num"])) + "_" + str(int(res["z_offset"])) + ".bin"

@@ -1,0 +1,219 @@
+"""Stage M on the GPU: HIP kernels and the product modules against the reference's golden logits (tolerance 1e-3,
+BASELINE.json north_star) and against the CPU oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cfgs import ehem_cfg, octattn_cfg
+from conftest import GOLDEN, golden
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from scp_amd import native
+    native.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ehem(dev):
+    from scp_amd.models import EHEM
+    from scp_amd.weights import fill_weights
+    m = EHEM(ehem_cfg())
+    fill_weights(m, 0)
+    return m.to(dev)
+
+
+@pytest.fixture(scope="module")
+def octattn(dev):
+    from scp_amd.models import OctAttention
+    from scp_amd.weights import fill_weights
+    m = OctAttention(octattn_cfg())
+    fill_weights(m, 0)
+    return m.to(dev)
+
+
+# ----------------------------------------------------------------------------------------------- kNN
+def ref_knn_values(x, k):
+    """dgcnn.py:18-20 distances in float64 (ground truth for 'is this a valid top-k set')."""
+    x = x.double()
+    inner = x @ x.transpose(1, 2)
+    xx = (x ** 2).sum(2)
+    return 2 * inner - xx[:, None, :] - xx[:, :, None]
+
+
+@pytest.mark.parametrize("B,n,C", [(1, 1, 3), (1, 7, 3), (2, 300, 3), (1, 1000, 144), (1, 2500, 192), (1, 8192, 3)])
+def test_knn_topk_is_a_valid_topk(dev, B, n, C):
+    from scp_amd import native
+    g = torch.Generator().manual_seed(n * 7 + C)
+    if C == 3:   # lattice positions like the real input (many exact ties)
+        x = torch.randint(0, 60, (B, n, C), generator=g).float() / 59.0
+    else:
+        x = torch.randn((B, n, C), generator=g)
+    k = min(20, n)
+    idx = native.knn_topk(x.to(dev), k).cpu().long()
+    assert idx.shape == (B, n, k) and idx.min() >= 0 and idx.max() < n
+    # no duplicates inside a row
+    assert (torch.sort(idx, 2)[0].diff(dim=2) != 0).all() if k > 1 else True
+    d = ref_knn_values(x, k)
+    got = torch.gather(d, 2, idx)
+    kth = torch.topk(d, k, dim=2)[0][..., -1:]
+    # every returned neighbour is at least as close as the true k-th neighbour (up to float32 rounding of the distance)
+    tol = 4e-6 * d.abs().max()
+    assert (got >= kth - tol).all()
+    # sorted by decreasing value
+    assert (got.diff(dim=2) <= tol).all()
+
+
+def test_knn_matches_cpu_reference_topk_on_real_window(dev):
+    from scp_amd import native
+    from oracle import models_ref
+    z = golden("logits_ehem_c1024")
+    pos = torch.from_numpy(z["pos"])[None]          # [1,3,c]
+    ref = models_ref.knn(pos, 20)                   # CPU torch, reference formula
+    got = native.knn_topk(pos.transpose(1, 2).contiguous().to(dev), 20).cpu().long()
+    same = (torch.sort(ref, 2)[0] == torch.sort(got, 2)[0]).all(2).float().mean().item()
+    print(f"kNN neighbour sets identical to CPU torch.topk for {100 * same:.2f}% of the points")
+    assert same > 0.5
+
+
+# ----------------------------------------------------------------------------------------------- edge conv
+def test_edge_gather_max_vs_torch(dev):
+    from scp_amd import native
+    g = torch.Generator().manual_seed(3)
+    B, n, Co, k = 2, 777, 128, 20
+    u = torch.randn((B, n, Co), generator=g)
+    v = torch.randn((B, n, Co), generator=g)
+    idx = torch.randint(0, n, (B, n, k), generator=g, dtype=torch.int32)
+    scale = torch.randn(Co, generator=g)
+    shift = torch.randn(Co, generator=g)
+    got = native.edge_gather_max(u.to(dev), v.to(dev), idx.to(dev), scale.to(dev), shift.to(dev)).cpu()
+    nb = torch.stack([u[b][idx[b].long()] for b in range(B)])           # [B,n,k,Co]
+    y = torch.nn.functional.leaky_relu(scale * (nb + v[:, :, None]) + shift, 0.2).max(2)[0]
+    assert torch.allclose(got, y, atol=1e-6, rtol=1e-6)
+
+
+def gpu_knn_for_oracle(dev):
+    """Neighbour indices chosen by the HIP kernel, handed to the CPU oracle (isolates everything but tie-breaking)."""
+    from scp_amd import native
+
+    def f(x, k):
+        return native.knn_topk(x.transpose(1, 2).contiguous().to(dev), k).cpu().long()
+    return f
+
+
+def test_edge_conv_matches_oracle_formulation(dev, ehem):
+    """split-GEMM + gather/max == cat(f_j - f_i, f_i) conv + BN + LeakyReLU + max (dgcnn.py:48-71), same neighbours."""
+    from oracle import models_ref
+    from scp_amd.models.ehem import _edge_conv
+    sd = {k: v.cpu() for k, v in ehem.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1, 500, 144), generator=g)
+    models_ref.KNN_OVERRIDE = gpu_knn_for_oracle(dev)
+    try:
+        want = models_ref.edge_conv(sd, "geo_feat_generator.conv2", x.transpose(1, 2).contiguous(), 20).transpose(1, 2)
+    finally:
+        models_ref.KNN_OVERRIDE = None
+    got = _edge_conv(ehem.geo_feat_generator.conv2, x.to(dev), 20).cpu()
+    assert torch.allclose(got, want, atol=2e-5, rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------- Swin
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "swin_*_s*_L*.npz"))))
+def test_swin_layer_vs_reference(dev, name):
+    from scp_amd.models.ehem import SwinLayer, swin_layer_forward
+    from scp_amd.weights import fill_weights
+    z = golden(name)
+    _, kind, s, L = name.split("_")
+    shift, L = int(s[1:]), int(L[1:])
+    layer = SwinLayer()
+    fill_weights(layer, int(z["wseed"]))
+    layer = layer.to(dev)
+    rng = np.random.default_rng(int(z["x_seed"]))
+    x = torch.from_numpy(rng.standard_normal((1, L, 256), dtype=np.float32)).to(dev)
+    q = torch.from_numpy(rng.standard_normal((1, L, 256), dtype=np.float32)).to(dev)
+    with torch.no_grad():
+        y = swin_layer_forward(layer, x, L, shift, q if kind == "cross" else None)
+    err = np.abs(y[0, ::int(z["stride"])].cpu().numpy() - z["y"]).max()
+    assert err < 1e-4, err
+
+
+def test_swin_attention_argument_errors(dev):
+    from scp_amd import native
+    q = torch.zeros((1, 500, 256), device=dev)
+    with pytest.raises(native.ScpError):
+        native.swin_attention(q, q, q, torch.zeros((1023, 4), device=dev), 0)     # Lp not a multiple of 512
+
+
+# ----------------------------------------------------------------------------------------------- EHEM
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_ehem_*.npz"))))
+def test_ehem_logits_vs_reference(dev, ehem, name):
+    z = golden(name)
+    data = torch.from_numpy(z["data"].astype(np.int64))
+    pos = torch.from_numpy(z["pos"])
+    if data.dim() == 3:
+        data, pos = data[None], pos[None]
+    o1, o2 = ehem(data.to(dev), pos.to(dev), enc=True)
+    o1, o2 = o1.cpu().numpy(), o2.cpu().numpy()
+    if "out1_sub" in z:
+        st = int(z["stride"])
+        e1 = np.abs(o1[0, ::st] - z["out1_sub"])
+        e2 = np.abs(o2[0, ::st] - z["out2_sub"])
+    else:
+        w1, w2 = z["out1"], z["out2"]
+        if w1.ndim == 2:
+            w1, w2 = w1[None], w2[None]
+        assert o1.shape == w1.shape and o2.shape == w2.shape
+        e1, e2 = np.abs(o1 - w1), np.abs(o2 - w2)
+    e = np.concatenate([e1.reshape(-1, 255), e2.reshape(-1, 255)]) if e2.size else e1.reshape(-1, 255)
+    rows_ok = (e.max(1) <= LOGIT_TOL).mean()
+    print(f"{name}: vs reference (its own CPU top-k tie-breaking): max|dlogit| = {e.max():.3e}, "
+          f"rows within 1e-3: {100 * rows_ok:.2f}%")
+    # The reference's neighbour choice among EXACTLY tied distances is an artefact of its top-k implementation
+    # (std::partial_sort on CPU, radix-select on CUDA); rows whose 20th/21st neighbours tie can differ.  Demand
+    # that the bulk of the rows agree with the golden logits ...
+    assert rows_ok >= 0.85, (e.max(), rows_ok)
+    # ... and that ALL rows agree to 1e-3 with the CPU oracle once it is given the same neighbour sets.
+    from oracle import models_ref
+    sd = {k: v.cpu() for k, v in ehem.state_dict().items()}
+    models_ref.KNN_OVERRIDE = gpu_knn_for_oracle(dev)
+    try:
+        with torch.no_grad():
+            r1, r2 = models_ref.ehem_forward(sd, data, pos)
+    finally:
+        models_ref.KNN_OVERRIDE = None
+    d = max(np.abs(o1 - r1.numpy()).max(), np.abs(o2 - r2.numpy()).max() if o2.size else 0.0)
+    print(f"{name}: vs CPU oracle with identical neighbour sets: max|dlogit| = {d:.3e}")
+    assert d <= LOGIT_TOL, d
+
+
+def test_ehem_forward_ctx_equals_reference_signature(dev, ehem):
+    z = golden("logits_ehem_c600")
+    data = torch.from_numpy(z["data"].astype(np.int64))[None].to(dev)
+    pos = torch.from_numpy(z["pos"])[None].to(dev)
+    a1, a2 = ehem(data, pos)
+    b1, b2 = ehem.forward_ctx(data.reshape(1, -1, 12).to(torch.uint8), pos.transpose(1, 2).contiguous())
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    with pytest.raises(Exception):
+        ehem(data.cpu(), pos.cpu())      # no CPU fallback
+
+
+# ----------------------------------------------------------------------------------------------- OctAttention
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_octattn_*.npz"))))
+def test_octattn_logits_vs_reference(dev, octattn, name):
+    z = golden(name)
+    data = torch.from_numpy(z["data"].astype(np.int64))[None].to(dev)
+    pos = torch.from_numpy(z["pos"])[None].to(dev)
+    keep = data.clone()
+    o = octattn(data, pos)[0].cpu().numpy()
+    assert torch.equal(data, keep)            # forward is a pure function (reference edits `level` in place)
+    e = np.abs(o - z["out"]).max()
+    print(f"{name}: max|dlogit| = {e:.3e}")
+    assert e <= LOGIT_TOL
