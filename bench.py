@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: KITTI-like frames/s encode, SCP-EHEM, lidar_level 16 --spher --mullevel (BASELINE.json configs[2]).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one synthetic 120 000-point frame through the whole hot path on one GPU: quantiser (3 shells) -> octree
+serialisation -> context tables -> EHEM over every <= 8192-node window -> softmax/integer CDF -> range coder.  The frame
+is resident in HBM before the timed region; the (c_low, c_high) pairs (4 B/node) go D2H and the serial range coder runs
+on the host inside the timed region, as in a real encode.  Frames are independent: rank r encodes its own frames
+(weak scaling), the only collective is the end-of-run all-reduce of the 5 summary scalars (RCCL).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--level", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def measure_dominant_kernel(enc, xyz_dev):
+    """Live HIP-event timing of the dominant kernel (knn_kernel) over one frame, on the stream it is launched on."""
+    from scp_amd import native
+    recs = []
+    orig = native.knn_topk
+
+    def timed(x, k):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = orig(x, k)
+        e.record()
+        B, n, C = x.shape
+        recs.append((s, e, 2.0 * B * n * n * C))
+        return out
+
+    native.knn_topk = timed
+    try:
+        enc.encode(xyz_dev)
+        torch.cuda.synchronize()
+    finally:
+        native.knn_topk = orig
+    ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+    flops = sum(f for _, _, f in recs)
+    return dict(launches=len(recs), avg_launch_us=1e3 * ms / max(1, len(recs)), flops_per_launch=flops / max(1, len(recs)),
+                tflops=flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, total_ms=ms)
+
+
+def cpu_baseline(level, n_nodes_frame, xyz):
+    """The CPU oracle (a port of the reference path: C octree / CDF / range coder + PyTorch-CPU EHEM) on a bounded sample."""
+    from cfgs import ehem_cfg
+    from oracle import models_ref, scp_oracle as orc
+    from scp_amd.models import EHEM
+    from scp_amd.weights import fill_weights
+    threads = min(os.cpu_count() or 1, 32)   # PyTorch-CPU oversubscribes badly beyond this on 128-core hosts
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    shells = orc.mullevel_shells(xyz, level, "spher")           # quantiser + octree + K records for all three shells
+    ids, poss, pos_mm, data, oct_seq = orc.ehem_mullevel_context([s["records"] for s in shells], level)
+    t_geom = time.perf_counter() - t0
+    sd = fill_weights(EHEM(ehem_cfg()), 0).state_dict()
+    big = max(range(len(data)), key=lambda i: len(data[i]))
+    c = min(8192, len(data[big]))
+    d = torch.from_numpy(data[big][:c])[None]
+    p = torch.from_numpy(poss[big][:, :c])[None]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        o1, o2 = models_ref.ehem_forward(sd, d, p)
+    t_model = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pmf = torch.softmax(torch.cat((o1[0], o2[0])), 1).numpy()
+    sym = np.concatenate((data[big][:c:2, -1, 2], data[big][1:c:2, -1, 2])).astype(np.int16)
+    orc.encode_pmf(pmf, sym)
+    t_code = time.perf_counter() - t0
+    per_node = (t_model + t_code) / c
+    frame_s = t_geom + per_node * n_nodes_frame
+    return dict(value=1.0 / frame_s, unit="frames/s", cores=threads, kind="port",
+                sample=f"oracle octree+records+context for all 3 shells of one frame ({t_geom:.2f}s, 1 thread) + one full "
+                       f"{c}-node EHEM window on PyTorch-CPU ({t_model:.2f}s, {threads} threads) + its CDF/range coding "
+                       f"({t_code:.3f}s), extrapolated linearly to the frame's {n_nodes_frame} nodes")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cfgs import ehem_cfg
+    from scp_amd import native
+    from scp_amd.encoder import FrameEncoder
+    from scp_amd.models import EHEM
+    from scp_amd.synth import synth_frame
+    from scp_amd.weights import fill_weights
+    native.lib()
+    model = fill_weights(EHEM(ehem_cfg()), 0).to(dev)
+    enc = FrameEncoder(model, "kitti", args.level, spher=True, mullevel=True, device=dev)
+
+    total = args.warmup + args.steps
+    frames_host = [synth_frame(rank * 1000 + i) for i in range(total)]
+    frames = [torch.from_numpy(f).to(dev) for f in frames_host]      # resident in HBM before the timed region
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        enc.encode(frames[i])
+    barrier()
+    t0 = time.perf_counter()
+    results = []
+    for i in range(args.warmup, total):
+        results.append(enc.encode(frames[i]))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # end-of-run summary reduction (encode.py:293-305): [sum bpp, sum psnr, sum chamfer, sum time, count] over all ranks
+    summ = torch.tensor([sum(r["bpp"] for r in results), 0.0, 0.0, sum(r["times"]["total"] for r in results), len(results)],
+                        dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(summ, op=dist.ReduceOp.SUM)
+    summ = summ.cpu().numpy()
+
+    if rank == 0:
+        n_nodes = results[-1]["n_nodes"]
+        dom = measure_dominant_kernel(enc, frames[-1])
+        st = enc.encode(frames[-1], timing=True)["times"]     # per-stage wall times with a device sync after every stage
+        P = results[-1]["n_points"]
+        bytes_G = 12 * P + 25 * n_nodes            # SURVEY.md §8d algorithmic bytes of stage G
+        bytes_C = n_nodes * (255 * 4 + 4)
+        out = {
+            "metric": "KITTI frames/sec encode (SCP-EHEM, level 16) + bpp match vs ref",
+            "value": world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"SCP-EHEM KITTI-like synthetic 120k-pt frames, --spher --mullevel lidar_level={args.level} "
+                                   "(BASELINE.json configs[2]), seeded random weights", "nodes_per_frame": int(n_nodes),
+                       "windows_per_frame": len(__import__("scp_amd.encoder", fromlist=["EncodePlan"]).EncodePlan(
+                           results[-1]["level_sizes"], 8192).windows),
+                       "frames_per_gpu": args.steps, "parallelism": f"frame-sharded x{world}"},
+            "bpp_mean": float(summ[0] / summ[4]),
+            "stage_ms": {k: round(1e3 * v, 3) for k, v in st.items()},
+            "roofline": {"bound": "mfma", "kernel": "knn_kernel (fused distance + top-20, v_mfma_f32_16x16x4_f32)",
+                         "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": dom["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_frame": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
+                         "flops_per_launch": dom["flops_per_launch"]},
+            "roofline_stages": {
+                "G": {"bound": "hbm", "achieved": bytes_G / st["geom"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": bytes_G / st["geom"] / 1e9 / HBM_PEAK_GBS, "bytes": bytes_G,
+                      "note": "host wall time of the whole stage incl. its 5 small D2H syncs"},
+                "C": {"bound": "hbm", "achieved": bytes_C / st["cdf"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": bytes_C / st["cdf"] / 1e9 / HBM_PEAK_GBS, "bytes": bytes_C,
+                      "note": "includes the 4 B/node D2H copy"}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.level, int(n_nodes), frames_host[-1])
+            except Exception as e:   # the baseline is a reported number, never a reason to lose the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

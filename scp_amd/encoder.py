@@ -78,23 +78,34 @@ class FrameEncoder:
         self.cart_offset = -200.0 if data_type == KITTI else -float(2 ** 17)
 
     # ------------------------------------------------------------------------------------------ stage G
-    def preprocess(self, xyz_dev):
-        """-> dict with ctx/pos/sym device tensors for the whole frame (all shells concatenated), level sizes, meta."""
+    def shells(self):
         L = self.lidar_level
-        n = xyz_dev.shape[0]
-        if self.mullevel:
-            shells = [([0, 0], L), ([0, 1], L + 1), ([1], L + 2)]
-        else:
-            shells = [(None, L)]
+        return [([0, 0], L), ([0, 1], L + 1), ([1], L + 2)] if self.mullevel else [(None, L)]
+
+    def quantize(self, xyz_dev):
+        """xyz -> list of per-shell integer clouds (device int32 [P,3]) + (bin_num, z_offset)."""
         qs, infos = [], []
-        for path, lv in shells:
+        for path, lv in self.shells():
             q, qi, _ = native.quantize(xyz_dev, self.mode, level_qs(self.data_type, lv),
                                        0.0 if self.mullevel else self.cart_offset)
             qs.append(q)
             infos.append(qi)
+        return qs, infos[0].bin_num, (infos[0].offset[2] if self.cylin else 0.0)
+
+    def preprocess(self, xyz_dev):
+        qs, bin_num, z_off = self.quantize(xyz_dev)
+        return self.preprocess_ints(qs, bin_num, z_off, xyz_dev.shape[0])
+
+    def preprocess_ints(self, qs, bin_num, z_offset, n_points):
+        """qs: per-shell quantised integer clouds (device int32 [P_s,3]) - the entry point for already-quantised input
+        (the reference's --preproc_path flow).  -> ctx/pos/sym device tensors for all shells, level sizes, meta."""
+        L = self.lidar_level
         q = torch.cat(qs) if len(qs) > 1 else qs[0]
-        segs = [(k * n, n, path, self.mullevel) for k, (path, _) in enumerate(shells)]
-        self.geom.build(q, segs)
+        segs, off = [], 0
+        for (path, _), qq in zip(self.shells(), qs):
+            segs.append((off, qq.shape[0], path, self.mullevel))
+            off += qq.shape[0]
+        self.geom.build(q.contiguous(), segs)
         pos_mode = native.POS_MINMAX_MUL if self.mullevel else (native.POS_POW2 if self.mode == native.CART else native.POS_MINMAX)
         ctxs, poss, syms, mms, sizes = [], [], [], [], []
         for s in range(len(segs)):
@@ -105,8 +116,7 @@ class FrameEncoder:
                 counts[-1] -= 1          # Octree.py:259-262: the records drop the last BFS node
             sizes += counts
         return dict(ctx=torch.cat(ctxs), pos=torch.cat(poss), sym=torch.cat(syms), pos_mm=torch.cat(mms),
-                    level_sizes=sizes, bin_num=infos[0].bin_num, z_offset=infos[0].offset[2] if self.cylin else 0.0,
-                    n_points=n)
+                    level_sizes=sizes, bin_num=bin_num, z_offset=z_offset, n_points=n_points)
 
     # ------------------------------------------------------------------------------------------ stage M + C
     def logits_in_coding_order(self, pre, plan):
@@ -135,7 +145,16 @@ class FrameEncoder:
         if isinstance(xyz, np.ndarray):
             xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
         xyz_dev = xyz.to(self.device, non_blocking=True)
-        pre = self.preprocess(xyz_dev)
+        return self._encode_pre(self.preprocess(xyz_dev), t0, timing)
+
+    def encode_ints(self, qs, bin_num, z_offset, n_points, timing=False):
+        """Encode from already-quantised integer coordinates (list of per-shell int32 [P_s,3] arrays / tensors)."""
+        t0 = time.perf_counter()
+        dq = [(torch.from_numpy(np.ascontiguousarray(q, np.int32)) if isinstance(q, np.ndarray) else q).to(self.device)
+              for q in qs]
+        return self._encode_pre(self.preprocess_ints(dq, bin_num, z_offset, n_points), t0, timing)
+
+    def _encode_pre(self, pre, t0, timing):
         if timing:
             torch.cuda.synchronize()
         t1 = time.perf_counter()
