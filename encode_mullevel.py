@@ -1,0 +1,6 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's encode_mullevel.py (same flags): see scp_amd/cli.py."""
+from scp_amd.cli import main
+
+if __name__ == "__main__":
+    main(mullevel=True)

@@ -159,14 +159,31 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
             }
         }
         // ---- selection: this lane holds candidates row = (r&3) + 8(r>>2) + 4h of the tile for query qi ------------
+        // Pass 1 (cheap, branch-free): distances + a bit mask of the candidates that beat the current 20th best.
+        // Pass 2: lanes pop their survivors one at a time, so the wavefront pays for max-over-lanes survivors (1-3 per
+        // tile) instead of for all 16 slots as soon as any lane has a hit in each of them.
         const int c0 = cur * 32;
-        float thr = fmaxf(v[TK - 1], __shfl_xor(v[TK - 1], 32));   // both lanes of a query prune with the tighter bound
+        const float thr = fmaxf(v[TK - 1], __shfl_xor(v[TK - 1], 32));   // both lanes of a query prune with the tighter bound
+        float dd[16];
+        unsigned pend = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int j = c0 + cl;
-            const float d = (2.f * acc[r] - txx[buf][cl]) - xxi;
-            if (j < n && d >= thr && ((d > v[TK - 1]) || (d == v[TK - 1] && j < id[TK - 1]))) topk_insert(v, id, d, j);
+            dd[r] = (2.f * acc[r] - txx[buf][cl]) - xxi;
+            const bool pass = j < n && dd[r] >= thr && ((dd[r] > v[TK - 1]) || (dd[r] == v[TK - 1] && j < id[TK - 1]));
+            pend |= pass ? (1u << r) : 0u;
+        }
+        while (__any(pend != 0u)) {   // wave-uniform loop; lanes without a survivor insert a harmless (-inf, INT_MAX)
+            const bool act = pend != 0u;
+            const int r = act ? (__ffs(pend) - 1) : 0;
+            pend &= pend - 1u;
+            float d = dd[0];
+#pragma unroll
+            for (int rr = 1; rr < 16; ++rr) d = (rr == r) ? dd[rr] : d;
+            d = act ? d : -INFINITY;
+            const int j = act ? (c0 + (r & 3) + 8 * (r >> 2) + 4 * h) : INT_MAX;
+            topk_insert(v, id, d, j);   // a survivor that no longer qualifies simply falls off the end
         }
         if (nxt >= 0) commit(buf ^ 1);
         cur = nxt;

@@ -183,3 +183,68 @@ class FrameEncoder:
         elif self.cylin:
             base += "_cylin"
         return base + "_" + str(res["n_levels"]) + "_" + str(int(res["bin_num"])) + "_" + str(int(res["z_offset"])) + ".bin"
+
+
+class OctAttnFrameEncoder:
+    """OctAttention path (encode.py:23-82 `compress` + dataloaders/encode_dataset.py:32-55): one BFS sequence, front-padded
+    with context_size-1 rows (occ 255), cut into consecutive 1024-windows; node r is predicted at position (r+1023) % 1024
+    of window (r+1023) // 1024.  Plain BFS coding order.  `--cylin` is wired here (the reference forgot to, SURVEY B-7)."""
+
+    def __init__(self, model, data_type=KITTI, lidar_level=12, spher=True, cylin=False, max_batch=16, device=None):
+        self.model = model
+        self.data_type = data_type
+        self.lidar_level = lidar_level
+        self.mode = native.CYLIN if cylin else (native.SPHER if spher else native.CART)
+        self.spher, self.cylin = spher and not cylin, cylin
+        self.max_batch = max_batch
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.context_size = model.cfg.model.context_size
+        self.geom = native.Geom()
+        self.cart_offset = -200.0 if data_type == KITTI else -float(2 ** 17)
+
+    def encode(self, xyz, timing=False):
+        t0 = time.perf_counter()
+        if isinstance(xyz, np.ndarray):
+            xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
+        xyz_dev = xyz.to(self.device)
+        q, qi, _ = native.quantize(xyz_dev, self.mode, level_qs(self.data_type, self.lidar_level), self.cart_offset)
+        return self.encode_ints(q, qi.bin_num, xyz_dev.shape[0], t0)
+
+    def encode_ints(self, q, bin_num, n_points, t0=None):
+        t0 = t0 or time.perf_counter()
+        if isinstance(q, np.ndarray):
+            q = torch.from_numpy(np.ascontiguousarray(q, np.int32))
+        q = q.to(self.device)
+        self.geom.build(q.contiguous(), [(0, q.shape[0], None, False)])
+        ctx, pos, sym = self.geom.context_octattn(0)
+        N, cs = ctx.shape[0], self.context_size
+        pad_ctx = torch.zeros((cs - 1, 12), dtype=torch.uint8, device=self.device)
+        pad_ctx[:, 0::3] = 255
+        seq_ctx = torch.cat((pad_ctx, ctx))
+        seq_pos = torch.cat((torch.zeros((cs - 1, 4, 3), dtype=torch.float32, device=self.device), pos))
+        total = N + cs - 1
+        table = torch.empty((N, 255), dtype=torch.float32, device=self.device)
+        n_full = total // cs
+        for b0 in range(0, n_full, self.max_batch):
+            b1 = min(n_full, b0 + self.max_batch)
+            d = seq_ctx[b0 * cs:b1 * cs].reshape(b1 - b0, cs, 4, 3)
+            p = seq_pos[b0 * cs:b1 * cs].reshape(b1 - b0, cs, 4, 3)
+            out = self.model(d, p).reshape(-1, 255)
+            lo = max(b0 * cs - (cs - 1), 0)                     # first real node covered by this batch
+            skip = lo + (cs - 1) - b0 * cs                      # pad rows at the head of the first window
+            table[lo:b1 * cs - (cs - 1)] = out[skip:]
+        if total % cs:
+            d = seq_ctx[n_full * cs:].reshape(1, -1, 4, 3)
+            p = seq_pos[n_full * cs:].reshape(1, -1, 4, 3)
+            out = self.model(d, p)[0]
+            lo = n_full * cs - (cs - 1)
+            table[max(lo, 0):] = out[max(-lo, 0):]
+        lohi = native.softmax_cdf(table, sym)["lohi"].cpu().numpy()
+        stream = native.ac_encode_lohi(lohi)
+        bits = 8 * len(stream)
+        return dict(bytes=stream, bits=bits, bpp=bits / n_points, n_nodes=N, n_points=n_points, bin_num=bin_num, z_offset=0.0,
+                    n_levels=1, pos_mm=np.zeros((0, 2)), level_sizes=[N], times=dict(total=time.perf_counter() - t0),
+                    _debug=dict(table=table, sym_coded=sym))
+
+    def outfile(self, base, res):
+        return base + ".bin"

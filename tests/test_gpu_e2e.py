@@ -96,3 +96,62 @@ def test_determinism(enc_parts):
     xyz = synth_frame(5)[::10].copy()
     enc = FrameEncoder(model, "kitti", 12, spher=True, device=dev)
     assert enc.encode(xyz)["bytes"] == enc.encode(xyz)["bytes"]
+
+
+def test_octattn_frame_vs_reference_driver(orc):
+    """BASELINE.json configs[0]/[4]: OctAttention path (reference `compress`), L12 --spher."""
+    from cfgs import octattn_cfg
+    from scp_amd import native
+    from scp_amd.encoder import OctAttnFrameEncoder
+    from scp_amd.models import OctAttention
+    from scp_amd.weights import fill_weights
+    dev = torch.device("cuda:0")
+    model = fill_weights(OctAttention(octattn_cfg()), 0).to(dev)
+    z = golden("e2e_octattn_spher_L12")
+    _, bin_num, _, _, pt = orc.quantise(z["xyz"], 400 / (2 ** 12 - 1), "spher")
+    enc = OctAttnFrameEncoder(model, "kitti", 12, spher=True, device=dev)
+    res = enc.encode_ints(np.ascontiguousarray(pt, np.int32), bin_num, len(z["xyz"]))
+    assert res["n_nodes"] == int(z["n_nodes"])
+    sym = res["_debug"]["sym_coded"].cpu().numpy()
+    assert np.array_equal(sym.astype(np.int16), z["sym_coded"])
+    pmf = native.softmax_cdf(res["_debug"]["table"], want_pmf=True, want_lohi=False)["pmf"].cpu().numpy()[::int(z["pdf_stride"])]
+    assert np.abs(pmf - z["pdf_sub"]).max() < 1e-4
+    ref_bits = 8 * len(z["bytes"])
+    print(f"octattn bits {res['bits']} vs reference {ref_bits}")
+    assert abs(res["bits"] - ref_bits) <= 0.002 * ref_bits
+    cdf = native.softmax_cdf(res["_debug"]["table"], want_lohi=False, want_cdf=True)["cdf"].cpu().numpy().view(np.uint16)
+    assert orc.ac_encode(cdf, sym.astype(np.int16)) == res["bytes"]
+
+
+def test_numpyac_api_roundtrip():
+    """B3: arithmeticCoding / arithmeticDeCoding keep the reference's names and argument order."""
+    from scp_amd import numpyAc
+    z = golden("ac_streams")
+    pdf = np.tile(z["n1000_pdfbase"], (4, 1))[:1000]
+    sym = z["n1000_sym"]
+    codec = numpyAc.arithmeticCoding()
+    bs, bits = codec.encode(pdf, sym, None)
+    assert bs == z["n1000_bytes"].tobytes() and bits == 8 * len(bs)
+    dec = numpyAc.arithmeticDeCoding(bs, 1000, 255, None)
+    assert [dec.decode(pdf[i:i + 1]) for i in range(50)] == sym[:50].tolist()
+    assert dec.decode_ehem(pdf[50:60]) == sym[50:60].tolist()
+
+
+def test_cli_encode_mullevel_writes_reference_named_files(tmp_path):
+    """B5: the drop-in CLI on a synthetic KITTI-layout tree."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    from scp_amd.synth import synth_frame, write_kitti_bin
+    seq = tmp_path / "seq07"
+    seq.mkdir()
+    for i in range(2):
+        write_kitti_bin(str(seq / f"{i:06d}.bin"), synth_frame(i)[::60])
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(ROOT, "encode_mullevel.py"), "--test_files", str(seq / "*.bin"), "--type", "kitti",
+           "--lidar_level", "12", "--spher", "--random_weights", "0", "--out_dir", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "bit per pixel" in r.stdout and "sample number: 2" in r.stdout
+    bins = sorted(p.name for p in out.iterdir() if p.name.endswith(".bin"))
+    assert len(bins) == 2 and bins[0].startswith("seq07000000_spher_") and (out / (bins[0] + ".dat")).exists()
+    assert (tmp_path / "test_results_mul_kitti_12.txt").exists()
