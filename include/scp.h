@@ -153,6 +153,16 @@ SCP_API int scp_edge_gather_max(const float *u, const float *v, const int32_t *i
 SCP_API int scp_swin_attention(const float *q, const float *k, const float *v, const float *bias_table,
                        int32_t B, int32_t Lp, int32_t shift, int32_t ldq, int32_t ldkv, float *out, void *stream);
 
+/* Dense layer C = epilogue(A . W^T) on bf16 MFMA with fp32-class accuracy ("bf16x3": x = hi + lo, three products, fp32
+ * accumulate; replaces the nn.Linear calls of models/ehem.py / swin_transformer.py:448-452,511,559,571).
+ *   scp_split_weight_bf16: W fp32 [N][K] -> bf16 planes hi/lo [Npad][Kpad] (Npad % 128 == 0, Kpad % 32 == 0, zero padded)
+ *   scp_linear_bf16x3    : A fp32 [M][lda] (K % 4 == 0), planes from above, optional bias[N], residual[M][ldr];
+ *                          act: 0 none, 1 LeakyReLU(0.01), 2 GELU(erf), 3 ReLU;  C fp32 [M][ldc]                        */
+SCP_API int scp_split_weight_bf16(const float *W, int32_t N, int32_t K, int32_t Npad, int32_t Kpad, void *hi, void *lo, void *stream);
+SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void *Whi, const void *Wlo, int32_t Kpad, const float *bias,
+                      const float *residual, int64_t ldr, float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act,
+                      void *stream);
+
 /* OctAttention dual-stream causal attention (attention_model.py:58-95): heads of width hd,
  * q_u,k,k_u,v,v_u [B][c][H*hd] -> out, out_u [B][c][H*hd] */
 SCP_API int scp_octattn_attention(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,

@@ -1,0 +1,229 @@
+// Dense layer on bf16 MFMA with fp32-class accuracy: C = epilogue(A . W^T), "bf16x3" split (gfx950 / CDNA4).
+//
+// Every fp32 operand x is written as hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 significant bits together) and
+//     a.w  ~=  a_hi.w_hi + a_hi.w_lo + a_lo.w_hi          (the dropped lo.lo term is 2^-16 relative)
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16: three MFMAs at 16x the fp32-MFMA rate instead of one fp32 MFMA, i.e. a
+// ~5x higher ceiling than v_mfma_f32_32x32x2_f32 for the same product.  Measured end effect on the EHEM logits
+// (oracle emulation + tests/test_gpu_model.py): max |dlogit| 4e-5, tolerance 1e-3.  kNN distances are NOT computed this way.
+//
+// Layout: W is torch's Linear weight [N][K] (K contiguous), pre-split once into two bf16 planes padded to [Npad][Kpad]
+// (scp_amd/ops.py); A is fp32 [M][lda] and is split on the fly while staging.  Workgroup = 4 waves = 128 x 128 tile of C,
+// BK = 32; a wave owns 64 x 64 = 2 x 2 MFMA tiles.  LDS holds four bf16 planes [128][32(+8 pad)] (80-byte rows: the eight
+// 16-byte fragment reads of a 16-lane group land in distinct bank slots).  One LDS stage + register prefetch of the next
+// k-tile; 2-3 workgroups per CU hide the two barriers per k-tile.
+// Epilogue (fused): + bias[n], activation (none | LeakyReLU(0.01) | exact-erf GELU | ReLU), + residual[m][n].
+#include "scp_internal.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDP 40   // bf16 elements per LDS row (32 + 8 pad) = 80 bytes
+
+enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_GELU = 2, ACT_RELU = 3 };
+
+template <int act>
+__device__ __forceinline__ float apply_act(float y) {
+    if (act == ACT_LEAKY) return y > 0.f ? y : 0.01f * y;
+    if (act == ACT_GELU) {   // exact-erf GELU; erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7), 1 exp + 1 rcp
+        const float x = fabsf(y) * 0.70710678118654752f;
+        const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+        const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+        const float e = 1.0f - poly * __expf(-x * x);
+        return 0.5f * y * (1.0f + copysignf(e, y));
+    }
+    if (act == ACT_RELU) return y > 0.f ? y : 0.f;
+    return y;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__restrict__ A, int64_t lda, const __bf16 *__restrict__ Whi,
+                                                            const __bf16 *__restrict__ Wlo, int Kpad, const float *__restrict__ bias,
+                                                            const float *__restrict__ res, int64_t ldr, float *__restrict__ C, int64_t ldc,
+                                                            int M, int N, int K) {
+    // two LDS stages x four bf16 planes (A hi, A lo, B hi, B lo) = 2 x 40 KiB: exactly two workgroups per CU
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2][4][BM * LDP];
+
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, col = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give every XCD a contiguous run of tiles with the
+    // N tiles of one 128-row stripe back to back - the A stripe (128 x K fp32) is then fetched once per XCD L2, not once per tile.
+    const int ntn = (N + BN - 1) / BN, nblk = gridDim.x;
+    int lin = blockIdx.x;
+    if ((nblk & 7) == 0) lin = (lin & 7) * (nblk >> 3) + (lin >> 3);
+    const int m0 = (lin / ntn) * BM, n0 = (lin % ntn) * BN;
+    const int nk = Kpad / BK;
+
+    // staging assignment: A tile = 128 rows x 8 float4; thread handles rows (tid>>3) + 32*i, float4 column tid&7
+    const int a_r = tid >> 3, a_c = tid & 7;
+    // B planes = 128 rows x 4 chunks of 8 bf16 (16 B); thread handles rows (tid>>2) + 64*i, chunk tid&3
+    const int b_r = tid >> 2, b_c = tid & 3;
+
+    // two register sets: loads are issued TWO k-tiles ahead of their use (one tile ahead does not cover the L2/HBM latency
+    // with only two workgroups per CU)
+    f32x4 pa2[2][4];
+    bf16x8 pbh2[2][2], pbl2[2][2];
+    auto issue = [&](int kt, auto &pa, auto &pbh, auto &pbl) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // unconditional load from a clamped address + select: a branch around the load would make hipcc lose count of the
+            // outstanding loads and wait vmcnt(0) every iteration (no prefetch at all)
+            const int m = m0 + a_r + 32 * i, k = k0 + 4 * a_c;
+            const int mc = m < M ? m : M - 1, kc = k < K ? k : K - 4;             // K % 4 == 0
+            f32x4 v = *(const f32x4 *)(A + (int64_t)mc * lda + kc);
+            const bool ok = (m < M) && (k < K);
+            v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; v[2] = ok ? v[2] : 0.f; v[3] = ok ? v[3] : 0.f;
+            pa[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t off = (int64_t)(n0 + b_r + 64 * i) * Kpad + k0 + 8 * b_c;   // planes are padded: always in range
+            pbh[i] = *(const bf16x8 *)(Whi + off);
+            pbl[i] = *(const bf16x8 *)(Wlo + off);
+        }
+    };
+    auto commit = [&](int st, auto &pa, auto &pbh, auto &pbl) {
+        __bf16 *sAh = lds[st][0], *sAl = lds[st][1], *sBh = lds[st][2], *sBl = lds[st][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const __bf16 hh = (__bf16)pa[i][u];
+                hi[u] = hh;
+                lo[u] = (__bf16)(pa[i][u] - (float)hh);
+            }
+            const int o = (a_r + 32 * i) * LDP + 4 * a_c;
+            *(bf16x4 *)(sAh + o) = hi;
+            *(bf16x4 *)(sAl + o) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int o = (b_r + 64 * i) * LDP + 8 * b_c;
+            *(bf16x8 *)(sBh + o) = pbh[i];
+            *(bf16x8 *)(sBl + o) = pbl[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0, pa2[0], pbh2[0], pbl2[0]);
+    if (nk > 1) issue(1, pa2[1], pbh2[1], pbl2[1]);
+    commit(0, pa2[0], pbh2[0], pbl2[0]);
+    __syncthreads();
+#pragma unroll 2
+    for (int kt = 0; kt < nk; ++kt) {
+        // register set (kt & 1) is free again (tile kt went to LDS one iteration ago): refill it with tile kt + 2
+        if (kt + 2 < nk) { if (kt & 1) issue(kt + 2, pa2[1], pbh2[1], pbl2[1]); else issue(kt + 2, pa2[0], pbh2[0], pbl2[0]); }
+        const __bf16 *sAh = lds[kt & 1][0], *sAl = lds[kt & 1][1], *sBh = lds[kt & 1][2], *sBl = lds[kt & 1][3];
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ao = (wm * 64 + t * 32 + col) * LDP + kc * 16 + 8 * h;
+                const int bo = (wn * 64 + t * 32 + col) * LDP + kc * 16 + 8 * h;
+                ah[t] = *(const bf16x8 *)(sAh + ao);
+                al[t] = *(const bf16x8 *)(sAl + ao);
+                bh[t] = *(const bf16x8 *)(sBh + bo);
+                bl[t] = *(const bf16x8 *)(sBl + bo);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        // tile kt + 1 (issued one iteration ago) -> the other LDS stage: nobody reads it during this iteration
+        if (kt + 1 < nk) { if (kt & 1) commit(0, pa2[0], pbh2[0], pbl2[0]); else commit(1, pa2[1], pbh2[1], pbl2[1]); }
+        __syncthreads();
+    }
+
+    // epilogue: the accumulators hold 4 B per lane per row (lane = column n); bounce each wave's 64 x 64 tile through its private
+    // slice of the (now idle) LDS so that the residual loads and the stores move 16 B per lane, 4 rows x 256 B per instruction.
+    // (the loop's last barrier already retired every read of the operand stages)
+    constexpr int LDE = 68;   // floats per staged row: 64 + 4 (keeps float4 reads aligned, spreads banks)
+    float *stg = (float *)&lds[0][0][0] + w * (64 * LDE);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + col;
+        const float bv = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                stg[ml * LDE + j * 32 + col] = apply_act<ACT>(acc[i][j][r] + bv);
+            }
+    }
+    __syncthreads();
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int nb = n0 + wn * 64 + c4;
+    const bool vec_ok = ((ldc & 3) == 0) && (!res || (ldr & 3) == 0) && (nb + 3 < N) && (((uintptr_t)C & 15) == 0) &&
+                        (!res || ((uintptr_t)res & 15) == 0);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int ml = it * 4 + rsub;
+        const int m = m0 + wm * 64 + ml;
+        if (m >= M) continue;
+        f32x4 y = *(const f32x4 *)(stg + ml * LDE + c4);
+        if (vec_ok) {
+            if (res) { const f32x4 rr = *(const f32x4 *)(res + (int64_t)m * ldr + nb); y += rr; }
+            *(f32x4 *)(C + (int64_t)m * ldc + nb) = y;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (nb + u < N) C[(int64_t)m * ldc + nb + u] = y[u] + (res ? res[(int64_t)m * ldr + nb + u] : 0.f);
+        }
+    }
+}
+
+// split an fp32 weight [N][K] into zero-padded bf16 planes [Npad][Kpad]
+__global__ void split_weight_kernel(const float *__restrict__ W, int N, int K, int Npad, int Kpad, __bf16 *__restrict__ hi,
+                                    __bf16 *__restrict__ lo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)Npad * Kpad) return;
+    const int n = (int)(i / Kpad), k = (int)(i - (int64_t)n * Kpad);
+    const float v = (n < N && k < K) ? W[(int64_t)n * K + k] : 0.f;
+    const __bf16 hh = (__bf16)v;
+    hi[i] = hh;
+    lo[i] = (__bf16)(v - (float)hh);
+}
+
+extern "C" SCP_API int scp_split_weight_bf16(const float *W, int32_t N, int32_t K, int32_t Npad, int32_t Kpad, void *hi, void *lo, void *stream) {
+    if (!W || !hi || !lo || N <= 0 || K <= 0 || Npad < N || Kpad < K || (Npad % BN) || (Kpad % BK)) return SCP_EINVAL;
+    const int64_t tot = (int64_t)Npad * Kpad;
+    hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream, W, N, K, Npad, Kpad,
+                       (__bf16 *)hi, (__bf16 *)lo);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+extern "C" SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void *Whi, const void *Wlo, int32_t Kpad, const float *bias,
+                                         const float *residual, int64_t ldr, float *C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                                         int32_t act, void *stream) {
+    if (!A || !Whi || !Wlo || !C || M <= 0 || N <= 0 || K <= 0 || (K & 3) || (lda & 3) || Kpad < K || (Kpad % BK) || act < 0 || act > 3 ||
+        ((uintptr_t)A & 15) || lda < K || ldc < N || (residual && ldr < N))
+        return SCP_EINVAL;
+    const dim3 grid((unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM)));
+#define GO(ACT) hipLaunchKernelGGL(gemm_bf16x3_kernel<ACT>, grid, dim3(256), 0, (hipStream_t)stream, A, lda, (const __bf16 *)Whi, \
+                              (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K)
+    switch (act) { case ACT_LEAKY: GO(ACT_LEAKY); break; case ACT_GELU: GO(ACT_GELU); break; case ACT_RELU: GO(ACT_RELU); break; default: GO(ACT_NONE); }
+#undef GO
+    LAUNCH_CHECK();
+    return SCP_OK;
+}

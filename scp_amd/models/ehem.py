@@ -137,7 +137,7 @@ def _edge_conv(conv, feat, k):
         conv._scp_packed = packed
     Wuv, scale, shift = packed
     idx = native.knn_topk(feat, k)
-    uv = linear(feat, Wuv, None)                      # [B,n,2C']
+    uv = linear(feat, Wuv, None, exact=True)          # [B,n,2C'] plain fp32: these features feed the next kNN search
     u = uv[..., :Cout].contiguous()
     v = uv[..., Cout:].contiguous()
     return native.edge_gather_max(u, v, idx, scale, shift)
@@ -155,7 +155,7 @@ def geo_feat_forward(g, ctx, pos):
     k = min(g.k, c)
     pos1 = _edge_conv(g.conv1, pos.contiguous(), k)
     pos2 = _edge_conv(g.conv2, torch.cat((pos1, x), 2), k)
-    x = leaky_mlp3(g.mlp2, x)
+    x = leaky_mlp3(g.mlp2, x, exact=True)     # feeds the third kNN search: keep plain fp32
     pos3 = _edge_conv(g.conv3, torch.cat((pos2, x), 2), k)
     x = leaky_mlp3(g.mlp3, x)
     ec = leaky_mlp3(g.edge_mlp1, torch.cat((pos1, pos2, pos3), 2))
@@ -193,10 +193,11 @@ def swin_layer_forward(layer, x, L, shift, query=None):
         kv = linear(h, Wqkv, bqkv)
         k, v = kv[..., :256], kv[..., 256:]
     o = native.swin_attention(q, k, v, att.relative_position_bias_table, shift)
-    o = linear(o, layer.attention.output.dense.weight, layer.attention.output.dense.bias)
-    x = x + o[:, :L]
+    if o.shape[1] != L:
+        o = o[:, :L].contiguous()
+    x = linear(o, layer.attention.output.dense.weight, layer.attention.output.dense.bias, residual=x)
     y = gelu_linear(layer_norm(x, layer.layernorm_after), layer.intermediate.dense.weight, layer.intermediate.dense.bias)
-    return x + linear(y, layer.output.dense.weight, layer.output.dense.bias)
+    return linear(y, layer.output.dense.weight, layer.output.dense.bias, residual=x)
 
 
 def patch_merge_forward(m, x, L):

@@ -70,6 +70,8 @@ def lib():
         "scp_edge_gather_max": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_swin_attention": (C.c_int, [_vp, _vp, _vp, _vp, i32, i32, i32, i32, i32, _vp, _vp]),
         "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
+        "scp_split_weight_bf16": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp, _vp]),
+        "scp_linear_bf16x3": (C.c_int, [_vp, i64, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp]),
         "scp_softmax_cdf": (C.c_int, [_vp, i64, i64, i32, _vp, _vp, _vp, _vp, _vp]),
         "scp_pmf_cdf": (C.c_int, [_vp, i64, i32, _vp, _vp, _vp, _vp]),
         "scp_ac_encode_cdf": (C.c_int, [_vp, _vp, i64, i32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -258,6 +260,48 @@ def swin_attention(q, k, v, bias_table, shift):
                                   q.stride(1), k.stride(1), _dev(out), _stream())
     _check(rc, "scp_swin_attention")
     return out
+
+
+ACT_NONE, ACT_LEAKY, ACT_GELU, ACT_RELU = 0, 1, 2, 3
+
+
+class SplitWeight:
+    """bf16 hi/lo planes of a Linear weight [N,K], zero-padded to [Npad,Kpad] (built once per weight)."""
+
+    def __init__(self, w):
+        N, K = w.shape
+        self.N, self.K = N, K
+        self.Npad, self.Kpad = -(-N // 128) * 128, -(-K // 32) * 32
+        self.hi = torch.empty((self.Npad, self.Kpad), dtype=torch.bfloat16, device=w.device)
+        self.lo = torch.empty_like(self.hi)
+        wc = w.detach().contiguous().float()
+        _check(lib().scp_split_weight_bf16(_dev(wc), N, K, self.Npad, self.Kpad, _dev(self.hi), _dev(self.lo), _stream()),
+               "scp_split_weight_bf16")
+
+
+def linear_bf16x3(x, sw, bias=None, act=ACT_NONE, residual=None, out=None):
+    """x [..., K] fp32 (unit last stride, uniform row stride) -> [..., N]; out may be a column slice of a wider buffer."""
+    K, N = sw.K, sw.N
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, K) if x.is_contiguous() else x
+    if x2.dim() != 2:
+        x2 = x.contiguous().reshape(-1, K)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        o2 = out
+    else:
+        o2 = out.reshape(-1, N) if out.is_contiguous() else out
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, N) if residual.is_contiguous() else residual.contiguous().reshape(-1, N)
+    rc = lib().scp_linear_bf16x3(x2.data_ptr(), x2.stride(0), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.Kpad, _opt(bias),
+                                 None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0), o2.data_ptr(),
+                                 o2.stride(0), M, N, K, act, _stream())
+    _check(rc, "scp_linear_bf16x3")
+    return out.reshape(*lead, N) if out.dim() == 2 and len(lead) != 1 else out
 
 
 def octattn_attention(q_u, k, k_u, v, v_u, heads):

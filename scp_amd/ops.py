@@ -1,15 +1,57 @@
-"""Dense-layer helpers used by the context models (fp32).
+"""Dense-layer helpers used by the context models.
 
-Plain library GEMMs (rocBLAS / hipBLASLt through torch.nn.functional.linear) carry the Linear layers;
-LayerNorm / GELU / LeakyReLU epilogues are device ops on the same stream.  Everything here requires
-device tensors - there is no CPU path in the product.
+Default path: the hand-written bf16x3 MFMA GEMM (csrc/gemm.hip, fp32-class accuracy, fused bias / activation / residual
+epilogue) through the C ABI.  `SCP_GEMM=f32` switches to plain fp32 library GEMMs (rocBLAS / hipBLASLt via torch) - used by
+the tests to bracket the numerical effect of the split, and automatically for shapes the kernel does not cover (K % 4 != 0
+or K < 32).  Everything here requires device tensors - there is no CPU path in the product.
 """
+import os
+import weakref
+
 import torch
 import torch.nn.functional as F
 
+from . import native
 
-def linear(x, w, b=None):
-    return F.linear(x, w, b)
+MODE = os.environ.get("SCP_GEMM", "bf16x3")
+_ACT = {None: native.ACT_NONE, "leaky": native.ACT_LEAKY, "gelu": native.ACT_GELU, "relu": native.ACT_RELU}
+_cache = {}
+
+
+def set_mode(mode):
+    global MODE
+    assert mode in ("bf16x3", "f32")
+    MODE = mode
+
+
+def _split(w):
+    """bf16 hi/lo planes of a weight, cached per tensor OBJECT (evicted when the tensor dies or is modified in place)."""
+    key = id(w)
+    ent = _cache.get(key)
+    if ent is None or ent[1] != w._version or ent[2]() is not w:
+        sw = native.SplitWeight(w)
+        _cache[key] = (sw, w._version, weakref.ref(w, lambda _r, k=key: _cache.pop(k, None)))
+        return sw
+    return ent[0]
+
+
+def clear_cache():
+    _cache.clear()
+
+
+def linear(x, w, b=None, act=None, residual=None, exact=False):
+    """act(x @ w.T + b) + residual.  exact=True keeps plain fp32 (used where the result feeds a kNN search)."""
+    K = w.shape[1]
+    if MODE == "bf16x3" and not exact and K % 4 == 0 and K >= 32 and x.is_cuda:
+        return native.linear_bf16x3(x, _split(w), b, _ACT[act], residual)
+    y = F.linear(x, w, b)
+    if act == "leaky":
+        y = F.leaky_relu(y, 0.01)
+    elif act == "gelu":
+        y = F.gelu(y)
+    elif act == "relu":
+        y = torch.relu(y)
+    return y if residual is None else y + residual
 
 
 def layer_norm(x, ln):
@@ -17,11 +59,11 @@ def layer_norm(x, ln):
 
 
 def gelu_linear(x, w, b):
-    return F.gelu(F.linear(x, w, b))
+    return linear(x, w, b, act="gelu")
 
 
-def leaky_mlp3(seq, x, slope=0.01):
+def leaky_mlp3(seq, x, slope=0.01, exact=False):
     """nn.Sequential(Linear, LeakyReLU, Linear, LeakyReLU, Linear) as stored under keys .0 / .2 / .4"""
-    x = F.leaky_relu(F.linear(x, seq[0].weight, seq[0].bias), slope)
-    x = F.leaky_relu(F.linear(x, seq[2].weight, seq[2].bias), slope)
-    return F.linear(x, seq[4].weight, seq[4].bias)
+    x = linear(x, seq[0].weight, seq[0].bias, act="leaky", exact=exact)
+    x = linear(x, seq[2].weight, seq[2].bias, act="leaky", exact=exact)
+    return linear(x, seq[4].weight, seq[4].bias, exact=exact)

@@ -125,6 +125,49 @@ def test_edge_conv_matches_oracle_formulation(dev, ehem):
     assert torch.allclose(got, want, atol=2e-5, rtol=1e-5)
 
 
+# ----------------------------------------------------------------------------------------------- dense layers
+@pytest.mark.parametrize("M,N,K", [(1, 255, 256), (7, 16, 32), (300, 768, 256), (1000, 256, 1024), (4100, 255, 512), (513, 240, 80)])
+@pytest.mark.parametrize("act", [None, "leaky", "gelu"])
+def test_linear_bf16x3_vs_float64(dev, M, N, K, act):
+    """bf16x3 split GEMM: fp32-class accuracy (the three-product split drops only the 2^-16 lo.lo term)."""
+    from scp_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn((M, K), generator=g)
+    w = torch.randn((N, K), generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn((M, N), generator=g)
+    ops.set_mode("bf16x3")
+    y = ops.linear(x.to(dev), w.to(dev), b.to(dev), act=act, residual=r.to(dev)).cpu().double()
+    ref = x.double() @ w.double().T + b.double()
+    if act == "leaky":
+        ref = torch.nn.functional.leaky_relu(ref, 0.01)
+    elif act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    ref = ref + r.double()
+    err = (y - ref).abs().max().item()
+    f32 = (torch.nn.functional.linear(x, w, b).double() - (x.double() @ w.double().T + b.double())).abs().max().item()
+    print(f"M={M} N={N} K={K} act={act}: bf16x3 err {err:.2e} (plain fp32 CPU matmul err {f32:.2e})")
+    assert err < 3e-5, err
+
+
+def test_ehem_logits_bf16x3_vs_fp32_library_gemm(dev, ehem):
+    """Same window through both dense-layer paths: the split changes the logits by far less than the 1e-3 tolerance."""
+    from scp_amd import ops
+    z = golden("logits_ehem_c1024")
+    data = torch.from_numpy(z["data"].astype(np.int64))[None].to(dev)
+    pos = torch.from_numpy(z["pos"])[None].to(dev)
+    try:
+        ops.set_mode("f32")
+        a1, a2 = ehem(data, pos)
+        ops.set_mode("bf16x3")
+        b1, b2 = ehem(data, pos)
+    finally:
+        ops.set_mode("bf16x3")
+    d = max((a1 - b1).abs().max().item(), (a2 - b2).abs().max().item())
+    print(f"bf16x3 vs fp32 library GEMMs: max|dlogit| = {d:.3e}")
+    assert d < 2e-4, d
+
+
 # ----------------------------------------------------------------------------------------------- Swin
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "swin_*_s*_L*.npz"))))
 def test_swin_layer_vs_reference(dev, name):

@@ -47,6 +47,12 @@ if 'gemm' in which:
         a = torch.randn((M, K), device=dev); w = torch.randn((N, K), device=dev); b = torch.randn(N, device=dev)
         ms = timeit(lambda: F.linear(a, w, b))
         print(f"torch linear M={M} N={N} K={K}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.2f} TFLOP/s")
+    from scp_amd import ops
+    for M, N, K in ((65536, 768, 256), (65536, 256, 256), (65536, 1024, 256), (65536, 256, 1024), (65536, 1024, 1280), (8192, 768, 256), (512, 768, 256)):
+        a = torch.randn((M, K), device=dev); w = torch.randn((N, K), device=dev); b = torch.randn(N, device=dev); r = torch.randn((M, N), device=dev)
+        ops.set_mode("bf16x3")
+        ms = timeit(lambda: ops.linear(a, w, b, act="gelu", residual=r))
+        print(f"bf16x3 linear+gelu+res M={M} N={N} K={K}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.2f} TFLOP/s-equivalent")
     x = torch.randn((65536, 256), device=dev); ln_w = torch.ones(256, device=dev); ln_b = torch.zeros(256, device=dev)
     print(f"layer_norm 65536x256: {timeit(lambda: F.layer_norm(x, (256,), ln_w, ln_b))*1e3:.1f} us")
     y = torch.randn((65536, 1024), device=dev)
