@@ -140,6 +140,10 @@ SCP_API int scp_geom_context_octattn(scp_geom *g, int32_t seg, uint8_t *ctx, flo
  * the k largest of  2*xi.xj - |xj|^2 - |xi|^2  (dgcnn.py:18-20), ties -> lower index. */
 SCP_API int scp_knn_topk(const float *x, int32_t B, int32_t n, int32_t C, int32_t k, int32_t *idx, void *stream);
 
+/* packed ("varlen") form for many windows in one launch: x [total_rows][C], every sequence padded to a multiple of 512 rows;
+ * ctab[2c] = first row of the sequence owning 512-row chunk c, ctab[2c+1] = its real length; idx [total_rows][20] holds GLOBAL rows */
+SCP_API int scp_knn_topk_packed(const float *x, const int32_t *ctab, int32_t total_rows, int32_t C, int32_t *idx, void *stream);
+
 /* edge-conv tail: out[b][i][c] = lrelu_0.2( scale[c] * (sel_j u[b][idx[b][i][j]][c] + v[b][i][c]) + shift[c] ),
  * sel = max when scale[c] >= 0 else min  (== max over j of BN(conv(edge feature)), dgcnn.py:62-71,132-134) */
 SCP_API int scp_edge_gather_max(const float *u, const float *v, const int32_t *idx, const float *scale, const float *shift,
@@ -162,6 +166,10 @@ SCP_API int scp_split_weight_bf16(const float *W, int32_t N, int32_t K, int32_t 
 SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void *Whi, const void *Wlo, int32_t Kpad, const float *bias,
                       const float *residual, int64_t ldr, float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act,
                       void *stream);
+
+/* packed form: total_windows windows of 512 rows; wtab[2w] = first row of the sequence owning window w, wtab[2w+1] = its padded length */
+SCP_API int scp_swin_attention_packed(const float *q, const float *k, const float *v, const float *bias_table, const int32_t *wtab,
+                              int32_t total_windows, int32_t shift, int32_t ldq, int32_t ldkv, float *out, void *stream);
 
 /* OctAttention dual-stream causal attention (attention_model.py:58-95): heads of width hd,
  * q_u,k,k_u,v,v_u [B][c][H*hd] -> out, out_u [B][c][H*hd] */

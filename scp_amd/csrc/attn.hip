@@ -28,7 +28,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256, 2) void swin_attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                           const float *__restrict__ v, const float *__restrict__ table,
-                                                          int Lp, int shift, int ldq, int ldkv, float *__restrict__ out) {
+                                                          int Lp, int shift, int ldq, int ldkv, float *__restrict__ out,
+                                                          const int *__restrict__ wtab /* per 512-window: (sequence base row, sequence Lp) or NULL */) {
     __shared__ __attribute__((aligned(16))) float Ks[KT * LDK];
     __shared__ __attribute__((aligned(16))) float Vs[KT * HD];
     __shared__ float tab[2 * WIN - 1];
@@ -37,10 +38,13 @@ __global__ __launch_bounds__(256, 2) void swin_attn_kernel(const float *__restri
     int bid = blockIdx.x;
     const int qtile = bid & 3; bid >>= 2;
     const int head = bid & 3; bid >>= 2;
-    const int nW = Lp / WIN;
-    const int wnd = bid % nW, b = bid / nW;
-    const size_t base = (size_t)b * Lp * (NH * HD) + head * HD;        // output (dense [B][Lp][256])
-    const size_t qbase = (size_t)b * Lp * ldq + head * HD, kbase = (size_t)b * Lp * ldkv + head * HD;
+    // dense mode: B sequences of Lp rows each; packed mode: sequences of different (x512) lengths back to back, described per window
+    size_t seq_row;
+    int wnd, nW;
+    if (wtab) { seq_row = (size_t)wtab[2 * bid]; Lp = wtab[2 * bid + 1]; nW = Lp / WIN; wnd = (int)(((size_t)bid * WIN - seq_row) / WIN); }
+    else { nW = Lp / WIN; wnd = bid % nW; seq_row = (size_t)(bid / nW) * Lp; }
+    const size_t base = seq_row * (NH * HD) + head * HD;        // output (dense rows of 256)
+    const size_t qbase = seq_row * ldq + head * HD, kbase = seq_row * ldkv + head * HD;
     const bool masked = (shift > 0) && (wnd == nW - 1);
 
     for (int i = tid; i < 2 * WIN - 1; i += 256) tab[i] = table[i * NH + head];
@@ -136,13 +140,25 @@ __global__ __launch_bounds__(256, 2) void swin_attn_kernel(const float *__restri
     }
 }
 
+// packed ("varlen") form: total_windows 512-row windows, wtab[2*w] = first row of the sequence that owns window w, wtab[2*w+1] = its padded length
+extern "C" int scp_swin_attention_packed(const float *q, const float *k, const float *v, const float *bias_table, const int32_t *wtab,
+                                         int32_t total_windows, int32_t shift, int32_t ldq, int32_t ldkv, float *out, void *stream) {
+    if (!q || !k || !v || !bias_table || !out || !wtab || total_windows <= 0 || (shift != 0 && shift != WIN / 2) || ldq < NH * HD ||
+        ldkv < NH * HD || (ldq & 3) || (ldkv & 3) || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15))
+        return SCP_EINVAL;
+    hipLaunchKernelGGL(swin_attn_kernel, dim3(total_windows * NH * (WIN / QT)), dim3(256), 0, (hipStream_t)stream, q, k, v, bias_table, 0, shift,
+                       ldq, ldkv, out, wtab);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
 extern "C" int scp_swin_attention(const float *q, const float *k, const float *v, const float *bias_table, int32_t B, int32_t Lp,
                                   int32_t shift, int32_t ldq, int32_t ldkv, float *out, void *stream) {
     if (!q || !k || !v || !bias_table || !out || B <= 0 || Lp <= 0 || (Lp % WIN) != 0 || (shift != 0 && shift != WIN / 2) ||
         ldq < NH * HD || ldkv < NH * HD || (ldq & 3) || (ldkv & 3) || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15))
         return SCP_EINVAL;
     const int nblk = B * (Lp / WIN) * NH * (WIN / QT);
-    hipLaunchKernelGGL(swin_attn_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, q, k, v, bias_table, Lp, shift, ldq, ldkv, out);
+    hipLaunchKernelGGL(swin_attn_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, q, k, v, bias_table, Lp, shift, ldq, ldkv, out, (const int *)nullptr);
     LAUNCH_CHECK();
     return SCP_OK;
 }

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float *__restrict__ x
 // ------------------------------------------------------------------------------------------------ specialised kernel
 template <int KS>   // MFMA k-steps = padded C / 2
 __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xx, int n, int C, int k,
-                                                         int *__restrict__ idx) {
+                                                         int *__restrict__ idx, const int *__restrict__ ctab /* packed mode: per 512-row chunk (seq base row, seq n) */) {
     constexpr int K = 2 * KS;                       // padded feature count (multiple of 4)
     constexpr int LD = (K % 8 == 0) ? K + 4 : K;    // LDS row stride in floats: LD/4 odd -> conflict-free ds_read_b128
     constexpr int F4 = K / 4;                       // float4 per candidate row
@@ -63,9 +63,20 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
     int *midx = (int *)(pool + 128 * 2 * TK);
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, col = lane & 31, h = lane >> 5;
-    const float *xb = x + (size_t)blockIdx.y * n * C;
-    const float *xxb = xx + (size_t)blockIdx.y * n;
-    const int q0 = blockIdx.x * 128;
+    // dense mode: blockIdx.y = batch item with n points.  packed mode: sequences padded to x512 rows lie back to back; the chunk
+    // table says which sequence (first row, real length) the 128 query rows of this workgroup belong to; indices come out GLOBAL
+    // and always TK per row (rows of sequences shorter than TK repeat their nearest neighbour, harmless under the max-pool).
+    size_t row0 = (size_t)blockIdx.y * n;
+    int q0 = blockIdx.x * 128;
+    if (ctab) {
+        const int ch = (blockIdx.x * 128) >> 9;
+        row0 = (size_t)ctab[2 * ch];
+        n = ctab[2 * ch + 1];
+        q0 = blockIdx.x * 128 - (int)row0;
+        if (q0 >= n) return;   // workgroup entirely inside the padding of its sequence
+    }
+    const float *xb = x + row0 * C;
+    const float *xxb = xx + row0;
     const int qi = q0 + w * 32 + col;
     const int nt = (n + 31) >> 5;
 
@@ -199,15 +210,23 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
     __syncthreads();
     if (tid < 128 && q0 + tid < n) {
         int h0 = 0, h1 = 0;
-        int *out = idx + ((size_t)blockIdx.y * n + q0 + tid) * k;
+        const int kk = ctab ? (n < TK ? n : TK) : k;                  // neighbours that exist
+        const int kout = ctab ? TK : k;                               // entries written per row
+        const int add = ctab ? (int)row0 : 0;
+        int *out = idx + (row0 + q0 + tid) * (size_t)kout;
         const float *va = mval + (tid * 2) * TK, *vb = va + TK;
         const int *ia = midx + (tid * 2) * TK, *ib = ia + TK;
-        for (int o = 0; o < k; ++o) {
-            const float a = h0 < TK ? va[h0] : -INFINITY, b = h1 < TK ? vb[h1] : -INFINITY;
-            const int ja = h0 < TK ? ia[h0] : INT_MAX, jb = h1 < TK ? ib[h1] : INT_MAX;
-            const bool takea = (a > b) || (a == b && ja < jb);
-            out[o] = takea ? ja : jb;
-            if (takea) ++h0; else ++h1;
+        int first = 0;
+        for (int o = 0; o < kout; ++o) {
+            if (o < kk) {
+                const float a = h0 < TK ? va[h0] : -INFINITY, b = h1 < TK ? vb[h1] : -INFINITY;
+                const int ja = h0 < TK ? ia[h0] : INT_MAX, jb = h1 < TK ? ib[h1] : INT_MAX;
+                const bool takea = (a > b) || (a == b && ja < jb);
+                const int j = (takea ? ja : jb) + add;
+                if (o == 0) first = j;
+                out[o] = j;
+                if (takea) ++h0; else ++h1;
+            } else out[o] = first;
         }
     }
 }
@@ -313,9 +332,10 @@ extern "C" int scp_knn_topk(const float *x, int32_t B, int32_t n, int32_t C, int
     hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)cdiv64(npts, 256)), dim3(256), 0, st, x, npts, C, xx);
     LAUNCH_CHECK();
     const dim3 grid2((n + 127) / 128, B);
-    if (C <= 4) hipLaunchKernelGGL(knn_mfma_kernel<2>, grid2, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx);
-    else if (C == 144) hipLaunchKernelGGL(knn_mfma_kernel<72>, grid2, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx);
-    else if (C == 192) hipLaunchKernelGGL(knn_mfma_kernel<96>, grid2, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx);
+    const int *none = nullptr;
+    if (C <= 4) hipLaunchKernelGGL(knn_mfma_kernel<2>, grid2, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, none);
+    else if (C == 144) hipLaunchKernelGGL(knn_mfma_kernel<72>, grid2, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, none);
+    else if (C == 192) hipLaunchKernelGGL(knn_mfma_kernel<96>, grid2, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, none);
     else {
         const int Cpad = (C + 3) & ~3;
         int ldC = Cpad;
@@ -329,6 +349,25 @@ extern "C" int scp_knn_topk(const float *x, int32_t B, int32_t n, int32_t C, int
         }
         hipLaunchKernelGGL(knn_generic_kernel, dim3((n + 63) / 64, B), dim3(256), lds, st, x, (const float *)xx, n, C, ldC, k, idx);
     }
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+
+// packed ("varlen") form: x [total_rows][C] with sequences padded to multiples of 512 rows, ctab[2*c] = first row of the sequence owning
+// 512-row chunk c, ctab[2*c+1] = its real length; idx [total_rows][20] GLOBAL row indices (rows beyond a sequence's length are not written).
+extern "C" SCP_API int scp_knn_topk_packed(const float *x, const int32_t *ctab, int32_t total_rows, int32_t C, int32_t *idx, void *stream) {
+    if (!x || !ctab || !idx || total_rows <= 0 || (total_rows & 511) || (C != 144 && C != 192 && C > 4)) return SCP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = g_xx.reserve((size_t)total_rows * sizeof(float));
+    if (rc) return rc;
+    float *xx = g_xx.as<float>();
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)cdiv64(total_rows, 256)), dim3(256), 0, st, x, (int64_t)total_rows, C, xx);
+    LAUNCH_CHECK();
+    const dim3 grid(total_rows / 128, 1);
+    if (C <= 4) hipLaunchKernelGGL(knn_mfma_kernel<2>, grid, dim3(256), 0, st, x, (const float *)xx, 0, C, TK, idx, ctab);
+    else if (C == 144) hipLaunchKernelGGL(knn_mfma_kernel<72>, grid, dim3(256), 0, st, x, (const float *)xx, 0, C, TK, idx, ctab);
+    else hipLaunchKernelGGL(knn_mfma_kernel<96>, grid, dim3(256), 0, st, x, (const float *)xx, 0, C, TK, idx, ctab);
     LAUNCH_CHECK();
     return SCP_OK;
 }

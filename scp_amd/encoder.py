@@ -64,8 +64,10 @@ class EncodePlan:
 
 class FrameEncoder:
     def __init__(self, model, data_type=KITTI, lidar_level=12, spher=True, cylin=False, mullevel=False, max_batch=8,
-                 device=None):
+                 device=None, packed=True, max_tokens=320_000):
         self.model = model
+        self.packed = packed            # one packed forward for all windows (default) vs one forward per group of equal windows
+        self.max_tokens = max_tokens
         self.data_type = data_type
         self.lidar_level = lidar_level
         self.mode = native.CYLIN if cylin else (native.SPHER if spher else native.CART)
@@ -120,6 +122,8 @@ class FrameEncoder:
 
     # ------------------------------------------------------------------------------------------ stage M + C
     def logits_in_coding_order(self, pre, plan):
+        if self.packed:
+            return self.logits_packed(pre, plan)
         N = plan.n_rows
         table = torch.empty((N, 255), dtype=torch.float32, device=self.device)
         ctx, pos = pre["ctx"], pre["pos"]
@@ -136,6 +140,27 @@ class FrameEncoder:
                 table[coded:coded + ne] = o1[b]
                 if c > 1:
                     table[coded + ne:coded + c] = o2[b]
+        return table
+
+    def logits_packed(self, pre, plan):
+        """All windows of the frame through ONE packed forward per chunk of <= max_tokens tokens (models/packed.py)."""
+        from .models.packed import PackedPlan
+        table = torch.empty((plan.n_rows, 255), dtype=torch.float32, device=self.device)
+        ctx, pos = pre["ctx"], pre["pos"]
+        ws = plan.windows
+        i = 0
+        while i < len(ws):
+            j, tok = i, 0
+            while j < len(ws) and (tok == 0 or tok + ws[j][1] <= self.max_tokens):
+                tok += ws[j][1]
+                j += 1
+            r0 = ws[i][0]
+            pp = PackedPlan([w[1] for w in ws[i:j]], device=self.device)
+            ev, od = self.model.forward_packed(ctx[r0:r0 + tok], pos[r0:r0 + tok], None, plan=pp)
+            table[pp.d["even_dst"] + r0] = ev
+            if od.shape[0]:
+                table[pp.d["odd_dst"] + r0] = od
+            i = j
         return table
 
     def encode(self, xyz, timing=False):

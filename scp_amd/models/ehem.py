@@ -143,6 +143,29 @@ def _edge_conv(conv, feat, k):
     return native.edge_gather_max(u, v, idx, scale, shift)
 
 
+def _edge_conv_packed(conv, feat, ktab):
+    """packed layout: feat [T,C] (all windows back to back, padded to x512 rows), ktab int32 [T/512,2] -> [T,C']."""
+    W = conv[0].weight
+    bn = conv[1]
+    Cout, C2 = W.shape[0], W.shape[1]
+    C = C2 // 2
+    packed = getattr(conv, "_scp_packed", None)
+    if packed is None or packed[0].device != W.device:
+        W2d = W.detach().reshape(Cout, C2)
+        Wuv = torch.cat((W2d[:, :C], W2d[:, C:] - W2d[:, :C]), 0).contiguous()
+        scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).contiguous()
+        shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+        packed = (Wuv, scale, shift)
+        conv._scp_packed = packed
+    Wuv, scale, shift = packed
+    feat = feat.contiguous()
+    idx = native.knn_topk_packed(feat, ktab)
+    uv = linear(feat, Wuv, None, exact=True)
+    u = uv[:, :Cout].contiguous()
+    v = uv[:, Cout:].contiguous()
+    return native.edge_gather_max(u[None], v[None], idx[None], scale, shift)[0]
+
+
 def geo_feat_forward(g, ctx, pos):
     """ctx int64 [B,c,12] (level, octant, occ) x 4 with the self occupancy still present; pos [B,c,3] f32."""
     B, c = ctx.shape[:2]
@@ -264,6 +287,17 @@ class EHEM(nn.Module):
             raise native.ScpError("EHEM runs on the MI355X only (no CPU fallback); move the inputs to cuda")
         B, c = data.shape[:2]
         return self.forward_ctx(data.reshape(B, c, 12).long(), pos.transpose(1, 2).contiguous())
+
+    @torch.no_grad()
+    def forward_packed(self, ctx, pos, lengths, plan=None):
+        """All windows in one pass: ctx [T,12], pos [T,3] (windows back to back), lengths = window sizes.
+        Returns (even rows [sum ceil(c/2),255], odd rows [sum floor(c/2),255]); see models/packed.py."""
+        from .packed import PackedPlan, ehem_forward_packed
+        if not ctx.is_cuda:
+            raise native.ScpError("EHEM runs on the MI355X only (no CPU fallback)")
+        if plan is None:
+            plan = PackedPlan(lengths, device=ctx.device)
+        return ehem_forward_packed(self, ctx, pos, plan)
 
     @torch.no_grad()
     def forward_ctx(self, ctx, pos):

@@ -67,6 +67,8 @@ def lib():
         "scp_geom_context_ehem": (C.c_int, [_vp, i32, i32, i32, _vp, _vp, _vp, _vp, _vp]),
         "scp_geom_context_octattn": (C.c_int, [_vp, i32, _vp, _vp, _vp, _vp]),
         "scp_knn_topk": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp]),
+        "scp_knn_topk_packed": (C.c_int, [_vp, _vp, i32, i32, _vp, _vp]),
+        "scp_swin_attention_packed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp]),
         "scp_edge_gather_max": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_swin_attention": (C.c_int, [_vp, _vp, _vp, _vp, i32, i32, i32, i32, i32, _vp, _vp]),
         "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
@@ -230,6 +232,24 @@ def knn_topk(x, k):
     idx = torch.empty((B, n, k), dtype=torch.int32, device=x.device)
     _check(lib().scp_knn_topk(_dev(x, torch.float32), B, n, Cc, k, _dev(idx), _stream()), "scp_knn_topk")
     return idx
+
+
+def knn_topk_packed(x, ctab):
+    """x cuda f32 [T,C] (T % 512 == 0), ctab cuda int32 [T/512, 2] = (sequence base row, real length) -> idx int32 [T,20] global."""
+    T, Cc = x.shape
+    idx = torch.zeros((T, 20), dtype=torch.int32, device=x.device)
+    _check(lib().scp_knn_topk_packed(_dev(x, torch.float32), _dev(ctab, torch.int32), T, Cc, _dev(idx), _stream()), "scp_knn_topk_packed")
+    return idx
+
+
+def swin_attention_packed(q, k, v, bias_table, wtab, shift):
+    """q,k,v cuda f32 [T,256] views (unit channel stride), wtab int32 [T/512, 2] = (sequence base row, padded length)."""
+    T = q.shape[0]
+    out = torch.empty((T, 256), dtype=torch.float32, device=q.device)
+    rc = lib().scp_swin_attention_packed(q.data_ptr(), k.data_ptr(), v.data_ptr(), _dev(bias_table, torch.float32),
+                                         _dev(wtab, torch.int32), T // 512, shift, q.stride(0), k.stride(0), _dev(out), _stream())
+    _check(rc, "scp_swin_attention_packed")
+    return out
 
 
 def edge_gather_max(u, v, idx, scale, shift, out=None):

@@ -248,6 +248,31 @@ def test_ehem_forward_ctx_equals_reference_signature(dev, ehem):
         ehem(data.cpu(), pos.cpu())      # no CPU fallback
 
 
+def test_packed_forward_equals_per_window_forward(dev, ehem):
+    """models/packed.py: windows of assorted lengths in ONE pass == one forward per window (same kernels, same numerics)."""
+    z = golden("logits_ehem_c1024")
+    data = torch.from_numpy(z["data"].astype(np.int64)).to(dev)       # [1024,4,3]
+    pos = torch.from_numpy(z["pos"]).to(dev)                            # [3,1024]
+    lengths = [1, 7, 2, 300, 513, 1, 200]
+    assert sum(lengths) == 1024
+    ctx = data.reshape(1024, 12).to(torch.uint8)
+    p = pos.T.contiguous()
+    ev, od = ehem.forward_packed(ctx, p, lengths)
+    a = 0
+    e0 = o0 = 0
+    worst = 0.0
+    for c in lengths:
+        r1, r2 = ehem.forward_ctx(ctx[a:a + c][None], p[a:a + c][None])
+        ne, no = (c + 1) // 2, c // 2
+        worst = max(worst, (ev[e0:e0 + ne] - r1[0]).abs().max().item())
+        if no:
+            worst = max(worst, (od[o0:o0 + no] - r2[0]).abs().max().item())
+        a += c; e0 += ne; o0 += no
+    assert e0 == ev.shape[0] and o0 == od.shape[0]
+    print(f"packed vs per-window forward: max|dlogit| = {worst:.3e}")
+    assert worst < 2e-4, worst
+
+
 # ----------------------------------------------------------------------------------------------- OctAttention
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_octattn_*.npz"))))
 def test_octattn_logits_vs_reference(dev, octattn, name):
