@@ -131,12 +131,11 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        enc.encode(frames[i])
+        enc.finish(enc.encode_async(frames[i]))
     barrier()
     t0 = time.perf_counter()
-    results = []
-    for i in range(args.warmup, total):
-        results.append(enc.encode(frames[i]))
+    handles = [enc.encode_async(frames[i]) for i in range(args.warmup, total)]   # frame i is range-coded on a worker thread
+    results = [enc.finish(h) for h in handles]                                        # while frame i+1 runs on the GPU
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

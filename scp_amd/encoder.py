@@ -12,6 +12,7 @@ Per-window softmax, the [N,255] PMF table on the host, the int64 [N,4,6] records
 the reference do not exist here.  The returned dict carries the same scalars the reference prints.
 """
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -51,6 +52,16 @@ class EncodePlan:
             for i in range(0, len(ws), max_batch):
                 out.append((c, ws[i:i + max_batch]))
         return out
+
+    def coding_order_device(self, dev):
+        """coding_order() built with vectorised device ops (no per-window host loop over 577k rows)."""
+        w = torch.as_tensor(np.asarray(self.windows, np.int64), device=dev)          # [W,3] (start, length, coded)
+        start, c = w[:, 0], w[:, 1]
+        ne = (c + 1) // 2
+        wid = torch.repeat_interleave(torch.arange(len(self.windows), device=dev), c)
+        pos = torch.arange(self.n_rows, device=dev) - start[wid]                        # coded position inside the window
+        even = pos < ne[wid]
+        return start[wid] + torch.where(even, 2 * pos, 2 * (pos - ne[wid]) + 1)
 
     def coding_order(self):
         """Row index (frame order) of every coded position - for tests and for the reference-compatible view."""
@@ -179,13 +190,56 @@ class FrameEncoder:
               for q in qs]
         return self._encode_pre(self.preprocess_ints(dq, bin_num, z_offset, n_points), t0, timing)
 
+    # ------------------------------------------------------------------------------------------ pipelined variant
+    def encode_async(self, xyz):
+        """Like encode(), but the D2H copy of the (c_low, c_high) pairs and the serial host range coder run on a worker
+        thread (ctypes releases the GIL) behind an event on a side stream, so the caller can enqueue the next frame while this
+        one is being coded.  Returns a handle; `finish(handle)` blocks and returns the usual result dict."""
+        t0 = time.perf_counter()
+        if isinstance(xyz, np.ndarray):
+            xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
+        pre = self.preprocess(xyz.to(self.device, non_blocking=True))
+        plan = EncodePlan(pre["level_sizes"], self.context_size)
+        table = self.logits_in_coding_order(pre, plan)
+        order = plan.coding_order_device(self.device)
+        sym_coded = pre["sym"][order].contiguous()
+        lohi = native.softmax_cdf(table, sym_coded)["lohi"]
+        if not hasattr(self, "_pool"):
+            self._pool = ThreadPoolExecutor(max_workers=2)
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        done = torch.cuda.Event()
+        done.record()
+        host = torch.empty(lohi.shape, dtype=lohi.dtype, pin_memory=True)
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(done)
+            host.copy_(lohi, non_blocking=True)
+            lohi.record_stream(self._copy_stream)
+            copied = torch.cuda.Event()
+            copied.record()
+
+        def work():
+            copied.synchronize()
+            return native.ac_encode_lohi(host.numpy())
+
+        fut = self._pool.submit(work)
+        return dict(future=fut, pre=pre, plan=plan, t0=t0)
+
+    def finish(self, h):
+        stream = h["future"].result()
+        pre, plan = h["pre"], h["plan"]
+        bits = 8 * len(stream)
+        return dict(bytes=stream, bits=bits, bpp=bits / pre["n_points"], n_nodes=plan.n_rows, n_points=pre["n_points"],
+                    bin_num=pre["bin_num"], z_offset=pre["z_offset"], n_levels=len(pre["level_sizes"]),
+                    pos_mm=pre["pos_mm"].cpu().numpy(), level_sizes=pre["level_sizes"],
+                    times=dict(total=time.perf_counter() - h["t0"]))
+
     def _encode_pre(self, pre, t0, timing):
         if timing:
             torch.cuda.synchronize()
         t1 = time.perf_counter()
         plan = EncodePlan(pre["level_sizes"], self.context_size)
         table = self.logits_in_coding_order(pre, plan)
-        order = torch.from_numpy(plan.coding_order()).to(self.device)
+        order = plan.coding_order_device(self.device)
         sym_coded = pre["sym"][order].contiguous()
         if timing:
             torch.cuda.synchronize()

@@ -22,58 +22,66 @@ def _ceil512(a):
     return (a + WINDOW - 1) // WINDOW * WINDOW
 
 
+def _tokens(L):
+    """(window id, position in window) of every real token of a layout, windows concatenated (device tensors)."""
+    wid = torch.repeat_interleave(torch.arange(L.numel(), device=L.device), L)
+    first = torch.cumsum(L, 0) - L
+    return wid, torch.arange(int(L.sum()), device=L.device) - first[wid]
+
+
 class StageLayout:
     """Rows of one Swin stage: window i owns rows [base[i], base[i] + Lp[i]), the first L[i] of them real."""
 
     def __init__(self, L):
-        self.L = np.asarray(L, np.int64)
-        self.Lp = _ceil512(self.L)
-        self.base = np.concatenate(([0], np.cumsum(self.Lp)[:-1]))
+        self.L = L
+        self.Lp = _ceil512(L)
+        self.base = torch.cumsum(self.Lp, 0) - self.Lp
         self.rows = int(self.Lp.sum())
+        self.wid, self.t = _tokens(L)
+        self.real_rows = self.base[self.wid] + self.t          # global rows of the real tokens
 
     def table(self, real=False):
         """int32 [rows/512, 2]: (sequence base row, padded length | real length) for every 512-row chunk."""
         reps = self.Lp // WINDOW
-        return np.stack([np.repeat(self.base, reps), np.repeat(self.L if real else self.Lp, reps)], 1).astype(np.int32)
+        return torch.stack([torch.repeat_interleave(self.base, reps), torch.repeat_interleave(self.L if real else self.Lp, reps)],
+                           1).to(torch.int32).contiguous()
 
     def valid(self):
-        v = np.zeros(self.rows, np.float32)
-        for b, l in zip(self.base, self.L):
-            v[b:b + l] = 1.0
-        return v
+        v = torch.zeros(self.rows, dtype=torch.float32, device=self.L.device)
+        v[self.real_rows] = 1.0
+        return v[:, None]
 
-    def row_index(self, counts=None):
-        """global rows of the first counts[i] (default L[i]) tokens of every window, concatenated."""
-        counts = self.L if counts is None else counts
-        return np.concatenate([b + np.arange(c) for b, c in zip(self.base, counts)]) if len(self.base) else np.zeros(0, np.int64)
+    def row_index(self, counts):
+        """global rows of the first counts[i] tokens of every window, concatenated."""
+        wid, t = _tokens(counts)
+        return self.base[wid] + t
 
 
 def _merge_maps(cur, nxt):
     """patch merging cur -> nxt: rows (even, odd) of cur feeding every row of nxt; `cur.rows` is the index of an all-zero row."""
-    even = np.full(nxt.rows, cur.rows, np.int64)
-    odd = np.full(nxt.rows, cur.rows, np.int64)
-    for i in range(len(cur.L)):
-        t = np.arange(nxt.L[i])
-        even[nxt.base[i] + t] = cur.base[i] + 2 * t
-        o = 2 * t + 1
-        odd[nxt.base[i] + t] = np.where(o < cur.L[i], cur.base[i] + o, cur.rows)
+    dev = cur.L.device
+    even = torch.full((nxt.rows,), cur.rows, dtype=torch.int64, device=dev)
+    odd = torch.full((nxt.rows,), cur.rows, dtype=torch.int64, device=dev)
+    even[nxt.real_rows] = cur.base[nxt.wid] + 2 * nxt.t
+    o = 2 * nxt.t + 1
+    odd[nxt.real_rows] = torch.where(o < cur.L[nxt.wid], cur.base[nxt.wid] + o, torch.full_like(o, cur.rows))
     return even, odd
 
 
 def _concat_map(l0, ls, s):
     """rows of stage-s layout `ls` that stage-0 token t of each window gathers (t >> s)."""
-    m = np.zeros(l0.rows, np.int64)
-    for i in range(len(l0.L)):
-        t = np.arange(l0.L[i])
-        m[l0.base[i] + t] = ls.base[i] + (t >> s)
+    m = torch.zeros(l0.rows, dtype=torch.int64, device=l0.L.device)
+    m[l0.real_rows] = ls.base[l0.wid] + (l0.t >> s)
     return m
 
 
 class PackedPlan:
-    """All index maps for one list of window lengths (host side, numpy; uploaded once)."""
+    """All index maps for one list of window lengths, built ON THE DEVICE from the (tiny) list of lengths with a few dozen
+    vectorised index ops - the host never touches a per-token array."""
 
     def __init__(self, lengths, n_self=5, n_cross=4, device=None):
-        c = np.asarray(lengths, np.int64)
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        c = torch.as_tensor(np.asarray(lengths, np.int64), device=dev)
         self.c = c
         e = c + (c & 1)                                   # ehem.py:92-99: odd windows get one pad token
         self.self_layouts = [StageLayout(e)]
@@ -85,45 +93,27 @@ class PackedPlan:
         P0, Q0 = self.self_layouts[0], self.cross_layouts[0]
         # input gather: token rows of the frame arrays (window i = rows [start_i, start_i + c_i)); sentinel = pad token
         self.n_tokens = int(c.sum())
-        starts = np.concatenate(([0], np.cumsum(c)[:-1]))
-        inmap = np.full(P0.rows, self.n_tokens, np.int64)
-        for i in range(len(c)):
-            inmap[P0.base[i]:P0.base[i] + c[i]] = starts[i] + np.arange(c[i])
-        self.inmap = inmap
-        self.self_merge = [_merge_maps(self.self_layouts[s], self.self_layouts[s + 1]) for s in range(n_self - 1)]
-        self.cross_merge = [_merge_maps(self.cross_layouts[s], self.cross_layouts[s + 1]) for s in range(n_cross - 1)]
-        self.self_concat = [_concat_map(P0, self.self_layouts[s], s) for s in range(1, n_self)]
-        self.cross_concat = [_concat_map(Q0, self.cross_layouts[s], s) for s in range(1, n_cross)]
-        a1 = np.zeros(Q0.rows, np.int64)
-        a2 = np.zeros(Q0.rows, np.int64)
-        for i in range(len(c)):
-            t = np.arange(Q0.L[i])
-            a1[Q0.base[i] + t] = P0.base[i] + 2 * t
-            a2[Q0.base[i] + t] = P0.base[i] + 2 * t + 1
-        self.a1map, self.a2map = a1, a2
+        inmap = torch.full((P0.rows,), self.n_tokens, dtype=torch.int64, device=dev)
+        inmap[P0.row_index(c)] = torch.arange(self.n_tokens, device=dev)
+        a1 = torch.zeros(Q0.rows, dtype=torch.int64, device=dev)
+        a2 = torch.zeros(Q0.rows, dtype=torch.int64, device=dev)
+        a1[Q0.real_rows] = P0.base[Q0.wid] + 2 * Q0.t
+        a2[Q0.real_rows] = P0.base[Q0.wid] + 2 * Q0.t + 1
         # outputs in coding order: window i -> [evens (ceil(c/2)) | odds (floor(c/2))] (encode.py:126-131)
-        self.even_rows = Q0.row_index((c + 1) // 2)
-        self.odd_rows = Q0.row_index(c // 2)
-        ne = (c + 1) // 2
-        coded = np.concatenate(([0], np.cumsum(c)[:-1]))
-        self.even_dst = np.concatenate([coded[i] + np.arange(ne[i]) for i in range(len(c))])
-        self.odd_dst = np.concatenate([coded[i] + ne[i] + np.arange(c[i] // 2) for i in range(len(c))]) if (c // 2).sum() else np.zeros(0, np.int64)
-        if device is not None:
-            self.to(device)
-
-    def to(self, dev):
-        def up(a, dt=torch.int64):
-            return torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+        ne, no = (c + 1) // 2, c // 2
+        coded = torch.cumsum(c, 0) - c
+        we, te = _tokens(ne)
+        wo, to = _tokens(no)
         self.d = dict(
-            inmap=up(self.inmap), a1map=up(self.a1map), a2map=up(self.a2map),
-            even_rows=up(self.even_rows), odd_rows=up(self.odd_rows), even_dst=up(self.even_dst), odd_dst=up(self.odd_dst),
-            self_merge=[(up(a), up(b)) for a, b in self.self_merge], cross_merge=[(up(a), up(b)) for a, b in self.cross_merge],
-            self_concat=[up(m) for m in self.self_concat], cross_concat=[up(m) for m in self.cross_concat],
-            self_tab=[up(l.table(), torch.int32) for l in self.self_layouts], cross_tab=[up(l.table(), torch.int32) for l in self.cross_layouts],
-            knn_tab=up(self.self_layouts[0].table(real=True), torch.int32),
-            self_valid=[up(l.valid(), torch.float32)[:, None] for l in self.self_layouts],
-            cross_valid=[up(l.valid(), torch.float32)[:, None] for l in self.cross_layouts])
-        return self
+            inmap=inmap, a1map=a1, a2map=a2, even_rows=Q0.row_index(ne), odd_rows=Q0.row_index(no),
+            even_dst=coded[we] + te, odd_dst=coded[wo] + ne[wo] + to,
+            self_merge=[_merge_maps(self.self_layouts[s], self.self_layouts[s + 1]) for s in range(n_self - 1)],
+            cross_merge=[_merge_maps(self.cross_layouts[s], self.cross_layouts[s + 1]) for s in range(n_cross - 1)],
+            self_concat=[_concat_map(P0, self.self_layouts[s], s) for s in range(1, n_self)],
+            cross_concat=[_concat_map(Q0, self.cross_layouts[s], s) for s in range(1, n_cross)],
+            self_tab=[l.table() for l in self.self_layouts], cross_tab=[l.table() for l in self.cross_layouts],
+            knn_tab=P0.table(real=True),
+            self_valid=[l.valid() for l in self.self_layouts], cross_valid=[l.valid() for l in self.cross_layouts])
 
 
 def _swin_layer(layer, x, valid, wtab, shift, query=None):

@@ -89,6 +89,20 @@ def test_batched_windows_equal_single_windows(enc_parts):
     assert d < 1e-4, d
 
 
+def test_async_pipeline_equals_sync(enc_parts):
+    from scp_amd.encoder import FrameEncoder, EncodePlan
+    from scp_amd.synth import synth_frame
+    model, dev = enc_parts
+    enc = FrameEncoder(model, "kitti", 12, spher=True, device=dev)
+    frames = [synth_frame(s)[::12].copy() for s in (1, 2, 3)]
+    want = [enc.encode(f)["bytes"] for f in frames]
+    hs = [enc.encode_async(f) for f in frames]
+    got = [enc.finish(h)["bytes"] for h in hs]
+    assert got == want
+    plan = EncodePlan([1, 6, 8193, 7, 2], 8192)
+    assert np.array_equal(plan.coding_order_device(dev).cpu().numpy(), plan.coding_order())
+
+
 def test_determinism(enc_parts):
     from scp_amd.encoder import FrameEncoder
     from scp_amd.synth import synth_frame
