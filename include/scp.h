@@ -171,6 +171,16 @@ SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void *Whi, cons
 SCP_API int scp_swin_attention_packed(const float *q, const float *k, const float *v, const float *bias_table, const int32_t *wtab,
                               int32_t total_windows, int32_t shift, int32_t ldq, int32_t ldkv, float *out, void *stream);
 
+/* Token-wise glue of the packed forward (csrc/fused.hip):
+ *   scp_layernorm_rows: out[r] = valid[r] * LayerNorm_C(row), C in {256, 512}, eps as given; row = x[r] (ia == NULL), x[ia[r]] (C 256)
+ *                       or cat(x[ia[r]], x[ib[r]]) (C 512, patch merging swin_transformer.py:350-367); an index == n_src_rows is a zero row;
+ *                       valid (nullable) zeroes the rows a window pads after LayerNorm (swin_transformer.py:638-641)
+ *   scp_gather_rows   : out[r][0:C] = src[idx[r]][0:C] with independent row strides (concat_states ehem.py:75-86, even/odd split :113)  */
+SCP_API int scp_layernorm_rows(const float *x, int64_t ldx, int64_t n_src_rows, const int64_t *ia, const int64_t *ib, int32_t C,
+                       const float *gamma, const float *beta, const float *valid, float eps, float *out, int64_t ldo, int64_t rows,
+                       void *stream);
+SCP_API int scp_gather_rows(const float *src, int64_t lds, const int64_t *idx, int32_t C, float *out, int64_t ldo, int64_t rows, void *stream);
+
 /* OctAttention dual-stream causal attention (attention_model.py:58-95): heads of width hd,
  * q_u,k,k_u,v,v_u [B][c][H*hd] -> out, out_u [B][c][H*hd] */
 SCP_API int scp_octattn_attention(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,

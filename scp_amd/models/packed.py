@@ -113,7 +113,7 @@ class PackedPlan:
             cross_concat=[_concat_map(Q0, self.cross_layouts[s], s) for s in range(1, n_cross)],
             self_tab=[l.table() for l in self.self_layouts], cross_tab=[l.table() for l in self.cross_layouts],
             knn_tab=P0.table(real=True),
-            self_valid=[l.valid() for l in self.self_layouts], cross_valid=[l.valid() for l in self.cross_layouts])
+            self_valid=[l.valid().contiguous() for l in self.self_layouts], cross_valid=[l.valid().contiguous() for l in self.cross_layouts])
 
 
 def _swin_layer(layer, x, valid, wtab, shift, query=None):
@@ -132,26 +132,28 @@ def _swin_layer(layer, x, valid, wtab, shift, query=None):
         packed = (W, b, cross)
         layer._scp_packed_v = packed
     W, b, _ = packed
-    h = layer_norm(x, layer.layernorm_before) * valid
+    lnb = layer.layernorm_before
+    h = native.layernorm_rows(x, lnb.weight, lnb.bias, lnb.eps, valid=valid)
     if not cross:
         qkv = linear(h, W, b)
         q, k, v = qkv[:, :256], qkv[:, 256:512], qkv[:, 512:]
     else:
-        hq = layer_norm(query, layer.layernorm_before) * valid
+        hq = native.layernorm_rows(query, lnb.weight, lnb.bias, lnb.eps, valid=valid)
         q = linear(hq, att.query.weight, att.query.bias)
         kv = linear(h, W, b)
         k, v = kv[:, :256], kv[:, 256:]
     o = native.swin_attention_packed(q, k, v, att.relative_position_bias_table, wtab, shift)
     x = linear(o, layer.attention.output.dense.weight, layer.attention.output.dense.bias, residual=x)
-    y = linear(layer_norm(x, layer.layernorm_after), layer.intermediate.dense.weight, layer.intermediate.dense.bias, act="gelu")
+    lna = layer.layernorm_after
+    y = linear(native.layernorm_rows(x, lna.weight, lna.bias, lna.eps), layer.intermediate.dense.weight, layer.intermediate.dense.bias, act="gelu")
     return linear(y, layer.output.dense.weight, layer.output.dense.bias, residual=x)
 
 
 def _merge(m, x, maps):
-    ev, od = maps
-    xe = torch.cat((x, torch.zeros((1, x.shape[1]), dtype=x.dtype, device=x.device)))      # zero row for odd-length pads
-    y = torch.cat((xe[ev], xe[od]), 1)
-    return linear(layer_norm(y, m.norm), m.reduction.weight, None)
+    """SwinPatchMerging: gather (even, odd) token of every pair + LayerNorm(512) in one kernel, then the 512 -> 256 reduction."""
+    ev, od = maps          # index == x.shape[0] stands for the zero row an odd-length window is padded with
+    y = native.layernorm_rows(x, m.norm.weight, m.norm.bias, m.norm.eps, ia=ev, ib=od)
+    return linear(y, m.reduction.weight, None)
 
 
 def _encoder(enc, x, valids, tabs, merges, query=None):
@@ -167,8 +169,21 @@ def _encoder(enc, x, valids, tabs, merges, query=None):
     return hs
 
 
-def _concat(hs, cmaps):
-    return torch.cat([hs[1]] + [hs[s + 1][cmaps[s - 1]] for s in range(1, len(hs) - 1)], 1)
+def _concat(hs, cmaps, extra=None):
+    """concat_states (ehem.py:75-86): stage s is gathered at token >> s straight into its 256-column slot; `extra` = (src, map)
+    appends one more gathered slot (the odd-token features of the cross branch, ehem.py:124)."""
+    n = len(hs) - 1 + (1 if extra is not None else 0)
+    out = torch.empty((hs[1].shape[0], 256 * n), dtype=torch.float32, device=hs[1].device)
+    out[:, :256] = hs[1]
+    for s in range(1, len(hs) - 1):
+        native.gather_rows(hs[s + 1], cmaps[s - 1], out[:, 256 * s:256 * (s + 1)])
+    if extra is not None:
+        k = len(hs) - 1
+        if extra[1] is None:
+            out[:, 256 * k:] = extra[0]
+        else:
+            native.gather_rows(extra[0], extra[1], out[:, 256 * k:])
+    return out
 
 
 @torch.no_grad()
@@ -196,11 +211,13 @@ def ehem_forward_packed(model, ctx, pos, plan):
     feat = torch.cat((x, ec), 1)
     hs = _encoder(model.swin_self_transformer, feat, d["self_valid"], d["self_tab"], d["self_merge"])
     feat_a = leaky_mlp3(model.ancient_mlp, _concat(hs, d["self_concat"]))
-    a1, a2 = feat_a[d["a1map"]], feat_a[d["a2map"]]
+    Q0 = d["a1map"].shape[0]
+    a1 = native.gather_rows(feat_a, d["a1map"], torch.empty((Q0, 256), dtype=torch.float32, device=dev))
+    a2 = native.gather_rows(feat_a, d["a2map"], torch.empty((Q0, 256), dtype=torch.float32, device=dev))
     prob1 = leaky_mlp3(model.prob_pred_mlp1, a1)
     pre_occ = ctx0[d["a1map"], 11]
     occ_feat = leaky_mlp3(model.pre_occ_mlp, F.embedding(pre_occ, g.occ_enc.weight))
     pre = torch.cat((occ_feat, leaky_mlp3(model.pre_attn_mlp, a1)), 1)
     hc = _encoder(model.swin_cross_transformer, pre, d["cross_valid"], d["cross_tab"], d["cross_merge"], query=a2)
-    prob2 = leaky_mlp3(model.prob_pred_mlp2, torch.cat((_concat(hc, d["cross_concat"]), a2), 1))
+    prob2 = leaky_mlp3(model.prob_pred_mlp2, _concat(hc, d["cross_concat"], extra=(a2, None)))
     return prob1[d["even_rows"]], prob2[d["odd_rows"]]

@@ -74,6 +74,8 @@ def lib():
         "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
         "scp_split_weight_bf16": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp, _vp]),
         "scp_linear_bf16x3": (C.c_int, [_vp, i64, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp]),
+        "scp_layernorm_rows": (C.c_int, [_vp, i64, i64, _vp, _vp, i32, _vp, _vp, _vp, C.c_float, _vp, i64, i64, _vp]),
+        "scp_gather_rows": (C.c_int, [_vp, i64, _vp, i32, _vp, i64, i64, _vp]),
         "scp_softmax_cdf": (C.c_int, [_vp, i64, i64, i32, _vp, _vp, _vp, _vp, _vp]),
         "scp_pmf_cdf": (C.c_int, [_vp, i64, i32, _vp, _vp, _vp, _vp]),
         "scp_ac_encode_cdf": (C.c_int, [_vp, _vp, i64, i32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -322,6 +324,30 @@ def linear_bf16x3(x, sw, bias=None, act=ACT_NONE, residual=None, out=None):
                                  o2.stride(0), M, N, K, act, _stream())
     _check(rc, "scp_linear_bf16x3")
     return out.reshape(*lead, N) if out.dim() == 2 and len(lead) != 1 else out
+
+
+def layernorm_rows(x, gamma, beta, eps=1e-5, valid=None, ia=None, ib=None, out=None):
+    """x [n,256|512...] fp32 rows (unit channel stride).  Plain LN (ia None), LN of gathered rows (ia, C = 256) or of
+    cat(x[ia], x[ib]) (C = 512).  valid: fp32 [rows] or [rows,1] multiplier.  Returns [rows, C]."""
+    Cc = gamma.shape[0]
+    rows = x.shape[0] if ia is None else ia.shape[0]
+    if out is None:
+        out = torch.empty((rows, Cc), dtype=torch.float32, device=x.device)
+    rc = lib().scp_layernorm_rows(x.data_ptr(), x.stride(0), x.shape[0], None if ia is None else _dev(ia, torch.int64),
+                                  None if ib is None else _dev(ib, torch.int64), Cc, _dev(gamma), _dev(beta),
+                                  None if valid is None else _dev(valid, torch.float32), float(eps), out.data_ptr(), out.stride(0),
+                                  rows, _stream())
+    _check(rc, "scp_layernorm_rows")
+    return out
+
+
+def gather_rows(src, idx, out):
+    """out[r, :C] = src[idx[r], :C]; `out` may be a column slice of a wider buffer (C = out.shape[1])."""
+    Cc = out.shape[1]
+    rc = lib().scp_gather_rows(src.data_ptr(), src.stride(0), _dev(idx, torch.int64), Cc, out.data_ptr(), out.stride(0), idx.shape[0],
+                               _stream())
+    _check(rc, "scp_gather_rows")
+    return out
 
 
 def octattn_attention(q_u, k, k_u, v, v_u, heads):
