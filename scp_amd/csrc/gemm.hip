@@ -7,8 +7,8 @@
 // (oracle emulation + tests/test_gpu_model.py): max |dlogit| 4e-5, tolerance 1e-3.  kNN distances are NOT computed this way.
 //
 // Layout: W is torch's Linear weight [N][K] (K contiguous), pre-split once into two bf16 planes padded to [Npad][Kpad]
-// (scp_amd/ops.py); A is fp32 [M][lda] and is split on the fly while staging.  Workgroup = 4 waves = 128 x 128 tile of C,
-// BK = 32; a wave owns 64 x 64 = 2 x 2 MFMA tiles.  LDS holds four bf16 planes [128][32(+8 pad)] (80-byte rows: the eight
+// (scp_amd/ops.py); A is fp32 [M][lda] and is split on the fly while staging.  Workgroup = 8 waves = 128 x 128 tile of C,
+// BK = 32; a wave owns 64 x 32 = 2 MFMA tiles (16 waves per CU hide the staging latency; measured).  LDS holds four bf16 planes [128][32(+8 pad)] (80-byte rows: the eight
 // 16-byte fragment reads of a 16-lane group land in distinct bank slots).  One LDS stage + register prefetch of the next
 // k-tile; 2-3 workgroups per CU hide the two barriers per k-tile.
 // Epilogue (fused): + bias[n], activation (none | LeakyReLU(0.01) | exact-erf GELU | ReLU), + residual[m][n].
@@ -41,7 +41,7 @@ __device__ __forceinline__ float apply_act(float y) {
 }
 
 template <int ACT>
-__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__restrict__ A, int64_t lda, const __bf16 *__restrict__ Whi,
+__global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__restrict__ A, int64_t lda, const __bf16 *__restrict__ Whi,
                                                             const __bf16 *__restrict__ Wlo, int Kpad, const float *__restrict__ bias,
                                                             const float *__restrict__ res, int64_t ldr, float *__restrict__ C, int64_t ldc,
                                                             int M, int N, int K) {
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__rest
     __shared__ __attribute__((aligned(16))) __bf16 lds[2][4][BM * LDP];
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, col = lane & 31, h = lane >> 5;
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w >> 2, wn = w & 3;   // 8 waves: 2 (M) x 4 (N), a wave owns 64 x 32 = two 32x32 MFMA tiles
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give every XCD a contiguous run of tiles with the
     // N tiles of one 128-row stripe back to back - the A stripe (128 x K fp32) is then fetched once per XCD L2, not once per tile.
     const int ntn = (N + BN - 1) / BN, nblk = gridDim.x;
@@ -58,39 +58,38 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__rest
     const int m0 = (lin / ntn) * BM, n0 = (lin % ntn) * BN;
     const int nk = Kpad / BK;
 
-    // staging assignment: A tile = 128 rows x 8 float4; thread handles rows (tid>>3) + 32*i, float4 column tid&7
+    // staging assignment (512 threads): A tile = 128 rows x 8 float4; thread handles rows (tid>>3) + 64*i, float4 column tid&7
     const int a_r = tid >> 3, a_c = tid & 7;
-    // B planes = 128 rows x 4 chunks of 8 bf16 (16 B); thread handles rows (tid>>2) + 64*i, chunk tid&3
+    // B planes = 128 rows x 4 chunks of 8 bf16 (16 B); thread handles row tid>>2, chunk tid&3
     const int b_r = tid >> 2, b_c = tid & 3;
 
     // two register sets: loads are issued TWO k-tiles ahead of their use (one tile ahead does not cover the L2/HBM latency
     // with only two workgroups per CU)
-    f32x4 pa2[2][4];
-    bf16x8 pbh2[2][2], pbl2[2][2];
+    f32x4 pa2[2][2];
+    bf16x8 pbh2[2][1], pbl2[2][1];
     auto issue = [&](int kt, auto &pa, auto &pbh, auto &pbl) {
         const int k0 = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             // unconditional load from a clamped address + select: a branch around the load would make hipcc lose count of the
             // outstanding loads and wait vmcnt(0) every iteration (no prefetch at all)
-            const int m = m0 + a_r + 32 * i, k = k0 + 4 * a_c;
+            const int m = m0 + a_r + 64 * i, k = k0 + 4 * a_c;
             const int mc = m < M ? m : M - 1, kc = k < K ? k : K - 4;             // K % 4 == 0
             f32x4 v = *(const f32x4 *)(A + (int64_t)mc * lda + kc);
             const bool ok = (m < M) && (k < K);
             v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; v[2] = ok ? v[2] : 0.f; v[3] = ok ? v[3] : 0.f;
             pa[i] = v;
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int64_t off = (int64_t)(n0 + b_r + 64 * i) * Kpad + k0 + 8 * b_c;   // planes are padded: always in range
-            pbh[i] = *(const bf16x8 *)(Whi + off);
-            pbl[i] = *(const bf16x8 *)(Wlo + off);
+        {
+            const int64_t off = (int64_t)(n0 + b_r) * Kpad + k0 + 8 * b_c;   // planes are padded: always in range
+            pbh[0] = *(const bf16x8 *)(Whi + off);
+            pbl[0] = *(const bf16x8 *)(Wlo + off);
         }
     };
     auto commit = [&](int st, auto &pa, auto &pbh, auto &pbl) {
         __bf16 *sAh = lds[st][0], *sAl = lds[st][1], *sBh = lds[st][2], *sBl = lds[st][3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             bf16x4 hi, lo;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -98,25 +97,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__rest
                 hi[u] = hh;
                 lo[u] = (__bf16)(pa[i][u] - (float)hh);
             }
-            const int o = (a_r + 32 * i) * LDP + 4 * a_c;
+            const int o = (a_r + 64 * i) * LDP + 4 * a_c;
             *(bf16x4 *)(sAh + o) = hi;
             *(bf16x4 *)(sAl + o) = lo;
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int o = (b_r + 64 * i) * LDP + 8 * b_c;
-            *(bf16x8 *)(sBh + o) = pbh[i];
-            *(bf16x8 *)(sBl + o) = pbl[i];
+        {
+            const int o = b_r * LDP + 8 * b_c;
+            *(bf16x8 *)(sBh + o) = pbh[0];
+            *(bf16x8 *)(sBl + o) = pbl[0];
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][1];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
 
     issue(0, pa2[0], pbh2[0], pbl2[0]);
     if (nk > 1) issue(1, pa2[1], pbh2[1], pbl2[1]);
@@ -129,20 +125,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__rest
         const __bf16 *sAh = lds[kt & 1][0], *sAl = lds[kt & 1][1], *sBh = lds[kt & 1][2], *sBl = lds[kt & 1][3];
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
-            bf16x8 ah[2], al[2], bh[2], bl[2];
+            bf16x8 ah[2], al[2], bh[1], bl[1];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int ao = (wm * 64 + t * 32 + col) * LDP + kc * 16 + 8 * h;
-                const int bo = (wn * 64 + t * 32 + col) * LDP + kc * 16 + 8 * h;
                 ah[t] = *(const bf16x8 *)(sAh + ao);
                 al[t] = *(const bf16x8 *)(sAl + ao);
-                bh[t] = *(const bf16x8 *)(sBh + bo);
-                bl[t] = *(const bf16x8 *)(sBl + bo);
+            }
+            {
+                const int bo = (wn * 32 + col) * LDP + kc * 16 + 8 * h;
+                bh[0] = *(const bf16x8 *)(sBh + bo);
+                bl[0] = *(const bf16x8 *)(sBl + bo);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < 1; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
@@ -156,28 +154,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float *__rest
     // epilogue: the accumulators hold 4 B per lane per row (lane = column n); bounce each wave's 64 x 64 tile through its private
     // slice of the (now idle) LDS so that the residual loads and the stores move 16 B per lane, 4 rows x 256 B per instruction.
     // (the loop's last barrier already retired every read of the operand stages)
-    constexpr int LDE = 68;   // floats per staged row: 64 + 4 (keeps float4 reads aligned, spreads banks)
+    constexpr int LDE = 36;   // floats per staged row: 32 + 4 (keeps float4 reads aligned, spreads banks)
     float *stg = (float *)&lds[0][0][0] + w * (64 * LDE);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + col;
+    {
+        const int n = n0 + wn * 32 + col;
         const float bv = (bias && n < N) ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                stg[ml * LDE + j * 32 + col] = apply_act<ACT>(acc[i][j][r] + bv);
+                stg[ml * LDE + col] = apply_act<ACT>(acc[i][0][r] + bv);
             }
     }
     __syncthreads();
-    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
-    const int nb = n0 + wn * 64 + c4;
+    const int c4 = (lane & 7) * 4, rsub = lane >> 3;   // 8 lanes x 16 B per row, 8 rows per instruction
+    const int nb = n0 + wn * 32 + c4;
     const bool vec_ok = ((ldc & 3) == 0) && (!res || (ldr & 3) == 0) && (nb + 3 < N) && (((uintptr_t)C & 15) == 0) &&
                         (!res || ((uintptr_t)res & 15) == 0);
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int ml = it * 4 + rsub;
+    for (int it = 0; it < 8; ++it) {
+        const int ml = it * 8 + rsub;
         const int m = m0 + wm * 64 + ml;
         if (m >= M) continue;
         f32x4 y = *(const f32x4 *)(stg + ml * LDE + c4);
@@ -220,7 +217,7 @@ extern "C" SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void
         ((uintptr_t)A & 15) || lda < K || ldc < N || (residual && ldr < N))
         return SCP_EINVAL;
     const dim3 grid((unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM)));
-#define GO(ACT) hipLaunchKernelGGL(gemm_bf16x3_kernel<ACT>, grid, dim3(256), 0, (hipStream_t)stream, A, lda, (const __bf16 *)Whi, \
+#define GO(ACT) hipLaunchKernelGGL(gemm_bf16x3_kernel<ACT>, grid, dim3(512), 0, (hipStream_t)stream, A, lda, (const __bf16 *)Whi, \
                               (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K)
     switch (act) { case ACT_LEAKY: GO(ACT_LEAKY); break; case ACT_GELU: GO(ACT_GELU); break; case ACT_RELU: GO(ACT_RELU); break; default: GO(ACT_NONE); }
 #undef GO

@@ -75,7 +75,7 @@ class EncodePlan:
 
 class FrameEncoder:
     def __init__(self, model, data_type=KITTI, lidar_level=12, spher=True, cylin=False, mullevel=False, max_batch=8,
-                 device=None, packed=True, max_tokens=320_000):
+                 device=None, packed=True, max_tokens=1_000_000):
         self.model = model
         self.packed = packed            # one packed forward for all windows (default) vs one forward per group of equal windows
         self.max_tokens = max_tokens

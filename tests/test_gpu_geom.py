@@ -326,3 +326,50 @@ def test_empty_and_ragged_cdf(dev):
         if n:
             c = r["cdf"].cpu().numpy().view(np.uint16).astype(np.int64)
             assert (np.diff(c[:, :255], axis=1) > 0).all() and (c[:, 0] == 0).all()   # entry 255 wraps to 0 (= 65536)
+
+
+# ----------------------------------------------------------------------------------------------- B1: legacy octree ABI
+def test_legacy_octree_abi_matches_reference_so(dev):
+    """The ten symbols Octreewarpper.py:17-39 binds, driven exactly the way that wrapper drives them."""
+    import ctypes as C
+    from scp_amd import native
+
+    class Node(C.Structure):     # Octreewarpper.py:6-14
+        _fields_ = [("nodeid", C.c_uint), ("octant", C.c_uint), ("parent", C.c_uint), ("oct", C.c_uint8), ("pos", C.c_uint * 3)]
+
+    lib = C.CDLL(native.LIB_PATH)
+    lib.new_vector.restype = C.c_void_p
+    lib.delete_vector.argtypes = [C.c_void_p]
+    lib.vector_size.argtypes = [C.c_void_p]
+    lib.vector_get.restype = C.c_void_p
+    lib.vector_get.argtypes = [C.c_void_p, C.c_int]
+    lib.genOctreeInterface.restype = C.c_void_p
+    lib.genOctreeInterface.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+    lib.Nodes_get.argtypes = [C.c_void_p, C.c_int]
+    lib.Nodes_get.restype = C.POINTER(Node)
+    lib.Nodes_size.argtypes = [C.c_void_p]
+    lib.int_size.argtypes = [C.c_void_p]
+    lib.int_get.argtypes = [C.c_void_p, C.c_int]
+    assert C.sizeof(Node) == 28
+    for name in ("oct_skew2000", "oct_frame5k_L12", "oct_single"):
+        z = golden(name)
+        data = np.ascontiguousarray(z["pts"]).astype(np.double)
+        vec = lib.new_vector()
+        codes = lib.genOctreeInterface(vec, data.ctypes.data_as(C.POINTER(C.c_double)), data.shape[0])
+        assert codes
+        assert lib.vector_size(vec) == int(z["depth"])
+        got_codes = [lib.int_get(codes, i) for i in range(lib.int_size(codes))]
+        assert got_codes == z["codes"].tolist()
+        n = 0
+        for L in range(lib.vector_size(vec)):
+            lvl = lib.vector_get(vec, L)
+            for i in range(lib.Nodes_size(lvl)):
+                nd = lib.Nodes_get(lvl, i).contents
+                assert nd.nodeid == n + 1 and nd.octant == z["octant"][n] and nd.oct == z["occ"][n]
+                assert [nd.pos[0], nd.pos[1], nd.pos[2]] == z["pos"][n].tolist()
+                if n:
+                    assert nd.parent == z["parent"][n]
+                n += 1
+        assert n == len(z["occ"])
+        lib.delete_vector(vec)
+    assert lib.genOctreeInterface(lib.new_vector(), np.zeros(3).ctypes.data_as(C.POINTER(C.c_double)), 1) is None   # depth 0: NULL, no abort
