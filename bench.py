@@ -107,10 +107,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # test hooks (used by a 2-rank dry run on a 1-GPU box): SCP_FORCE_DEVICE pins every rank to one GPU, SCP_DIST_BACKEND=gloo
+    local = int(os.environ.get("SCP_FORCE_DEVICE", local))
+    backend = os.environ.get("SCP_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from cfgs import ehem_cfg
     from scp_amd import native
@@ -141,13 +148,13 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # end-of-run summary reduction (encode.py:293-305): [sum bpp, sum psnr, sum chamfer, sum time, count] over all ranks
     summ = torch.tensor([sum(r["bpp"] for r in results), 0.0, 0.0, sum(r["times"]["total"] for r in results), len(results)],
-                        dtype=torch.float64, device=dev)
+                        dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(summ, op=dist.ReduceOp.SUM)
     summ = summ.cpu().numpy()
@@ -159,6 +166,12 @@ def main():
         P = results[-1]["n_points"]
         bytes_G = 12 * P + 25 * n_nodes            # SURVEY.md §8d algorithmic bytes of stage G
         bytes_C = n_nodes * (255 * 4 + 4)
+        traffic = None
+        try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (collected separately, see the file's note)
+            with open(os.path.join(ROOT, "profiles", "r1c_pmc_traffic.json")) as f:
+                traffic = json.load(f)["gemm_bf16x3_all_variants"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "KITTI frames/sec encode (SCP-EHEM, level 16) + bpp match vs ref",
             "value": world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -175,7 +188,7 @@ def main():
             # replaces); the kernel spends three bf16 MFMAs per product, so its own ceiling is a third of the dense bf16 peak.
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16x3_kernel (dense layers: 3x v_mfma_f32_32x32x16_bf16 per fp32-class product)",
                          "achieved": dom["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
-                         "frac": dom["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 3.0), "traffic": None,
+                         "frac": dom["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 3.0), "traffic": traffic,
                          "peak_note": "2500 TFLOP/s dense bf16 MFMA / 3 products; the fp32 MFMA peak this replaces is 157.3",
                          "launches_per_frame": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
                          "flops_per_launch": dom["flops_per_launch"]},

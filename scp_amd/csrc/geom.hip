@@ -10,6 +10,7 @@
 //   1 << digit over a contiguous run of <= 8 children: no atomics, no per-node point lists.
 #include <math.h>
 #include <string.h>
+#include <algorithm>
 #include <new>
 #include <vector>
 #include "scp_internal.h"
@@ -91,13 +92,21 @@ __global__ __launch_bounds__(WG) void transform_kernel(const float *__restrict__
         omax = f2ord(a);
         omin = f2ord(c);
     }
-    // wave reduce then one atomic per wave
+    // wave reduce, then LDS across the four waves, then ONE atomic pair per workgroup (thousands of same-address atomics
+    // serialise at ~10 ns each and used to dominate this kernel)
+    __shared__ uint32_t smax[4], smin[4];
     for (int off = 32; off > 0; off >>= 1) {
         uint32_t o1 = __shfl_xor(omax, off), o2 = __shfl_xor(omin, off);
         omax = omax > o1 ? omax : o1;
         omin = omin < o2 ? omin : o2;
     }
-    if ((threadIdx.x & 63) == 0) { atomicMax(&red[0], omax); atomicMin(&red[1], omin); }
+    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = omax; smin[threadIdx.x >> 6] = omin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = max(max(smax[0], smax[1]), max(smax[2], smax[3])), b = min(min(smin[0], smin[1]), min(smin[2], smin[3]));
+        atomicMax(&red[0], a);
+        atomicMin(&red[1], b);
+    }
 }
 
 struct QuantParams { double qs[3]; double off[3]; float qsf; float offf; int cart_f32; };
@@ -121,12 +130,18 @@ __global__ __launch_bounds__(WG) void quantize_kernel(const float *__restrict__ 
             mn = v < mn ? v : mn;
         }
     }
+    __shared__ int32_t smx[4], smn[4];
     for (int off = 32; off > 0; off >>= 1) {
         int32_t o1 = __shfl_xor(mx, off), o2 = __shfl_xor(mn, off);
         mx = mx > o1 ? mx : o1;
         mn = mn < o2 ? mn : o2;
     }
-    if ((threadIdx.x & 63) == 0) { atomicMax(&red[0], mx); atomicMin(&red[1], mn); }
+    if ((threadIdx.x & 63) == 0) { smx[threadIdx.x >> 6] = mx; smn[threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(&red[0], max(max(smx[0], smx[1]), max(smx[2], smx[3])));
+        atomicMin(&red[1], min(min(smn[0], smn[1]), min(smn[2], smn[3])));
+    }
 }
 
 static DevBuf g_qtmp;  // transform scratch for scp_quantize when the caller does not ask for tr_out
@@ -196,12 +211,18 @@ __global__ __launch_bounds__(WG) void seg_minmax_kernel(const int32_t *__restric
         mx = v > mx ? v : mx;
         mn = v < mn ? v : mn;
     }
+    __shared__ int32_t smx[4], smn[4];
     for (int off = 32; off > 0; off >>= 1) {
         int32_t o1 = __shfl_xor(mx, off), o2 = __shfl_xor(mn, off);
         mx = mx > o1 ? mx : o1;
         mn = mn < o2 ? mn : o2;
     }
-    if ((threadIdx.x & 63) == 0) { atomicMax(&red[2 * blockIdx.y], mx); atomicMin(&red[2 * blockIdx.y + 1], mn); }
+    if ((threadIdx.x & 63) == 0) { smx[threadIdx.x >> 6] = mx; smn[threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(&red[2 * blockIdx.y], max(max(smx[0], smx[1]), max(smx[2], smx[3])));
+        atomicMin(&red[2 * blockIdx.y + 1], min(min(smn[0], smn[1]), min(smn[2], smn[3])));
+    }
 }
 
 __global__ __launch_bounds__(WG) void morton_key_kernel(const int32_t *__restrict__ q, const SegTab *__restrict__ tab,
@@ -417,7 +438,7 @@ extern "C" int scp_geom_build(scp_geom *g, const int32_t *q, int64_t n, const sc
     for (int s = 0; s < nseg; ++s) { red[2 * s] = INT32_MIN; red[2 * s + 1] = INT32_MAX; }
     HIP_TRY(hipMemcpyAsync(g->red.p, red.data(), red.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dtab, g->segs.data(), sizeof(SegTab) * nseg, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(seg_minmax_kernel, dim3(grid_for(maxcount * 3), nseg), dim3(WG), 0, st, q, (const SegTab *)dtab, g->red.as<int32_t>());
+    hipLaunchKernelGGL(seg_minmax_kernel, dim3(std::min(grid_for(maxcount * 3), 64), nseg), dim3(WG), 0, st, q, (const SegTab *)dtab, g->red.as<int32_t>());
     LAUNCH_CHECK();
     HIP_TRY(hipMemcpyAsync(red.data(), g->red.p, red.size() * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
