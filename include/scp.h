@@ -167,6 +167,9 @@ SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void *Whi, cons
                       const float *residual, int64_t ldr, float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act,
                       void *stream);
 
+/* numerics of the two products inside scp_swin_attention*: 1 (default) = bf16x3 split on bf16 MFMA, 0 = plain fp32 MFMA */
+SCP_API int scp_set_attention_mode(int32_t bf16x3);
+
 /* packed form: total_windows windows of 512 rows; wtab[2w] = first row of the sequence owning window w, wtab[2w+1] = its padded length */
 SCP_API int scp_swin_attention_packed(const float *q, const float *k, const float *v, const float *bias_table, const int32_t *wtab,
                               int32_t total_windows, int32_t shift, int32_t ldq, int32_t ldkv, float *out, void *stream);

@@ -69,6 +69,7 @@ def lib():
         "scp_knn_topk": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp]),
         "scp_knn_topk_packed": (C.c_int, [_vp, _vp, i32, i32, _vp, _vp]),
         "scp_swin_attention_packed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp]),
+        "scp_set_attention_mode": (C.c_int, [i32]),
         "scp_edge_gather_max": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_swin_attention": (C.c_int, [_vp, _vp, _vp, _vp, i32, i32, i32, i32, i32, _vp, _vp]),
         "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
@@ -267,6 +268,11 @@ def edge_gather_max(u, v, idx, scale, shift, out=None):
                                    _dev(shift), B, n, Co, k, out.data_ptr(), stride, _stream())
     _check(rc, "scp_edge_gather_max")
     return out
+
+
+def set_attention_mode(bf16x3=True):
+    """True (default): QK^T / PV as bf16x3 splits on bf16 MFMA; False: plain fp32 MFMA."""
+    _check(lib().scp_set_attention_mode(1 if bf16x3 else 0), "scp_set_attention_mode")
 
 
 def swin_attention(q, k, v, bias_table, shift):

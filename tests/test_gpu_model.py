@@ -188,6 +188,30 @@ def test_swin_layer_vs_reference(dev, name):
     assert err < 1e-4, err
 
 
+def test_attention_bf16x3_vs_fp32_mfma(dev):
+    """The two numerics of the window-attention kernel on the same inputs (dense and packed entry points)."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn((2, 1024, 768), generator=g).to(dev)
+    tab = (torch.randn((1023, 4), generator=g) * 0.5).to(dev)
+    q, k, v = qkv[..., :256], qkv[..., 256:512], qkv[..., 512:]
+    try:
+        for shift in (0, 256):
+            native.set_attention_mode(False)
+            a = native.swin_attention(q, k, v, tab, shift)
+            native.set_attention_mode(True)
+            b = native.swin_attention(q, k, v, tab, shift)
+            err = (a - b).abs().max().item()
+            print(f"shift {shift}: bf16x3 vs fp32 attention max diff {err:.2e} (|out| max {a.abs().max().item():.2f})")
+            assert err < 5e-5
+            # packed entry point == dense entry point
+            wtab = torch.tensor([[0, 1024], [0, 1024], [1024, 1024], [1024, 1024]], dtype=torch.int32, device=dev)
+            c = native.swin_attention_packed(q.reshape(2048, 256), k.reshape(2048, 256), v.reshape(2048, 256), tab, wtab, shift)
+            assert torch.equal(c.reshape(2, 1024, 256), b)
+    finally:
+        native.set_attention_mode(True)
+
+
 def test_swin_attention_argument_errors(dev):
     from scp_amd import native
     q = torch.zeros((1, 500, 256), device=dev)
