@@ -184,6 +184,11 @@ SCP_API int scp_layernorm_rows(const float *x, int64_t ldx, int64_t n_src_rows, 
                        void *stream);
 SCP_API int scp_gather_rows(const float *src, int64_t lds, const int64_t *idx, int32_t C, float *out, int64_t ldo, int64_t rows, void *stream);
 
+/* exact fp32 dense layer (k-ordered FMA chain per output, independent of the number of rows in the launch): C = act(A . W^T + bias),
+ * any K / N; used for the small-K layers and for every feature that feeds a kNN search */
+SCP_API int scp_linear_f32(const float *A, int64_t lda, const float *W, const float *bias, float *C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                   int32_t act, void *stream);
+
 /* OctAttention dual-stream causal attention (attention_model.py:58-95): heads of width hd,
  * q_u,k,k_u,v,v_u [B][c][H*hd] -> out, out_u [B][c][H*hd] */
 SCP_API int scp_octattn_attention(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
@@ -213,6 +218,7 @@ SCP_API int scp_ac_encode_lohi(const uint32_t *lohi, int64_t n, uint8_t *out, si
 typedef struct scp_ac_dec scp_ac_dec;
 SCP_API int scp_ac_dec_new(scp_ac_dec **d, const uint8_t *stream, size_t len, int32_t Lp);
 SCP_API int scp_ac_dec_next(scp_ac_dec *d, const uint16_t *cdf_row); /* returns the symbol (>= 0) */
+SCP_API int scp_ac_dec_run(scp_ac_dec *d, const uint16_t *cdf, int64_t n, int16_t *out); /* n symbols, row i = CDF of symbol i */
 SCP_API int scp_ac_dec_free(scp_ac_dec *d);
 
 /* ------------------------------------------------------------------------------------------------

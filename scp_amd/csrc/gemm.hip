@@ -224,3 +224,83 @@ extern "C" SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void
     LAUNCH_CHECK();
     return SCP_OK;
 }
+
+// ================================================================================================================
+// Exact fp32 dense layer, batch-invariant: C = act(A . W^T + bias) on v_mfma_f32_32x32x2_f32.
+// Used where bf16x3 is not wanted or not possible: the small-K layers (K = 3, 16) and everything that feeds a kNN search
+// (edge-conv u/v products, mlp2), so that those features are plain fp32 FMA chains in k order - the same arithmetic as the
+// reference's CPU matmul - AND independent of how many rows share the launch: the encoder (one packed launch per frame) and the
+// decoder (one window at a time) must produce bit-identical features, which a library GEMM that picks its kernel by problem
+// size does not guarantee.  Workgroup = 4 waves = 128 rows x 64 columns; K is staged 32 at a time into LDS de-interleaved as
+// [row][even k | odd k] so that MFMA lane half h reads k = 2s + h contiguously (k order preserved); zero padding is exact.
+#define FBM 128
+#define FBN 64
+#define FBK 32
+#define FLD 36   // floats per staged row (32 + 4): 16-byte aligned rows, conflict-free ds_read_b128
+
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, float *__restrict__ C, int64_t ldc, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) float sA[FBM * FLD];
+    __shared__ __attribute__((aligned(16))) float sB[FBN * FLD];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, col = lane & 31, h = lane >> 5;
+    const int ntn = (N + FBN - 1) / FBN;
+    const int m0 = (blockIdx.x / ntn) * FBM, n0 = (blockIdx.x % ntn) * FBN;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int nk = (K + FBK - 1) / FBK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int k0 = kt * FBK;
+        __syncthreads();
+        // stage: element (row, k) -> [row][(k & 1) * 16 + (k >> 1)]
+        for (int e = tid; e < FBM * FBK; e += 256) {
+            const int r = e >> 5, k = e & 31;
+            const int m = m0 + r, kk = k0 + k;
+            sA[r * FLD + (k & 1) * 16 + (k >> 1)] = (m < M && kk < K) ? A[(int64_t)m * lda + kk] : 0.f;
+        }
+        for (int e = tid; e < FBN * FBK; e += 256) {
+            const int r = e >> 5, k = e & 31;
+            const int n = n0 + r, kk = k0 + k;
+            sB[r * FLD + (k & 1) * 16 + (k >> 1)] = (n < N && kk < K) ? W[(int64_t)n * K + kk] : 0.f;
+        }
+        __syncthreads();
+        const float *ar = sA + (w * 32 + col) * FLD + h * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a = *(const f32x4 *)(ar + 4 * g);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 b = *(const f32x4 *)(sB + (j * 32 + col) * FLD + h * 16 + 4 * g);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + j * 32 + col;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < M) C[(int64_t)m * ldc + n] = apply_act<ACT>(acc[j][r] + bv);
+        }
+    }
+}
+
+extern "C" SCP_API int scp_linear_f32(const float *A, int64_t lda, const float *W, const float *bias, float *C, int64_t ldc, int32_t M, int32_t N,
+                                      int32_t K, int32_t act, void *stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N || act < 0 || act > 3) return SCP_EINVAL;
+    const dim3 grid((unsigned)(((N + FBN - 1) / FBN) * ((M + FBM - 1) / FBM)));
+#define GOF(ACT) hipLaunchKernelGGL(gemm_f32_kernel<ACT>, grid, dim3(256), 0, (hipStream_t)stream, A, lda, W, bias, C, ldc, M, N, K)
+    switch (act) { case ACT_LEAKY: GOF(ACT_LEAKY); break; case ACT_GELU: GOF(ACT_GELU); break; case ACT_RELU: GOF(ACT_RELU); break; default: GOF(ACT_NONE); }
+#undef GOF
+    LAUNCH_CHECK();
+    return SCP_OK;
+}

@@ -164,6 +164,17 @@ extern "C" int scp_ac_dec_next(scp_ac_dec *d, const uint16_t *row) {
     return sy;
 }
 
+// decode n consecutive symbols, row i of the [n][Lp] table being the CDF of symbol i
+extern "C" int scp_ac_dec_run(scp_ac_dec *d, const uint16_t *cdf, int64_t n, int16_t *out) {
+    if (!d || !cdf || !out || n < 0) return SCP_EINVAL;
+    for (int64_t i = 0; i < n; ++i) {
+        const int s = scp_ac_dec_next(d, cdf + i * d->Lp);
+        if (s < 0) return s;
+        out[i] = (int16_t)s;
+    }
+    return SCP_OK;
+}
+
 extern "C" int scp_ac_dec_free(scp_ac_dec *d) {
     if (!d) return SCP_EINVAL;
     free(d->in);

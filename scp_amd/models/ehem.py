@@ -302,6 +302,12 @@ class EHEM(nn.Module):
     @torch.no_grad()
     def forward_ctx(self, ctx, pos):
         """ctx int64/uint8 [B,c,12]; pos float32 [B,c,3] (token-major layout used by the kernels)."""
+        prob1, st = self._phase1(ctx, pos)
+        prob2 = self._phase2(st, st["pre_occ"])
+        return prob1, prob2
+
+    def _phase1(self, ctx, pos):
+        """Everything that does not depend on the window's own occupancies (ehem.py:92-115): -> even-node logits + state."""
         ctx = ctx.long()
         if ctx.shape[1] % 2 == 1:                       # ehem.py:92-99: pad row (0,0,255) x 4, pos 0
             pad = torch.zeros_like(ctx[:, :1])
@@ -312,16 +318,32 @@ class EHEM(nn.Module):
         else:
             padded = False
         B, c = ctx.shape[:2]
-        pre_occ = ctx[:, ::2, 11]
         feat = geo_feat_forward(self.geo_feat_generator, ctx, pos)
         hs = swin_encoder_forward(self.swin_self_transformer, feat, c)
         feat_a = leaky_mlp3(self.ancient_mlp, concat_states(hs))
         a1, a2 = feat_a[:, ::2].contiguous(), feat_a[:, 1::2].contiguous()
         prob1 = leaky_mlp3(self.prob_pred_mlp1, a1)
-        occ_feat = leaky_mlp3(self.pre_occ_mlp, F.embedding(pre_occ, self.geo_feat_generator.occ_enc.weight))
+        return prob1, dict(a1=a1, a2=a2, padded=padded, pre_occ=ctx[:, ::2, 11])
+
+    def _phase2(self, st, pre_occ):
+        """Odd-node logits given the occupancies of the even nodes (ehem.py:117-127)."""
+        a1, a2 = st["a1"], st["a2"]
+        occ_feat = leaky_mlp3(self.pre_occ_mlp, F.embedding(pre_occ.long(), self.geo_feat_generator.occ_enc.weight))
         pre = torch.cat((occ_feat, leaky_mlp3(self.pre_attn_mlp, a1)), 2)
         hc = swin_encoder_forward(self.swin_cross_transformer, pre, a2.shape[1], query=a2)
         prob2 = leaky_mlp3(self.prob_pred_mlp2, torch.cat((concat_states(hc), a2), 2))
-        if padded:
+        if st["padded"]:
             prob2 = prob2[:, :-1]
-        return prob1, prob2
+        return prob2
+
+    @torch.no_grad()
+    def decode(self, data, pos, pre_occ=None):
+        """Reference decoder API (ehem.py:138-177): decode(data, pos) -> even logits (state is kept on the module);
+        decode(data, pos, pre_occ) -> odd logits given the decoded even occupancies [B, ceil(c/2)]."""
+        if not data.is_cuda:
+            raise native.ScpError("EHEM runs on the MI355X only (no CPU fallback); move the inputs to cuda")
+        if pre_occ is None:
+            B, c = data.shape[:2]
+            prob1, self._dec_state = self._phase1(data.reshape(B, c, 12), pos.transpose(1, 2).contiguous())
+            return prob1
+        return self._phase2(self._dec_state, pre_occ)

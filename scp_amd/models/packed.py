@@ -187,9 +187,9 @@ def _concat(hs, cmaps, extra=None):
 
 
 @torch.no_grad()
-def ehem_forward_packed(model, ctx, pos, plan):
-    """ctx uint8/int64 [T,12], pos float32 [T,3]: the frame's tokens, windows back to back (lengths = plan.c).
-    Returns (logits_even_rows [sum ceil(c/2), 255], logits_odd_rows [sum floor(c/2), 255]) in window order."""
+def ehem_phase1_packed(model, ctx, pos, plan):
+    """Everything that does not depend on the windows' own occupancies (ehem.py:92-115).
+    Returns (even-node logits in window order [sum ceil(c/2), 255], state for phase 2)."""
     d = plan.d
     g = model.geo_feat_generator
     dev = ctx.device
@@ -215,9 +215,27 @@ def ehem_forward_packed(model, ctx, pos, plan):
     a1 = native.gather_rows(feat_a, d["a1map"], torch.empty((Q0, 256), dtype=torch.float32, device=dev))
     a2 = native.gather_rows(feat_a, d["a2map"], torch.empty((Q0, 256), dtype=torch.float32, device=dev))
     prob1 = leaky_mlp3(model.prob_pred_mlp1, a1)
-    pre_occ = ctx0[d["a1map"], 11]
-    occ_feat = leaky_mlp3(model.pre_occ_mlp, F.embedding(pre_occ, g.occ_enc.weight))
+    return prob1[d["even_rows"]], dict(a1=a1, a2=a2, pre_occ=ctx0[d["a1map"], 11])
+
+
+@torch.no_grad()
+def ehem_phase2_packed(model, st, plan, pre_occ=None):
+    """Odd-node logits given the occupancies of the even nodes (ehem.py:117-127).  pre_occ: int64 [Q0 rows] in the cross
+    layout (None = the true occupancies taken from ctx, as the encoder does)."""
+    d = plan.d
+    g = model.geo_feat_generator
+    a1, a2 = st["a1"], st["a2"]
+    po = st["pre_occ"] if pre_occ is None else pre_occ
+    occ_feat = leaky_mlp3(model.pre_occ_mlp, F.embedding(po, g.occ_enc.weight))
     pre = torch.cat((occ_feat, leaky_mlp3(model.pre_attn_mlp, a1)), 1)
     hc = _encoder(model.swin_cross_transformer, pre, d["cross_valid"], d["cross_tab"], d["cross_merge"], query=a2)
     prob2 = leaky_mlp3(model.prob_pred_mlp2, _concat(hc, d["cross_concat"], extra=(a2, None)))
-    return prob1[d["even_rows"]], prob2[d["odd_rows"]]
+    return prob2[d["odd_rows"]]
+
+
+@torch.no_grad()
+def ehem_forward_packed(model, ctx, pos, plan):
+    """ctx uint8/int64 [T,12], pos float32 [T,3]: the frame's tokens, windows back to back (lengths = plan.c).
+    Returns (logits_even_rows [sum ceil(c/2), 255], logits_odd_rows [sum floor(c/2), 255]) in window order."""
+    ev, st = ehem_phase1_packed(model, ctx, pos, plan)
+    return ev, ehem_phase2_packed(model, st, plan)

@@ -77,12 +77,14 @@ def lib():
         "scp_linear_bf16x3": (C.c_int, [_vp, i64, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp]),
         "scp_layernorm_rows": (C.c_int, [_vp, i64, i64, _vp, _vp, i32, _vp, _vp, _vp, C.c_float, _vp, i64, i64, _vp]),
         "scp_gather_rows": (C.c_int, [_vp, i64, _vp, i32, _vp, i64, i64, _vp]),
+        "scp_linear_f32": (C.c_int, [_vp, i64, _vp, _vp, _vp, i64, i32, i32, i32, i32, _vp]),
         "scp_softmax_cdf": (C.c_int, [_vp, i64, i64, i32, _vp, _vp, _vp, _vp, _vp]),
         "scp_pmf_cdf": (C.c_int, [_vp, i64, i32, _vp, _vp, _vp, _vp]),
         "scp_ac_encode_cdf": (C.c_int, [_vp, _vp, i64, i32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
         "scp_ac_encode_lohi": (C.c_int, [_vp, i64, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
         "scp_ac_dec_new": (C.c_int, [C.POINTER(_vp), _vp, C.c_size_t, i32]),
         "scp_ac_dec_next": (C.c_int, [_vp, _vp]),
+        "scp_ac_dec_run": (C.c_int, [_vp, _vp, i64, _vp]),
         "scp_ac_dec_free": (C.c_int, [_vp]),
     }
     for name, (res, args) in sig.items():
@@ -356,6 +358,21 @@ def gather_rows(src, idx, out):
     return out
 
 
+def linear_f32(x, w, bias=None, act=ACT_NONE):
+    """exact fp32, batch-invariant dense layer: x [..., K] (unit last stride) @ w[N,K]^T (+bias, act) -> [..., N]."""
+    K = w.shape[1]
+    N = w.shape[0]
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, K) if x.is_contiguous() else x.contiguous().reshape(-1, K)
+    M = x2.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    wc = w if w.is_contiguous() else w.contiguous()
+    rc = lib().scp_linear_f32(x2.data_ptr(), x2.stride(0), _dev(wc.detach(), torch.float32), _opt(bias), out.data_ptr(), N, M, N, K, act,
+                              _stream())
+    _check(rc, "scp_linear_f32")
+    return out.reshape(*lead, N)
+
+
 def octattn_attention(q_u, k, k_u, v, v_u, heads):
     B, c, D = q_u.shape
     out, out_u = torch.empty_like(q_u), torch.empty_like(q_u)
@@ -433,6 +450,13 @@ class AcDecoder:
     def next(self, cdf_row):
         row = np.ascontiguousarray(cdf_row).view(np.uint16)
         return _check(lib().scp_ac_dec_next(self._h, row.ctypes.data), "scp_ac_dec_next")
+
+    def run(self, cdf):
+        """cdf uint16/int16 numpy [n,Lp] -> int16 numpy [n] (n consecutive symbols)."""
+        cdf = np.ascontiguousarray(cdf).view(np.uint16)
+        out = np.empty(cdf.shape[0], np.int16)
+        _check(lib().scp_ac_dec_run(self._h, cdf.ctypes.data, cdf.shape[0], out.ctypes.data), "scp_ac_dec_run")
+        return out
 
     def __del__(self):
         try:

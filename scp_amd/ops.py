@@ -1,9 +1,10 @@
 """Dense-layer helpers used by the context models.
 
 Default path: the hand-written bf16x3 MFMA GEMM (csrc/gemm.hip, fp32-class accuracy, fused bias / activation / residual
-epilogue) through the C ABI.  `SCP_GEMM=f32` switches to plain fp32 library GEMMs (rocBLAS / hipBLASLt via torch) - used by
-the tests to bracket the numerical effect of the split, and automatically for shapes the kernel does not cover (K % 4 != 0
-or K < 32).  Everything here requires device tensors - there is no CPU path in the product.
+epilogue) through the C ABI.  Layers the split does not cover (K % 4 != 0 or K < 32) and every layer that feeds a kNN search run
+on the exact fp32 MFMA kernel (scp_linear_f32): k-ordered FMA chains whose result does not depend on the batch, so the encoder's
+one packed launch and the decoder's per-window launches agree bit for bit.  `SCP_GEMM=f32` switches everything to plain fp32
+library GEMMs (rocBLAS / hipBLASLt via torch) - used by the tests to bracket the numerical effect of the split.  Everything here requires device tensors - there is no CPU path in the product.
 """
 import os
 import weakref
@@ -42,8 +43,12 @@ def clear_cache():
 def linear(x, w, b=None, act=None, residual=None, exact=False):
     """act(x @ w.T + b) + residual.  exact=True keeps plain fp32 (used where the result feeds a kNN search)."""
     K = w.shape[1]
-    if MODE == "bf16x3" and not exact and K % 4 == 0 and K >= 32 and x.is_cuda:
-        return native.linear_bf16x3(x, _split(w), b, _ACT[act], residual)
+    if MODE == "bf16x3" and x.is_cuda:
+        if not exact and K % 4 == 0 and K >= 32:
+            return native.linear_bf16x3(x, _split(w), b, _ACT[act], residual)
+        # exact fp32 MFMA kernel: k-ordered FMA chains, results independent of how many rows share the launch
+        y = native.linear_f32(x, w, b, _ACT[act])
+        return y if residual is None else y + residual
     y = F.linear(x, w, b)
     if act == "leaky":
         y = F.leaky_relu(y, 0.01)

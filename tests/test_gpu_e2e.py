@@ -169,3 +169,31 @@ def test_cli_encode_mullevel_writes_reference_named_files(tmp_path):
     bins = sorted(p.name for p in out.iterdir() if p.name.endswith(".bin"))
     assert len(bins) == 2 and bins[0].startswith("seq07000000_spher_") and (out / (bins[0] + ".dat")).exists()
     assert (tmp_path / "test_results_mul_kitti_12.txt").exists()
+
+
+@pytest.mark.parametrize("mullevel,level", [(False, 12), (True, 12)])
+def test_encode_decode_roundtrip(enc_parts, mullevel, level):
+    """f1: the decoder regenerates the octree from the bitstream alone (+ the reference's side info) - codec loop closed."""
+    from scp_amd import native
+    from scp_amd.decoder import FrameDecoder
+    from scp_amd.encoder import FrameEncoder
+    from scp_amd.synth import synth_frame
+    model, dev = enc_parts
+    xyz = synth_frame(4)[::30].copy()                       # 4000 points
+    enc = FrameEncoder(model, "kitti", level, spher=True, mullevel=mullevel, device=dev)
+    res = enc.encode(xyz)
+    nodes = enc.geom.nodes(("occ", "level"))
+    dec = FrameDecoder(model, level, mullevel=mullevel, polar=True, device=dev)
+    shells = dec.decode(res["bytes"], res["n_levels"], res["pos_mm"])
+    assert len(shells) == (3 if mullevel else 1)
+    for s, (codes, leaves) in enumerate(shells):
+        info = enc.geom.info[s]
+        want = nodes["occ"][info.node_base:info.node_base + info.n_nodes].cpu().numpy()
+        got = torch.cat(codes).cpu().numpy()
+        assert len(got) == len(want)
+        if mullevel:
+            assert got[-1] == 0 and np.array_equal(got[:-1], want[:-1])      # the last BFS node is not coded (Octree.py:259-262)
+        else:
+            assert np.array_equal(got, want)
+            ref_leaves = enc.geom.leaves(s).cpu().numpy()
+            assert np.array_equal(leaves.cpu().numpy(), ref_leaves)
