@@ -129,7 +129,14 @@ def main(argv=None, mullevel=False):
         stem = (cur.split("/")[-2] + Path(cur).stem) if (args.type == "kitti" and name != "OctAttention" and "/" in cur.rstrip("/")
                                                           and len(cur.split("/")) >= 2) else Path(cur).stem
         t0 = time.time()
-        res = enc.encode(xyz)
+        if args.preproc_path and name != "OctAttention":
+            # encode_dataset_ehem.py:149-157 / ..._mullevel.py:147-155: records + meta written by the test-set generator
+            pp = args.preproc_path + ((cur.split("/")[-2] + Path(cur).stem) if args.type == "kitti" else Path(cur).stem)
+            meta = np.load(pp + "_meta.npy")
+            recs = [np.load(pp + sfx + ".npy") for sfx in (("_0_0", "_0_1", "_1") if mullevel else ("",))]
+            res = enc.encode_records(recs, float(meta[0]), float(meta[2]) if len(meta) > 2 else 0.0, len(xyz))
+        else:
+            res = enc.encode(xyz)
         elapsed = time.time() - t0
         outfile = enc.outfile(out_root + stem, res)
         with open(outfile, "wb") as f:

@@ -131,6 +131,39 @@ class FrameEncoder:
         return dict(ctx=torch.cat(ctxs), pos=torch.cat(poss), sym=torch.cat(syms), pos_mm=torch.cat(mms),
                     level_sizes=sizes, bin_num=bin_num, z_offset=z_offset, n_points=n_points)
 
+    def preprocess_records(self, records, bin_num, z_offset, n_points):
+        """--preproc_path flow (encode_dataset_ehem.py:149-157 + :52-105): the reference's int64 [N,4,6] record files (one per
+        shell) -> the same ctx/pos/sym tables the device octree path produces.  Pure index plumbing on the device."""
+        L = self.lidar_level
+        ctxs, poss, syms, mms, sizes = [], [], [], [], []
+        for rec in records:
+            r = (torch.from_numpy(np.ascontiguousarray(rec, np.int64)) if isinstance(rec, np.ndarray) else rec).to(self.device)
+            lvl = r[:, 3, 1]
+            depth = int(lvl.max())
+            counts = torch.bincount(lvl, minlength=depth + 1)[1:]
+            last = (lvl == depth)[:, None]
+            levels = torch.where(last, torch.clamp(r[:, :, 1], max=L), r[:, :, 1])          # ehem:86 clips the last chunk
+            ctx = torch.stack((levels, r[:, :, 2], r[:, :, 0] - 1), 2).reshape(-1, 12).to(torch.uint8)
+            p = r[:, 3, 3:6]
+            if self.mode == native.CART and not self.mullevel:
+                pos = (p.double() / float(2 ** depth)).float()
+                mm = torch.zeros((depth, 2), dtype=torch.int64, device=self.device)
+            else:
+                mn = torch.full((depth + 1,), 2 ** 62, dtype=torch.int64, device=self.device).scatter_reduce(0, lvl, p.min(1)[0], "amin")
+                mx = torch.full((depth + 1,), -2 ** 62, dtype=torch.int64, device=self.device).scatter_reduce(0, lvl, p.max(1)[0], "amax")
+                eps = torch.where((lvl == depth) & torch.tensor(self.mullevel, device=self.device), 0.0, 1e-9).double()
+                pos = ((p - mn[lvl][:, None]).double() / ((mx - mn)[lvl].double() + eps)[:, None]).float()
+                mm = torch.stack((mn[1:], mx[1:]), 1)
+            ctxs.append(ctx); poss.append(pos.contiguous()); syms.append((r[:, 3, 0] - 1).to(torch.uint8)); mms.append(mm)
+            sizes += counts.tolist()
+        return dict(ctx=torch.cat(ctxs), pos=torch.cat(poss), sym=torch.cat(syms), pos_mm=torch.cat(mms), level_sizes=sizes,
+                    bin_num=bin_num, z_offset=z_offset, n_points=n_points)
+
+    def encode_records(self, records, bin_num, z_offset, n_points, timing=False):
+        """Encode from the reference's preprocessed record files (list of int64 [N,4,6], one per shell)."""
+        t0 = time.perf_counter()
+        return self._encode_pre(self.preprocess_records(records, bin_num, z_offset, n_points), t0, timing)
+
     # ------------------------------------------------------------------------------------------ stage M + C
     def logits_in_coding_order(self, pre, plan):
         if self.packed:

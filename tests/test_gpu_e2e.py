@@ -1,4 +1,6 @@
 """Whole frames through FrameEncoder on the GPU vs the reference driver's recorded outputs (tests/golden/e2e_*.npz)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -197,3 +199,37 @@ def test_encode_decode_roundtrip(enc_parts, mullevel, level):
             assert np.array_equal(got, want)
             ref_leaves = enc.geom.leaves(s).cpu().numpy()
             assert np.array_equal(leaves.cpu().numpy(), ref_leaves)
+
+
+@pytest.mark.parametrize("mullevel", [False, True])
+def test_preproc_path_files_and_flow(enc_parts, orc, tmp_path, mullevel):
+    """B6 / f2: the generator writes the reference's record files; encoding from them equals encoding from the frame."""
+    from scp_amd.data_preproc.data_preprocess import write_testset
+    from scp_amd.encoder import FrameEncoder
+    from scp_amd.synth import synth_frame, write_kitti_bin
+    model, dev = enc_parts
+    seq = tmp_path / "seq03"
+    seq.mkdir()
+    xyz = synth_frame(6)[::40].copy()
+    f = str(seq / "000001.bin")
+    write_kitti_bin(f, xyz)
+    L = 14
+    name = write_testset(f, str(tmp_path / "pp"), "kitti", L, spher=True, mullevel=mullevel, chamfer=True)
+    assert name == "seq03000001"
+    pp = str(tmp_path / "pp" / name)
+    meta = np.load(pp + "_meta.npy")
+    sfx = ("_0_0", "_0_1", "_1") if mullevel else ("",)
+    recs = [np.load(pp + s + ".npy") for s in sfx]
+    assert all(r.dtype == np.int64 and r.shape[1:] == (4, 6) for r in recs)
+    # the record files equal what the reference pipeline (oracle restatement) produces from the same integers
+    enc = FrameEncoder(model, "kitti", L, spher=True, mullevel=mullevel, device=dev)
+    qs, bin_num, _ = enc.quantize(torch.from_numpy(xyz).to(dev))
+    assert float(meta[0]) == bin_num and meta[1] > 0
+    for k, (path, _) in enumerate(enc.shells()):
+        t = orc.octree_build(qs[k].cpu().numpy(), path)
+        assert np.array_equal(recs[k], t.krecords(drop_last=mullevel))
+    a = enc.encode(xyz)
+    b = enc.encode_records(recs, float(meta[0]), 0.0, len(xyz))
+    assert a["bytes"] == b["bytes"] and a["level_sizes"] == b["level_sizes"]
+    assert np.array_equal(a["pos_mm"], b["pos_mm"])
+    assert os.path.exists(pp + "_quant.ply") and os.path.exists(pp + sfx[0] + "_loc.npy")   # data_preprocess.py:78,153
