@@ -1,0 +1,120 @@
+"""Host-side logic that needs no GPU: window plans, packed-layout index maps, CLI plumbing, file readers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_encode_plan_matches_oracle_coding_order(orc):
+    from scp_amd.encoder import EncodePlan, level_qs
+    for sizes in ([1], [1, 6, 20, 8193, 1, 17000, 3], [2, 2, 2], [8192, 8192, 1]):
+        plan = EncodePlan(sizes, 8192)
+        _, want = orc.ehem_coding_plan(sizes, 8192, mullevel=True)
+        assert np.array_equal(plan.coding_order(), want)
+        assert np.array_equal(plan.coding_order_device(torch.device("cpu")).numpy(), want)
+        assert sum(w[1] for w in plan.windows) == sum(sizes)
+    assert level_qs("kitti", 16) == 400 / (2 ** 16 - 1) and level_qs("ford", 17) == 2.0
+    groups = EncodePlan([8192] * 10 + [5], 8192).groups(8)
+    assert [(c, len(ws)) for c, ws in groups] == [(8192, 8), (8192, 2), (5, 1)]
+
+
+def _loop_maps(c):
+    """Straightforward per-window construction of the packed layout (what models/packed.py vectorises)."""
+    c = np.asarray(c)
+    e = c + (c & 1)
+
+    def layout(L):
+        Lp = (L + 511) // 512 * 512
+        return L, Lp, np.concatenate(([0], np.cumsum(Lp)[:-1])), int(Lp.sum())
+    lay = [layout(e)]
+    for _ in range(4):
+        lay.append(layout((lay[-1][0] + 1) // 2))
+    return lay
+
+
+@pytest.mark.parametrize("lengths", [[1], [1, 6, 20, 56, 208, 1372, 5605, 8192, 4938, 7, 2, 513], [8192, 8192], [3, 3, 3]])
+def test_packed_plan_maps(lengths):
+    from scp_amd.models.packed import PackedPlan
+    p = PackedPlan(lengths, device=torch.device("cpu"))   # pure index arithmetic: runs on any torch device
+    c = np.asarray(lengths)
+    lay = _loop_maps(c)
+    for s, l in enumerate(p.self_layouts):
+        L, Lp, base, rows = lay[s]
+        assert np.array_equal(l.L.numpy(), L) and np.array_equal(l.base.numpy(), base) and l.rows == rows
+        tab = p.d["self_tab"][s].numpy()
+        assert tab.shape == (rows // 512, 2)
+        for i in range(len(c)):
+            ch = slice(base[i] // 512, (base[i] + Lp[i]) // 512)
+            assert (tab[ch, 0] == base[i]).all() and (tab[ch, 1] == Lp[i]).all()
+        v = p.d["self_valid"][s].numpy()[:, 0]
+        want = np.zeros(rows)
+        for i in range(len(c)):
+            want[base[i]:base[i] + L[i]] = 1
+        assert np.array_equal(v, want)
+    # input map, merge maps, concat maps, outputs
+    L0, Lp0, b0, rows0 = lay[0]
+    starts = np.concatenate(([0], np.cumsum(c)[:-1]))
+    inmap = np.full(rows0, c.sum())
+    for i in range(len(c)):
+        inmap[b0[i]:b0[i] + c[i]] = starts[i] + np.arange(c[i])
+    assert np.array_equal(p.d["inmap"].numpy(), inmap)
+    for s in range(4):
+        (L, Lp, b, rows), (L2, Lp2, b2, rows2) = lay[s], lay[s + 1]
+        ev, od = np.full(rows2, rows), np.full(rows2, rows)
+        for i in range(len(c)):
+            t = np.arange(L2[i])
+            ev[b2[i] + t] = b[i] + 2 * t
+            od[b2[i] + t] = np.where(2 * t + 1 < L[i], b[i] + 2 * t + 1, rows)
+        assert np.array_equal(p.d["self_merge"][s][0].numpy(), ev) and np.array_equal(p.d["self_merge"][s][1].numpy(), od)
+        m = np.zeros(rows0, np.int64)
+        for i in range(len(c)):
+            t = np.arange(L0[i])
+            m[b0[i] + t] = b2[i] + (t >> (s + 1))
+        assert np.array_equal(p.d["self_concat"][s].numpy(), m)
+    ne, no = (c + 1) // 2, c // 2
+    coded = np.concatenate(([0], np.cumsum(c)[:-1]))
+    ed = np.concatenate([coded[i] + np.arange(ne[i]) for i in range(len(c))])
+    od = np.concatenate([coded[i] + ne[i] + np.arange(no[i]) for i in range(len(c))]) if no.sum() else np.zeros(0)
+    assert np.array_equal(p.d["even_dst"].numpy(), ed) and np.array_equal(p.d["odd_dst"].numpy(), od)
+    assert sorted(np.concatenate([ed, od]).tolist()) == list(range(int(c.sum())))
+    assert p.d["knn_tab"].numpy()[:, 1].max() == (c + (c & 1)).max()
+
+
+def test_readers_and_cli_plumbing(tmp_path):
+    from scp_amd.cli import expand_files, get_args, load_cfg
+    from scp_amd.data_preproc import pt
+    from scp_amd.synth import synth_frame, write_kitti_bin
+    xyz = synth_frame(0)[:100]
+    f = tmp_path / "a.bin"
+    write_kitti_bin(str(f), xyz)
+    assert np.array_equal(pt.ptread(str(f)), xyz)
+    ply = tmp_path / "b.ply"
+    pt.write_ply_data(str(ply), xyz)
+    back = pt.ptread(str(ply))
+    assert back.dtype == np.float32 and np.allclose(back, xyz)
+    with pytest.raises(Exception):
+        pt.ptread(str(tmp_path / "missing.bin"))
+    assert expand_files([str(tmp_path)]) == sorted([str(f), str(ply)])
+    a = get_args(["--type", "kitti", "--lidar_level", "16", "--spher", "--test_files", "x.bin", "--preproc_path", "pp/"], mullevel=True)
+    assert a.type == "kitti" and a.lidar_level == 16 and a.spher and not a.cylin and a.preproc_path == "pp/" and not hasattr(a, "spher_circle")
+    assert hasattr(get_args([], mullevel=False), "spher_circle")
+    cfg = load_cfg("", "EHEM")
+    assert cfg.model.context_size == 8192 and cfg.model.max_level == 19 and cfg.model.token_num == 255
+    run = tmp_path / "run" / ".hydra"
+    run.mkdir(parents=True)
+    (run / "config.yaml").write_text("model:\n  class_name: OctAttention\n  context_size: 1024\n  token_num: 255\ntrain:\n  type: kitti\n")
+    cfg = load_cfg(str(tmp_path / "run" / "ckpt" / "epoch=1.ckpt"))
+    assert cfg.model.class_name == "OctAttention" and cfg.model.context_size == 1024 and cfg.data.extra_pos is False
+
+
+def test_product_refuses_cpu_tensors():
+    """No CPU fallback: the product modules fail loudly on CPU inputs."""
+    from cfgs import ehem_cfg
+    from scp_amd import native
+    from scp_amd.models import EHEM
+    m = EHEM(ehem_cfg())
+    with pytest.raises(native.ScpError):
+        m(torch.zeros((1, 4, 4, 3), dtype=torch.int64), torch.zeros((1, 3, 4)))
+    with pytest.raises(native.ScpError):
+        native.knn_topk(torch.zeros((1, 4, 3)), 2)
