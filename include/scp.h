@@ -159,13 +159,32 @@ SCP_API int scp_swin_attention(const float *q, const float *k, const float *v, c
 
 /* Dense layer C = epilogue(A . W^T) on bf16 MFMA with fp32-class accuracy ("bf16x3": x = hi + lo, three products, fp32
  * accumulate; replaces the nn.Linear calls of models/ehem.py / swin_transformer.py:448-452,511,559,571).
- *   scp_split_weight_bf16: W fp32 [N][K] -> bf16 planes hi/lo [Npad][Kpad] (Npad % 128 == 0, Kpad % 32 == 0, zero padded)
+ *   scp_split_weight_bf16: W fp32 [N][K] -> bf16 planes hi/lo [Npad][Kpad] (Npad % 256 == 0, Kpad % 32 == 0, zero padded)
  *   scp_linear_bf16x3    : A fp32 [M][lda] (K % 4 == 0), planes from above, optional bias[N], residual[M][ldr];
  *                          act: 0 none, 1 LeakyReLU(0.01), 2 GELU(erf), 3 ReLU;  C fp32 [M][ldc]                        */
 SCP_API int scp_split_weight_bf16(const float *W, int32_t N, int32_t K, int32_t Npad, int32_t Kpad, void *hi, void *lo, void *stream);
 SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void *Whi, const void *Wlo, int32_t Kpad, const float *bias,
                       const float *residual, int64_t ldr, float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act,
                       void *stream);
+
+/* The same dense layer with the ACTIVATION pre-split too: A arrives as bf16 planes hi/lo [M][lda] (lda % 8 == 0, lda >= Kpad,
+ * columns K..Kpad zero) written by the producing kernel (scp_split_rows, scp_layernorm_rows_split, the attention kernels, or this
+ * function's own split output), so operand tiles go global -> LDS by LDS-DMA with no conversion.  Outputs: C fp32 [M][ldc]
+ * and/or planes Ohi/Olo [M][ldo] (columns N..round32(N) zero filled).  Weight planes must be padded to Npad % 256 == 0.
+ * cfg: 0 automatic, 1 = 256 x 256 tile, 2 = 256 x 128 tile.  Results are bit-identical to scp_linear_bf16x3 on the same values.
+ *   scp_split_rows: fp32 rows -> planes, optionally gathered: out[r] = split(src[idx ? idx[r] : r]); idx == n_src -> zero row */
+SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
+                     const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, void *Ohi, void *Olo, int64_t ldo,
+                     int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream);
+SCP_API int scp_split_rows(const float *src, int64_t ld_src, int64_t n_src, const int64_t *idx, int32_t C, void *hi, void *lo, int64_t ldo,
+                   int64_t rows, void *stream);
+/* producers that write the split format directly (same arithmetic as their fp32 forms, then hi = bf16(y), lo = bf16(y - hi)) */
+SCP_API int scp_layernorm_rows_split(const float *x, int64_t ldx, int64_t n_src_rows, const int64_t *ia, const int64_t *ib, int32_t C,
+                             const float *gamma, const float *beta, const float *valid, float eps, void *ohi, void *olo, int64_t ldo,
+                             int64_t rows, void *stream);
+SCP_API int scp_swin_attention_packed_split(const float *q, const float *k, const float *v, const float *bias_table, const int32_t *wtab,
+                                    int32_t total_windows, int32_t shift, int32_t ldq, int32_t ldkv, void *ohi, void *olo, int64_t ldo,
+                                    void *stream);
 
 /* numerics of the two products inside scp_swin_attention*: 1 (default) = bf16x3 split on bf16 MFMA, 0 = plain fp32 MFMA */
 SCP_API int scp_set_attention_mode(int32_t bf16x3);

@@ -27,10 +27,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define KT 64    // keys per staged tile
 #define LDK 68   // K tile row stride (floats): conflict-free ds_read_b128, 16-B aligned rows
 
+typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_split4(__bf16 *hi, __bf16 *lo, float a, float b, float c, float d) {
+    const float f[4] = {a, b, c, d};
+    bf16x4s vh, vl;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const __bf16 hh = (__bf16)f[u];
+        vh[u] = hh;
+        vl[u] = (__bf16)(f[u] - (float)hh);
+    }
+    *(bf16x4s *)hi = vh;
+    *(bf16x4s *)lo = vl;
+}
+
 __global__ __launch_bounds__(256, 2) void swin_attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                           const float *__restrict__ v, const float *__restrict__ table,
                                                           int Lp, int shift, int ldq, int ldkv, float *__restrict__ out,
-                                                          const int *__restrict__ wtab /* per 512-window: (sequence base row, sequence Lp) or NULL */) {
+                                                          const int *__restrict__ wtab /* per 512-window: (sequence base row, sequence Lp) or NULL */,
+                                                          __bf16 *__restrict__ ohi, __bf16 *__restrict__ olo, int64_t ldo) {
     __shared__ __attribute__((aligned(16))) float Ks[KT * LDK];
     __shared__ __attribute__((aligned(16))) float Vs[KT * HD];
     __shared__ float tab[2 * WIN - 1];
@@ -135,6 +150,16 @@ __global__ __launch_bounds__(256, 2) void swin_attn_kernel(const float *__restri
     }
     // ---- normalise and store: lane = query, accumulator rows = head dims -----------------------------------
     const float inv = 1.0f / l_run;
+    if (ohi) {   // hi/lo bf16 planes: the operand format of the projection GEMM (scp_linear_split)
+        const size_t o = (seq_row + (size_t)qtok) * (size_t)ldo + head * HD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 8 * g + 4 * h;
+            store_split4(ohi + o + d, olo + o + d, o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            store_split4(ohi + o + 32 + d, olo + o + 32 + d, o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+        return;
+    }
     float *dst = out + base + (size_t)qtok * (NH * HD);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -161,7 +186,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 2) void swin_attn_bf16x3_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                  const float *__restrict__ v, const float *__restrict__ table,
                                                                  int Lp, int shift, int ldq, int ldkv, float *__restrict__ out,
-                                                                 const int *__restrict__ wtab) {
+                                                                 const int *__restrict__ wtab, __bf16 *__restrict__ ohi,
+                                                                 __bf16 *__restrict__ olo, int64_t ldo) {
     __shared__ __attribute__((aligned(16))) __bf16 Kh[KT * LDB], Kl[KT * LDB];      // [key][d]
     __shared__ __attribute__((aligned(16))) __bf16 Vh[HD * LDB], Vl[HD * LDB];      // [d][permuted key]
     __shared__ float tab[2 * WIN - 1];
@@ -290,6 +316,16 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bf16x3_kernel(const float *_
         }
     }
     const float inv = 1.0f / l_run;
+    if (ohi) {   // hi/lo bf16 planes: the operand format of the projection GEMM (scp_linear_split)
+        const size_t o = (seq_row + (size_t)qtok) * (size_t)ldo + head * HD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 8 * g + 4 * h;
+            store_split4(ohi + o + d, olo + o + d, o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            store_split4(ohi + o + 32 + d, olo + o + 32 + d, o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+        return;
+    }
     float *dst = out + base + (size_t)qtok * (NH * HD);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -307,19 +343,34 @@ static inline bool attn_bf16x3() {
 extern "C" SCP_API int scp_set_attention_mode(int32_t bf16x3) { g_attn_mode = bf16x3 ? 1 : 0; return SCP_OK; }
 
 // packed ("varlen") form: total_windows 512-row windows, wtab[2*w] = first row of the sequence that owns window w, wtab[2*w+1] = its padded length
-extern "C" int scp_swin_attention_packed(const float *q, const float *k, const float *v, const float *bias_table, const int32_t *wtab,
-                                         int32_t total_windows, int32_t shift, int32_t ldq, int32_t ldkv, float *out, void *stream) {
-    if (!q || !k || !v || !bias_table || !out || !wtab || total_windows <= 0 || (shift != 0 && shift != WIN / 2) || ldq < NH * HD ||
-        ldkv < NH * HD || (ldq & 3) || (ldkv & 3) || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15))
+static int attn_packed(const float *q, const float *k, const float *v, const float *bias_table, const int32_t *wtab, int32_t total_windows,
+                       int32_t shift, int32_t ldq, int32_t ldkv, float *out, __bf16 *ohi, __bf16 *olo, int64_t ldo, void *stream) {
+    if (!q || !k || !v || !bias_table || (!out && !ohi) || !wtab || total_windows <= 0 || (shift != 0 && shift != WIN / 2) || ldq < NH * HD ||
+        ldkv < NH * HD || (ldq & 3) || (ldkv & 3) || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) ||
+        (ohi && (!olo || ldo < NH * HD || (ldo & 3) || (((uintptr_t)ohi | (uintptr_t)olo) & 7))))
         return SCP_EINVAL;
     if (attn_bf16x3())
         hipLaunchKernelGGL(swin_attn_bf16x3_kernel, dim3(total_windows * NH * (WIN / QT)), dim3(256), 0, (hipStream_t)stream, q, k, v, bias_table,
-                           0, shift, ldq, ldkv, out, wtab);
+                           0, shift, ldq, ldkv, out, wtab, ohi, olo, ldo);
     else
         hipLaunchKernelGGL(swin_attn_kernel, dim3(total_windows * NH * (WIN / QT)), dim3(256), 0, (hipStream_t)stream, q, k, v, bias_table, 0, shift,
-                           ldq, ldkv, out, wtab);
+                           ldq, ldkv, out, wtab, ohi, olo, ldo);
     LAUNCH_CHECK();
     return SCP_OK;
+}
+
+extern "C" int scp_swin_attention_packed(const float *q, const float *k, const float *v, const float *bias_table, const int32_t *wtab,
+                                         int32_t total_windows, int32_t shift, int32_t ldq, int32_t ldkv, float *out, void *stream) {
+    if (!out) return SCP_EINVAL;
+    return attn_packed(q, k, v, bias_table, wtab, total_windows, shift, ldq, ldkv, out, nullptr, nullptr, 0, stream);
+}
+
+// the same, output written as bf16 hi/lo planes [rows][ldo] (operand format of scp_linear_split)
+extern "C" int scp_swin_attention_packed_split(const float *q, const float *k, const float *v, const float *bias_table, const int32_t *wtab,
+                                               int32_t total_windows, int32_t shift, int32_t ldq, int32_t ldkv, void *ohi, void *olo,
+                                               int64_t ldo, void *stream) {
+    if (!ohi || !olo) return SCP_EINVAL;
+    return attn_packed(q, k, v, bias_table, wtab, total_windows, shift, ldq, ldkv, nullptr, (__bf16 *)ohi, (__bf16 *)olo, ldo, stream);
 }
 
 extern "C" int scp_swin_attention(const float *q, const float *k, const float *v, const float *bias_table, int32_t B, int32_t Lp,
@@ -330,10 +381,10 @@ extern "C" int scp_swin_attention(const float *q, const float *k, const float *v
     const int nblk = B * (Lp / WIN) * NH * (WIN / QT);
     if (attn_bf16x3())
         hipLaunchKernelGGL(swin_attn_bf16x3_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, q, k, v, bias_table, Lp, shift, ldq, ldkv, out,
-                           (const int *)nullptr);
+                           (const int *)nullptr, (__bf16 *)nullptr, (__bf16 *)nullptr, (int64_t)0);
     else
         hipLaunchKernelGGL(swin_attn_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, q, k, v, bias_table, Lp, shift, ldq, ldkv, out,
-                           (const int *)nullptr);
+                           (const int *)nullptr, (__bf16 *)nullptr, (__bf16 *)nullptr, (int64_t)0);
     LAUNCH_CHECK();
     return SCP_OK;
 }

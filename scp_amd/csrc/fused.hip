@@ -10,13 +10,14 @@
 #include "scp_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 template <int NV>   // float4 per lane: C = 256 * NV
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float *__restrict__ x, int64_t ldx, int64_t n_src_rows,
                                                             const int64_t *__restrict__ ia, const int64_t *__restrict__ ib,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             const float *__restrict__ valid, float eps, float *__restrict__ out, int64_t ldo,
-                                                            int64_t rows) {
+                                                            int64_t rows, __bf16 *__restrict__ ohi, __bf16 *__restrict__ olo) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -49,24 +50,48 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float *__rest
         f32x4 y;
 #pragma unroll
         for (int u = 0; u < 4; ++u) y[u] = ((v[p][u] - mean) * rstd * g[u] + b[u]) * keep;
-        *(f32x4 *)(out + r * ldo + p * 256 + 4 * lane) = y;
+        if (ohi) {   // hi/lo bf16 planes (operand format of scp_linear_split)
+            bf16x4 vh, vl;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const __bf16 hh = (__bf16)y[u];
+                vh[u] = hh;
+                vl[u] = (__bf16)(y[u] - (float)hh);
+            }
+            *(bf16x4 *)(ohi + r * ldo + p * 256 + 4 * lane) = vh;
+            *(bf16x4 *)(olo + r * ldo + p * 256 + 4 * lane) = vl;
+        } else *(f32x4 *)(out + r * ldo + p * 256 + 4 * lane) = y;
     }
+}
+
+static int ln_rows(const float *x, int64_t ldx, int64_t n_src_rows, const int64_t *ia, const int64_t *ib, int32_t C, const float *gamma,
+                   const float *beta, const float *valid, float eps, float *out, __bf16 *ohi, __bf16 *olo, int64_t ldo, int64_t rows, void *stream) {
+    if (!x || !gamma || !beta || (!out && !ohi) || rows < 0 || (C != 256 && C != 512) || (ldx & 3) || (ldo & 3) || ldo < C ||
+        ((ia == nullptr) != (ib == nullptr) && C == 512) || (ia && C == 256 && ib) ||
+        (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) || (ohi && (!olo || (((uintptr_t)ohi | (uintptr_t)olo) & 7))))
+        return SCP_EINVAL;
+    if (rows == 0) return SCP_OK;
+    const unsigned nb = (unsigned)cdiv64(rows, 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 256) hipLaunchKernelGGL(layernorm_rows_kernel<1>, dim3(nb), dim3(256), 0, st, x, ldx, n_src_rows, ia, ia, gamma, beta, valid, eps, out, ldo, rows, ohi, olo);
+    else hipLaunchKernelGGL(layernorm_rows_kernel<2>, dim3(nb), dim3(256), 0, st, x, ldx, n_src_rows, ia, ib, gamma, beta, valid, eps, out, ldo, rows, ohi, olo);
+    LAUNCH_CHECK();
+    return SCP_OK;
 }
 
 extern "C" SCP_API int scp_layernorm_rows(const float *x, int64_t ldx, int64_t n_src_rows, const int64_t *ia, const int64_t *ib, int32_t C,
                                           const float *gamma, const float *beta, const float *valid, float eps, float *out, int64_t ldo,
                                           int64_t rows, void *stream) {
-    if (!x || !gamma || !beta || !out || rows < 0 || (C != 256 && C != 512) || (ldx & 3) || (ldo & 3) || ldo < C ||
-        ((ia == nullptr) != (ib == nullptr) && C == 512) || (ia && C == 256 && ib) ||
-        (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15))
-        return SCP_EINVAL;
-    if (rows == 0) return SCP_OK;
-    const unsigned nb = (unsigned)cdiv64(rows, 4);
-    hipStream_t st = (hipStream_t)stream;
-    if (C == 256) hipLaunchKernelGGL(layernorm_rows_kernel<1>, dim3(nb), dim3(256), 0, st, x, ldx, n_src_rows, ia, ia, gamma, beta, valid, eps, out, ldo, rows);
-    else hipLaunchKernelGGL(layernorm_rows_kernel<2>, dim3(nb), dim3(256), 0, st, x, ldx, n_src_rows, ia, ib, gamma, beta, valid, eps, out, ldo, rows);
-    LAUNCH_CHECK();
-    return SCP_OK;
+    if (!out) return SCP_EINVAL;
+    return ln_rows(x, ldx, n_src_rows, ia, ib, C, gamma, beta, valid, eps, out, nullptr, nullptr, ldo, rows, stream);
+}
+
+// the same, output written as bf16 hi/lo planes [rows][ldo] (operand format of scp_linear_split)
+extern "C" SCP_API int scp_layernorm_rows_split(const float *x, int64_t ldx, int64_t n_src_rows, const int64_t *ia, const int64_t *ib, int32_t C,
+                                                const float *gamma, const float *beta, const float *valid, float eps, void *ohi, void *olo,
+                                                int64_t ldo, int64_t rows, void *stream) {
+    if (!ohi || !olo) return SCP_EINVAL;
+    return ln_rows(x, ldx, n_src_rows, ia, ib, C, gamma, beta, valid, eps, nullptr, (__bf16 *)ohi, (__bf16 *)olo, ldo, rows, stream);
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, int64_t lds, const int64_t *__restrict__ idx, int C4,

@@ -1,0 +1,399 @@
+// Dense layer on bf16 MFMA with fp32-class accuracy, BOTH operands pre-split ("bf16x3", gfx950 / CDNA4).
+//
+//     C = epilogue(A . W^T),   a.w ~= a_lo.w_hi + a_hi.w_lo + a_hi.w_hi   (fp32 accumulate, same order as gemm.hip)
+//
+// An activation travels between the kernels of the context model as two bf16 planes hi = bf16(x), lo = bf16(x - hi) (the
+// producing kernel's epilogue writes them: LayerNorm, attention, this GEMM, the row gathers) - the same 4 bytes per element
+// as fp32, but the consumer needs no conversion: every operand tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4),
+// no VGPRs, no VALU.  That is what lets one workgroup per CU run a 256-row tile:
+//
+//   workgroup = 8 waves, tile BM x BN = 256 x 256 (waves 2 x 4) or 256 x 128 (waves 4 x 2), wave tile (TM x 32) x 64,
+//   K step = 32 elements x 2 planes = 64 B rows (the byte geometry of a plain bf16 BK = 64 GEMM), two LDS stages:
+//   stage = planes A_hi, A_lo [BM][32], W_hi, W_lo [BN][32]; 16-byte chunk q of row r sits at chunk q ^ ((r >> 2) & 3), so the
+//   16 rows a ds_read_b128 lane group touches cover all 64 banks.  The LDS image is lane-linear per LDS-DMA instruction
+//   (16 rows x 64 B = 1 KiB); the XOR is applied to the per-lane SOURCE address.
+//   Loop: wait own DMA (vmcnt 0) -> barrier -> start DMA of step k+1 into the other stage -> 2 x {12 ds_read_b128,
+//   3 x TM x 2 MFMA 32x32x16}.  Persistent: a workgroup walks tiles with stride gridDim.x and starts the first DMA of its next
+//   tile before the epilogue of the current one, so the HBM latency of a tile's first step hides behind the stores.
+//   Epilogue: accumulators -> wave-private LDS slice (32 x 64 fp32, rows of 256 B = one bank sweep) -> 16-byte rows:
+//   + bias, activation, + residual, written as fp32 and/or as hi/lo planes (columns N .. round32(N) are zero filled: the next
+//   layer's K padding).
+#include "scp_internal.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_GELU = 2, ACT_RELU = 3 };
+
+template <int act>
+__device__ __forceinline__ float apply_act_s(float y) {
+    if (act == ACT_LEAKY) return y > 0.f ? y : 0.01f * y;
+    if (act == ACT_GELU) {   // exact-erf GELU; erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7) - identical to gemm.hip
+        const float x = fabsf(y) * 0.70710678118654752f;
+        const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+        const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+        const float e = 1.0f - poly * __expf(-x * x);
+        return 0.5f * y * (1.0f + copysignf(e, y));
+    }
+    if (act == ACT_RELU) return y > 0.f ? y : 0.f;
+    return y;
+}
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+
+__device__ __forceinline__ void dma16(const void *g, char *l) {
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+}
+
+struct GemmSplitArgs {
+    const __bf16 *Ahi, *Alo; int64_t lda;        // activation planes [M][lda], lda % 8 == 0, columns K .. Kpad finite (zero)
+    const __bf16 *Whi, *Wlo; int Kpad;           // weight planes [Npad][Kpad], zero padded, Npad % 256 == 0, Kpad % 32 == 0
+    const float *bias;                           // [N] or null
+    const float *res; int64_t ldr;               // fp32 residual [M][ldr] or null
+    float *C; int64_t ldc;                       // fp32 output or null
+    __bf16 *Ohi, *Olo; int64_t ldo;              // split output planes or null
+    int M, N;
+    int prio;
+    int stagger;                                 // start delay units (x s_sleep 127) per (workgroup >> 3) & 3: de-phases the CUs
+    int vec_ok;                                  // fp32 rows of C / residual are 16-byte aligned
+    int ncols_out;                               // split output: columns written (N rounded up to 32, <= ldo): zero filled beyond N
+};
+
+template <int WM, int WN, int TM, int ACT>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmSplitArgs a) {
+    constexpr int NW = WM * WN;                            // waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU)
+    constexpr int TN = 2;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int STAGE = (BM + BN) * 128;                 // bytes: 2 planes x 64 B rows
+    constexpr int OFF_AL = BM * 64, OFF_BH = 2 * BM * 64, OFF_BL = 2 * BM * 64 + BN * 64;
+    constexpr int NA = BM / (16 * NW), NB = BN / (16 * NW);            // LDS-DMA instructions per plane per wave
+    static_assert(NW == 8 || NW == 4, "4 or 8 waves");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction; tell the compiler (LDS-DMA bases live in M0)
+    const int wm = w / WN, wn = w % WN;
+    const int nk = a.Kpad >> 5;
+    const int tn = (a.N + BN - 1) / BN, tm = (a.M + BM - 1) / BM;
+    const int ntiles = tn * tm;
+
+    // DMA lane constants: lane l of an instruction fills chunk l of its 1 KiB = row l >> 2, chunk position l & 3
+    const int d_row = lane >> 2;
+    const int d_q = (lane & 3) ^ ((lane >> 4) & 3);        // logical k-chunk stored at that position
+    // fragment read lane constants
+    const int f_pos0 = (h ^ ((lane >> 2) & 3)) << 4;       // byte offset of chunk (kc = 0, half h) in this lane's row; kc = 1: ^ 32
+
+    auto tile_coords = [&](int t, int &m0, int &n0) {
+        // XCD-aware order inside each round of gridDim.x tiles: workgroup b runs on XCD b & 7, so give every XCD a contiguous
+        // run of tiles (the N tiles of one row stripe back to back): the stripe is fetched once per XCD L2
+        // (full rounds only - the ragged last round keeps the identity, so the map stays a bijection)
+        const int g = gridDim.x;
+        const int round = t / g, b = t - round * g;
+        int lin = t;
+        if ((g & 7) == 0 && (round + 1) * g <= ntiles) lin = round * g + (b & 7) * (g >> 3) + (b >> 3);
+        m0 = (lin / tn) * BM;
+        n0 = (lin % tn) * BN;
+    };
+
+    auto stage_issue = [&](int st, int m0, int n0, int kt) {
+        char *base = smem + st * STAGE;
+        const int k0 = kt * 32 + 8 * d_q;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int cr = w + NW * j;                     // 16-row chunk of the plane
+            int m = m0 + 16 * cr + d_row;
+            m = m < a.M ? m : a.M - 1;
+            const int64_t off = (int64_t)m * a.lda + k0;
+            dma16(a.Ahi + off, base + cr * 1024);
+            dma16(a.Alo + off, base + OFF_AL + cr * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int cr = w + NW * j;
+            const int64_t off = (int64_t)(n0 + 16 * cr + d_row) * a.Kpad + k0;
+            dma16(a.Whi + off, base + OFF_BH + cr * 1024);
+            dma16(a.Wlo + off, base + OFF_BL + cr * 1024);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    for (int d = ((((blockIdx.x >> 3) & 1)) + 2 * ((blockIdx.x >> 8) & 1)) * a.stagger; d > 0; --d) __builtin_amdgcn_s_sleep(127);
+    // two waves share a SIMD (w and w + 4): the upper half always wins MFMA arbitration, so the pair falls out of phase - one
+    // runs its MFMA batch while the other waits for its fragment reads - instead of both stalling on LDS at the same time
+    if (a.prio && w >= 4) __builtin_amdgcn_s_setprio(1);
+    int m0, n0;
+    tile_coords(tile, m0, n0);
+    stage_issue(0, m0, n0, 0);
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // ---- software-pipelined k loop -----------------------------------------------------------------------------------
+        // A k-step (32 k x 2 planes) is four sub-phases of TM MFMA tiles x 3 products: (kc, p) = k-chunk of 16 x half of the
+        // wave's row tiles.  Every sub-phase first issues the fragment reads of the NEXT one (second register set), then runs
+        // its MFMAs, so LDS latency hides behind the matrix pipe.  One barrier per k-step, ahead of the last sub-phase: by then
+        // every read of the current stage has been issued and waited for, the DMA of step kt + 1 (issued a k-step ago) has
+        // landed, and the DMA of step kt + 2 may overwrite the current stage.
+        constexpr int HM = TM / 2;
+        bf16x8 Ah[2][HM], Al[2][HM], Bh[2][TN], Bl[2][TN];
+        const int fa = (wm * (TM * 32) + col) * 64, fb = OFF_BH + (wn * 64 + col) * 64;
+        auto load_b = [&](int buf, int sbo, int kc) {
+            const int ob = sbo + fb + (f_pos0 ^ (kc * 32));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                Bh[buf][j] = *(const bf16x8 *)(smem + ob + j * 2048);
+                Bl[buf][j] = *(const bf16x8 *)(smem + ob + (OFF_BL - OFF_BH) + j * 2048);
+            }
+        };
+        auto load_a = [&](int buf, int sbo, int kc, int p) {
+            const int oa = sbo + fa + (f_pos0 ^ (kc * 32)) + p * (HM * 2048);
+#pragma unroll
+            for (int i = 0; i < HM; ++i) {
+                Ah[buf][i] = *(const bf16x8 *)(smem + oa + i * 2048);
+                Al[buf][i] = *(const bf16x8 *)(smem + oa + OFF_AL + i * 2048);
+            }
+        };
+        auto mfma_sub = [&](int ab, int bb, int p) {
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[p * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ab][i], Bh[bb][j], acc[p * HM + i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[p * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ab][i], Bl[bb][j], acc[p * HM + i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[p * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ab][i], Bh[bb][j], acc[p * HM + i][j], 0, 0, 0);
+        };
+
+        __syncthreads();   // DMA of step 0 landed (the fence waits vmcnt 0); every wave is past the previous tile's epilogue
+        if (nk > 1) stage_issue(1, m0, n0, 1);
+        load_b(0, 0, 0);
+        load_a(0, 0, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int sbo = (kt & 1) * STAGE, sbn = STAGE - sbo;
+            load_a(1, sbo, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_sub(0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(1, sbo, 1);
+            load_a(0, sbo, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_sub(1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(1, sbo, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_sub(0, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) {
+                __syncthreads();
+                if (kt + 2 < nk) stage_issue(kt & 1, m0, n0, kt + 2);
+                load_b(0, sbn, 0);
+                load_a(0, sbn, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_sub(1, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();   // every wave is done with both stages
+        const int cm0 = m0, cn0 = n0;
+        if (tile + (int)gridDim.x < ntiles) {   // first step of the next tile: in flight during the epilogue (stage 0)
+            tile_coords(tile + gridDim.x, m0, n0);
+            stage_issue(0, m0, n0, 0);
+        }
+
+        // ---- epilogue through this wave's private 8 KiB slice of stage 1 ---------------------------------------------------
+        float *stg = (float *)(smem + STAGE + w * 8192);
+        float bv[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = cn0 + wn * 64 + j * 32 + col;
+            bv[j] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+        }
+        const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+        const int nb = cn0 + wn * 64 + c4;
+        const bool full = (cn0 + wn * 64 + 64 <= a.N) && a.vec_ok;        // wave-uniform: the wave's 64 columns are all real
+        const bool has_res = a.res != nullptr, has_c = a.C != nullptr, has_o = a.Ohi != nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = cm0 + wm * (TM * 32) + i * 32 + rsub;     // row of it = 0; it adds 4
+            f32x4 rr[8];
+            if (has_res && full) {   // residual rows first: eight independent 16-byte loads in flight (row clamped, no branch)
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = mb + 4 * it;
+                    const int mc = m < a.M ? m : a.M - 1;
+                    rr[it] = *(const f32x4 *)(a.res + (int64_t)mc * a.ldr + nb);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    stg[ml * 64 + j * 32 + col] = apply_act_s<ACT>(acc[i][j][r] + bv[j]);
+                }
+            if (full) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = mb + 4 * it;
+                    f32x4 y = *(const f32x4 *)(stg + (4 * it + rsub) * 64 + c4);
+                    if (has_res) y += rr[it];
+                    if (has_c) { if (m < a.M) *(f32x4 *)(a.C + (int64_t)m * a.ldc + nb) = y; }
+                    if (has_o) {
+                        bf16x4 hi, lo;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const __bf16 hh = (__bf16)y[u];
+                            hi[u] = hh;
+                            lo[u] = (__bf16)(y[u] - (float)hh);
+                        }
+                        if (m < a.M) {
+                            *(bf16x4 *)(a.Ohi + (int64_t)m * a.ldo + nb) = hi;
+                            *(bf16x4 *)(a.Olo + (int64_t)m * a.ldo + nb) = lo;
+                        }
+                    }
+                }
+            } else {   // ragged N edge (N = 240 / 255 / 128 under a wider tile): element-wise, rare
+                for (int it = 0; it < 8; ++it) {
+                    const int m = mb + 4 * it;
+                    f32x4 y = *(const f32x4 *)(stg + (4 * it + rsub) * 64 + c4);
+                    if (m >= a.M) continue;
+                    for (int u = 0; u < 4; ++u) {
+                        if (nb + u < a.N) {
+                            if (has_res) y[u] += a.res[(int64_t)m * a.ldr + nb + u];
+                            if (has_c) a.C[(int64_t)m * a.ldc + nb + u] = y[u];
+                        } else y[u] = 0.f;
+                    }
+                    if (has_o && nb < a.ncols_out) {
+                        bf16x4 hi, lo;
+                        for (int u = 0; u < 4; ++u) {
+                            const __bf16 hh = (__bf16)y[u];
+                            hi[u] = hh;
+                            lo[u] = (__bf16)(y[u] - (float)hh);
+                        }
+                        *(bf16x4 *)(a.Ohi + (int64_t)m * a.ldo + nb) = hi;
+                        *(bf16x4 *)(a.Olo + (int64_t)m * a.ldo + nb) = lo;
+                    }
+                }
+            }
+        }
+        // the next tile's first barrier orders these LDS reads before the DMA that refills stage 1
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 rows -> hi/lo planes, optionally gathered: out[r][0:C] = split(src[idx ? idx[r] : r][0:C]); idx == n_src -> zero row
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ src, int64_t lds_, int64_t n_src, const int64_t *__restrict__ idx,
+                                                        int C4, int Cp4, __bf16 *__restrict__ hi, __bf16 *__restrict__ lo, int64_t ldo, int64_t total) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const int64_t r = g / Cp4;
+    const int c = (int)(g - r * Cp4);
+    const int64_t s = idx ? idx[r] : r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < C4 && s < n_src) v = *(const f32x4 *)(src + s * lds_ + 4 * c);
+    bf16x4 vh, vl;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const __bf16 hh = (__bf16)v[u];
+        vh[u] = hh;
+        vl[u] = (__bf16)(v[u] - (float)hh);
+    }
+    *(bf16x4 *)(hi + r * ldo + 4 * c) = vh;
+    *(bf16x4 *)(lo + r * ldo + 4 * c) = vl;
+}
+
+extern "C" SCP_API int scp_split_rows(const float *src, int64_t ld_src, int64_t n_src, const int64_t *idx, int32_t C, void *hi, void *lo,
+                                      int64_t ldo, int64_t rows, void *stream) {
+    if (!src || !hi || !lo || rows < 0 || C <= 0 || (C & 3) || (ld_src & 3) || (ldo & 7) || ldo < C || (((uintptr_t)src) & 15) ||
+        (((uintptr_t)hi | (uintptr_t)lo) & 7))
+        return SCP_EINVAL;
+    if (rows == 0) return SCP_OK;
+    int Cp = (C + 31) & ~31;          // zero fill up to the next multiple of 32 (the consumer's K padding) when the row has room
+    if (Cp > ldo) Cp = C;
+    const int64_t total = rows * (Cp / 4);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, n_src, idx, C / 4,
+                       Cp / 4, (__bf16 *)hi, (__bf16 *)lo, ldo, total);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+static int g_num_cu = 0;
+
+template <int WM, int WN, int TM>
+static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * 64;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int BOUNCE = WM * WN * 8192;
+    constexpr int LDS = STAGE + (STAGE > BOUNCE ? STAGE : BOUNCE);   // stage 0 + max(stage 1, the epilogue's 8 KiB bounce slice per wave)
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        configured = true;
+    }
+    const int64_t ntiles = cdiv64(ga.M, BM) * cdiv64(ga.N, BN);
+    const int64_t slots = (int64_t)g_num_cu * (WM * WN == 4 ? 2 : 1);
+    const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+#define GOS(ACT) hipLaunchKernelGGL((gemm_split_kernel<WM, WN, TM, ACT>), dim3(grid), dim3(WM * WN * 64), LDS, st, ga)
+    switch (act) { case ACT_LEAKY: GOS(ACT_LEAKY); break; case ACT_GELU: GOS(ACT_GELU); break; case ACT_RELU: GOS(ACT_RELU); break; default: GOS(ACT_NONE); }
+#undef GOS
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
+                                        const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, void *Ohi, void *Olo,
+                                        int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream) {
+    if (!Ahi || !Alo || !Whi || !Wlo || (!C && !Ohi) || ((Ohi == nullptr) != (Olo == nullptr)) || M <= 0 || N <= 0 || K <= 0 || (lda & 7) ||
+        Kpad < K || (Kpad & 31) || lda < Kpad || (Npad & 255) || Npad < N || act < 0 || act > 3 || (C && ldc < N) ||
+        (residual && ldr < N) || (Ohi && ((ldo & 7) || ldo < N)) ||
+        (((uintptr_t)Ahi | (uintptr_t)Alo | (uintptr_t)Whi | (uintptr_t)Wlo) & 15) || (((uintptr_t)C | (uintptr_t)residual) & 3) ||
+        (((uintptr_t)Ohi | (uintptr_t)Olo) & 7))
+        return SCP_EINVAL;
+    if (!g_num_cu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipGetDeviceProperties(&p, dev));
+        g_num_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }
+    GemmSplitArgs ga;
+    ga.Ahi = (const __bf16 *)Ahi; ga.Alo = (const __bf16 *)Alo; ga.lda = lda;
+    ga.Whi = (const __bf16 *)Whi; ga.Wlo = (const __bf16 *)Wlo; ga.Kpad = Kpad;
+    ga.bias = bias; ga.res = residual; ga.ldr = ldr; ga.C = C; ga.ldc = ldc;
+    ga.Ohi = (__bf16 *)Ohi; ga.Olo = (__bf16 *)Olo; ga.ldo = ldo; ga.M = M; ga.N = N;
+    int nco = (N + 31) & ~31;
+    if (nco > ldo) nco = (N + 3) & ~3;
+    ga.ncols_out = nco;
+    ga.stagger = (cfg >> 8) & 255;
+    ga.prio = (cfg & 0x40000) ? 1 : 0;
+    if (cfg & 0x10000) ga.lda = 0;                                   // DEBUG timing probes (results wrong): all A rows = row 0
+    if (cfg & 0x20000) { ga.C = nullptr; ga.Ohi = ga.Olo = nullptr; ga.res = nullptr; }   // no epilogue traffic
+    cfg &= 255;
+    ga.vec_ok = !((C && ((ldc & 3) || ((uintptr_t)C & 15))) || (residual && ((ldr & 3) || ((uintptr_t)residual & 15))));
+    hipStream_t st = (hipStream_t)stream;
+    // cfg 0 = automatic: the 256 x 128 tile where a 256-wide one would leave the chip's last round mostly empty or N <= 128
+    if (cfg == 0) cfg = (N <= 128) ? 2 : 1;
+    if (cfg == 2) return launch_cfg<4, 2, 2>(ga, act, st);
+    if (cfg == 3) return launch_cfg<2, 2, 2>(ga, act, st);   // 128 x 128, 4 waves, two workgroups per CU
+    return launch_cfg<2, 4, 4>(ga, act, st);
+}

@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import native
-from ..ops import linear, layer_norm, leaky_mlp3
+from ..ops import linear_s, leaky_mlp3_s, split_cat, linear, layer_norm, leaky_mlp3
 from .ehem import SHIFT, WINDOW, _edge_conv_packed
 
 
@@ -133,27 +133,30 @@ def _swin_layer(layer, x, valid, wtab, shift, query=None):
         layer._scp_packed_v = packed
     W, b, _ = packed
     lnb = layer.layernorm_before
-    h = native.layernorm_rows(x, lnb.weight, lnb.bias, lnb.eps, valid=valid)
+    # every GEMM operand is produced in the split (bf16 hi/lo) format by the kernel before it: LN -> qkv, attention -> proj,
+    # LN -> fc1 -> fc2; the residual stream x stays fp32
+    h = native.layernorm_rows(x, lnb.weight, lnb.bias, lnb.eps, valid=valid, split=True)
     if not cross:
-        qkv = linear(h, W, b)
+        qkv = linear_s(h, W, b)
         q, k, v = qkv[:, :256], qkv[:, 256:512], qkv[:, 512:]
     else:
-        hq = native.layernorm_rows(query, lnb.weight, lnb.bias, lnb.eps, valid=valid)
-        q = linear(hq, att.query.weight, att.query.bias)
-        kv = linear(h, W, b)
+        hq = native.layernorm_rows(query, lnb.weight, lnb.bias, lnb.eps, valid=valid, split=True)
+        q = linear_s(hq, att.query.weight, att.query.bias)
+        kv = linear_s(h, W, b)
         k, v = kv[:, :256], kv[:, 256:]
-    o = native.swin_attention_packed(q, k, v, att.relative_position_bias_table, wtab, shift)
-    x = linear(o, layer.attention.output.dense.weight, layer.attention.output.dense.bias, residual=x)
+    o = native.swin_attention_packed(q, k, v, att.relative_position_bias_table, wtab, shift, split=True)
+    x = linear_s(o, layer.attention.output.dense.weight, layer.attention.output.dense.bias, residual=x)
     lna = layer.layernorm_after
-    y = linear(native.layernorm_rows(x, lna.weight, lna.bias, lna.eps), layer.intermediate.dense.weight, layer.intermediate.dense.bias, act="gelu")
-    return linear(y, layer.output.dense.weight, layer.output.dense.bias, residual=x)
+    y = linear_s(native.layernorm_rows(x, lna.weight, lna.bias, lna.eps, split=True), layer.intermediate.dense.weight,
+                 layer.intermediate.dense.bias, act="gelu", want="split")
+    return linear_s(y, layer.output.dense.weight, layer.output.dense.bias, residual=x)
 
 
 def _merge(m, x, maps):
     """SwinPatchMerging: gather (even, odd) token of every pair + LayerNorm(512) in one kernel, then the 512 -> 256 reduction."""
     ev, od = maps          # index == x.shape[0] stands for the zero row an odd-length window is padded with
-    y = native.layernorm_rows(x, m.norm.weight, m.norm.bias, m.norm.eps, ia=ev, ib=od)
-    return linear(y, m.reduction.weight, None)
+    y = native.layernorm_rows(x, m.norm.weight, m.norm.bias, m.norm.eps, ia=ev, ib=od, split=True)
+    return linear_s(y, m.reduction.weight, None)
 
 
 def _encoder(enc, x, valids, tabs, merges, query=None):
@@ -170,19 +173,17 @@ def _encoder(enc, x, valids, tabs, merges, query=None):
 
 
 def _concat(hs, cmaps, extra=None):
-    """concat_states (ehem.py:75-86): stage s is gathered at token >> s straight into its 256-column slot; `extra` = (src, map)
-    appends one more gathered slot (the odd-token features of the cross branch, ehem.py:124)."""
+    """concat_states (ehem.py:75-86): stage s is gathered at token >> s straight into its 256-column slot of a split (bf16 hi/lo)
+    buffer - the operand of the MLP that follows; `extra` = (src, map) appends one more gathered slot (the odd-token features of
+    the cross branch, ehem.py:124)."""
     n = len(hs) - 1 + (1 if extra is not None else 0)
-    out = torch.empty((hs[1].shape[0], 256 * n), dtype=torch.float32, device=hs[1].device)
-    out[:, :256] = hs[1]
+    out = native.SplitAct.empty(hs[1].shape[0], 256 * n, hs[1].device)
+    native.split_rows(hs[1], out=out.cols(0, 256))
     for s in range(1, len(hs) - 1):
-        native.gather_rows(hs[s + 1], cmaps[s - 1], out[:, 256 * s:256 * (s + 1)])
+        native.split_rows(hs[s + 1], idx=cmaps[s - 1], out=out.cols(256 * s, 256 * (s + 1)))
     if extra is not None:
         k = len(hs) - 1
-        if extra[1] is None:
-            out[:, 256 * k:] = extra[0]
-        else:
-            native.gather_rows(extra[0], extra[1], out[:, 256 * k:])
+        native.split_rows(extra[0], idx=extra[1], out=out.cols(256 * k, 256 * (k + 1)))
     return out
 
 
@@ -205,16 +206,21 @@ def ehem_phase1_packed(model, ctx, pos, plan):
     pos2 = _edge_conv_packed(g.conv2, torch.cat((pos1, x), 1), ktab)
     x = leaky_mlp3(g.mlp2, x, exact=True)
     pos3 = _edge_conv_packed(g.conv3, torch.cat((pos2, x), 1), ktab)
-    x = leaky_mlp3(g.mlp3, x)
-    ec = leaky_mlp3(g.edge_mlp1, torch.cat((pos1, pos2, pos3), 1))
-    ec = leaky_mlp3(g.edge_mlp2, torch.cat((pos3, ec), 1))
-    feat = torch.cat((x, ec), 1)
+    # dense part on the split-operand GEMM: fp32 tensors are split once, the MLP chains stay in the split format, the two
+    # halves of `feat` are written straight into their column slots
+    nx = g.mlp3[4].weight.shape[0]
+    feat = torch.empty((P0, nx + g.edge_mlp2[4].weight.shape[0]), dtype=torch.float32, device=dev)
+    leaky_mlp3_s(g.mlp3, native.split_rows(x), out=feat[:, :nx])
+    e_in = native.SplitAct.empty(P0, pos3.shape[1] + g.edge_mlp1[4].weight.shape[0], dev)     # cat(pos3, edge_mlp1(...))
+    native.split_rows(pos3, out=e_in.cols(0, pos3.shape[1]))
+    leaky_mlp3_s(g.edge_mlp1, split_cat((pos1, pos2, pos3)), want="split", out_split=e_in.cols(pos3.shape[1], e_in.K))
+    leaky_mlp3_s(g.edge_mlp2, e_in, out=feat[:, nx:])
     hs = _encoder(model.swin_self_transformer, feat, d["self_valid"], d["self_tab"], d["self_merge"])
-    feat_a = leaky_mlp3(model.ancient_mlp, _concat(hs, d["self_concat"]))
+    feat_a = leaky_mlp3_s(model.ancient_mlp, _concat(hs, d["self_concat"]))
     Q0 = d["a1map"].shape[0]
-    a1 = native.gather_rows(feat_a, d["a1map"], torch.empty((Q0, 256), dtype=torch.float32, device=dev))
+    a1 = native.split_rows(feat_a, idx=d["a1map"])
     a2 = native.gather_rows(feat_a, d["a2map"], torch.empty((Q0, 256), dtype=torch.float32, device=dev))
-    prob1 = leaky_mlp3(model.prob_pred_mlp1, a1)
+    prob1 = leaky_mlp3_s(model.prob_pred_mlp1, a1)
     return prob1[d["even_rows"]], dict(a1=a1, a2=a2, pre_occ=ctx0[d["a1map"], 11])
 
 
@@ -227,9 +233,12 @@ def ehem_phase2_packed(model, st, plan, pre_occ=None):
     a1, a2 = st["a1"], st["a2"]
     po = st["pre_occ"] if pre_occ is None else pre_occ
     occ_feat = leaky_mlp3(model.pre_occ_mlp, F.embedding(po, g.occ_enc.weight))
-    pre = torch.cat((occ_feat, leaky_mlp3(model.pre_attn_mlp, a1)), 1)
+    no = occ_feat.shape[1]
+    pre = torch.empty((a2.shape[0], no + model.pre_attn_mlp[4].weight.shape[0]), dtype=torch.float32, device=a2.device)
+    pre[:, :no] = occ_feat
+    leaky_mlp3_s(model.pre_attn_mlp, a1, out=pre[:, no:])
     hc = _encoder(model.swin_cross_transformer, pre, d["cross_valid"], d["cross_tab"], d["cross_merge"], query=a2)
-    prob2 = leaky_mlp3(model.prob_pred_mlp2, _concat(hc, d["cross_concat"], extra=(a2, None)))
+    prob2 = leaky_mlp3_s(model.prob_pred_mlp2, _concat(hc, d["cross_concat"], extra=(a2, None)))
     return prob2[d["odd_rows"]]
 
 

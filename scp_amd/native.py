@@ -69,13 +69,17 @@ def lib():
         "scp_knn_topk": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp]),
         "scp_knn_topk_packed": (C.c_int, [_vp, _vp, i32, i32, _vp, _vp]),
         "scp_swin_attention_packed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp]),
+        "scp_swin_attention_packed_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, i64, _vp]),
         "scp_set_attention_mode": (C.c_int, [i32]),
         "scp_edge_gather_max": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_swin_attention": (C.c_int, [_vp, _vp, _vp, _vp, i32, i32, i32, i32, i32, _vp, _vp]),
         "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
         "scp_split_weight_bf16": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp, _vp]),
         "scp_linear_bf16x3": (C.c_int, [_vp, i64, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp]),
+        "scp_linear_split": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
+        "scp_split_rows": (C.c_int, [_vp, i64, i64, _vp, i32, _vp, _vp, i64, i64, _vp]),
         "scp_layernorm_rows": (C.c_int, [_vp, i64, i64, _vp, _vp, i32, _vp, _vp, _vp, C.c_float, _vp, i64, i64, _vp]),
+        "scp_layernorm_rows_split": (C.c_int, [_vp, i64, i64, _vp, _vp, i32, _vp, _vp, _vp, C.c_float, _vp, _vp, i64, i64, _vp]),
         "scp_gather_rows": (C.c_int, [_vp, i64, _vp, i32, _vp, i64, i64, _vp]),
         "scp_linear_f32": (C.c_int, [_vp, i64, _vp, _vp, _vp, i64, i32, i32, i32, i32, _vp]),
         "scp_softmax_cdf": (C.c_int, [_vp, i64, i64, i32, _vp, _vp, _vp, _vp, _vp]),
@@ -247,9 +251,17 @@ def knn_topk_packed(x, ctab):
     return idx
 
 
-def swin_attention_packed(q, k, v, bias_table, wtab, shift):
-    """q,k,v cuda f32 [T,256] views (unit channel stride), wtab int32 [T/512, 2] = (sequence base row, padded length)."""
+def swin_attention_packed(q, k, v, bias_table, wtab, shift, split=False):
+    """q,k,v cuda f32 [T,256] views (unit channel stride), wtab int32 [T/512, 2] = (sequence base row, padded length).
+    split=True returns the output as a SplitAct (operand of linear_split) instead of fp32."""
     T = q.shape[0]
+    if split:
+        o = SplitAct.empty(T, 256, q.device)
+        rc = lib().scp_swin_attention_packed_split(q.data_ptr(), k.data_ptr(), v.data_ptr(), _dev(bias_table, torch.float32),
+                                                   _dev(wtab, torch.int32), T // 512, shift, q.stride(0), k.stride(0), o.t[0].data_ptr(),
+                                                   o.t[1].data_ptr(), o.t.stride(1), _stream())
+        _check(rc, "scp_swin_attention_packed_split")
+        return o
     out = torch.empty((T, 256), dtype=torch.float32, device=q.device)
     rc = lib().scp_swin_attention_packed(q.data_ptr(), k.data_ptr(), v.data_ptr(), _dev(bias_table, torch.float32),
                                          _dev(wtab, torch.int32), T // 512, shift, q.stride(0), k.stride(0), _dev(out), _stream())
@@ -301,7 +313,7 @@ class SplitWeight:
     def __init__(self, w):
         N, K = w.shape
         self.N, self.K = N, K
-        self.Npad, self.Kpad = -(-N // 128) * 128, -(-K // 32) * 32
+        self.Npad, self.Kpad = -(-N // 256) * 256, -(-K // 32) * 32
         self.hi = torch.empty((self.Npad, self.Kpad), dtype=torch.bfloat16, device=w.device)
         self.lo = torch.empty_like(self.hi)
         wc = w.detach().contiguous().float()
@@ -334,11 +346,80 @@ def linear_bf16x3(x, sw, bias=None, act=ACT_NONE, residual=None, out=None):
     return out.reshape(*lead, N) if out.dim() == 2 and len(lead) != 1 else out
 
 
-def layernorm_rows(x, gamma, beta, eps=1e-5, valid=None, ia=None, ib=None, out=None):
+class SplitAct:
+    """An activation [M, K] as bf16 planes hi = bf16(x), lo = bf16(x - hi): t is bfloat16 [2, M, ld] (ld = K rounded up to 32,
+    padding columns zero) or a column slice of such a buffer.  This is the operand format of scp_linear_split."""
+
+    __slots__ = ("t", "K")
+
+    def __init__(self, t, K):
+        self.t, self.K = t, K
+
+    @staticmethod
+    def empty(M, K, device):
+        return SplitAct(torch.empty((2, M, -(-K // 32) * 32), dtype=torch.bfloat16, device=device), K)
+
+    @property
+    def M(self):
+        return self.t.shape[1]
+
+    def cols(self, c0, c1):
+        """view of columns [c0, c1) (c0 % 8 == 0)"""
+        return SplitAct(self.t[:, :, c0:c1], c1 - c0)
+
+    def float(self):
+        return self.t[0, :, :self.K].float() + self.t[1, :, :self.K].float()
+
+
+def split_rows(x, idx=None, out=None):
+    """fp32 rows [n, C] -> SplitAct; idx int64 [rows] gathers rows (idx == n -> zero row)."""
+    Cc = x.shape[1]
+    rows = x.shape[0] if idx is None else idx.shape[0]
+    if out is None:
+        out = SplitAct.empty(rows, Cc, x.device)
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    t = out.t
+    _check(lib().scp_split_rows(x.data_ptr(), x.stride(0), x.shape[0], _opt(idx), Cc, t[0].data_ptr(), t[1].data_ptr(), t.stride(1), rows,
+                                _stream()), "scp_split_rows")
+    return out
+
+
+def linear_split(a, sw, bias=None, act=ACT_NONE, residual=None, out=None, out_split=None, want="f32", cfg=0):
+    """a SplitAct [M, K] -> act(a @ W.T + bias) + residual as fp32 [M, N] (want "f32"), as SplitAct (want "split") or both
+    (want "both": returns (fp32, SplitAct)).  out / out_split may be column slices of wider buffers."""
+    M, N, K = a.M, sw.N, sw.K
+    if a.K != K:
+        raise ScpError("linear_split: K mismatch %d vs %d" % (a.K, K))
+    t = a.t
+    c = o = None
+    if want in ("f32", "both"):
+        c = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=t.device)
+    if want in ("split", "both"):
+        o = out_split if out_split is not None else SplitAct.empty(M, N, t.device)
+    r2 = residual
+    rc = lib().scp_linear_split(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.Npad, sw.Kpad, _opt(bias),
+                                None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0),
+                                None if c is None else c.data_ptr(), 0 if c is None else c.stride(0),
+                                None if o is None else o.t[0].data_ptr(), None if o is None else o.t[1].data_ptr(),
+                                0 if o is None else o.t.stride(1), M, N, K, act, cfg, _stream())
+    _check(rc, "scp_linear_split")
+    return c if want == "f32" else (o if want == "split" else (c, o))
+
+
+def layernorm_rows(x, gamma, beta, eps=1e-5, valid=None, ia=None, ib=None, out=None, split=False):
     """x [n,256|512...] fp32 rows (unit channel stride).  Plain LN (ia None), LN of gathered rows (ia, C = 256) or of
-    cat(x[ia], x[ib]) (C = 512).  valid: fp32 [rows] or [rows,1] multiplier.  Returns [rows, C]."""
+    cat(x[ia], x[ib]) (C = 512).  valid: fp32 [rows] or [rows,1] multiplier.  Returns [rows, C] fp32, or a SplitAct (split=True)."""
     Cc = gamma.shape[0]
     rows = x.shape[0] if ia is None else ia.shape[0]
+    if split:
+        o = SplitAct.empty(rows, Cc, x.device)
+        rc = lib().scp_layernorm_rows_split(x.data_ptr(), x.stride(0), x.shape[0], None if ia is None else _dev(ia, torch.int64),
+                                            None if ib is None else _dev(ib, torch.int64), Cc, _dev(gamma), _dev(beta),
+                                            None if valid is None else _dev(valid, torch.float32), float(eps), o.t[0].data_ptr(),
+                                            o.t[1].data_ptr(), o.t.stride(1), rows, _stream())
+        _check(rc, "scp_layernorm_rows_split")
+        return o
     if out is None:
         out = torch.empty((rows, Cc), dtype=torch.float32, device=x.device)
     rc = lib().scp_layernorm_rows(x.data_ptr(), x.stride(0), x.shape[0], None if ia is None else _dev(ia, torch.int64),

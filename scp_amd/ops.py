@@ -59,6 +59,38 @@ def linear(x, w, b=None, act=None, residual=None, exact=False):
     return y if residual is None else y + residual
 
 
+def linear_s(a, w, b=None, act=None, residual=None, want="f32", out=None, out_split=None):
+    """The same layer on a pre-split activation (native.SplitAct): operands go global -> LDS by LDS-DMA (csrc/gemm_split.hip).
+    want: "f32" -> fp32 [M, N] (optionally into `out`, which may be a column slice), "split" -> SplitAct for the next layer."""
+    N = w.shape[0]
+    if want == "f32" and out is None and N % 4:
+        # rows must be 16-byte aligned for the vector epilogue: pad the row stride, hand back the [M, N] view
+        buf = torch.empty((a.M, -(-N // 4) * 4), dtype=torch.float32, device=a.t.device)
+        return native.linear_split(a, _split(w), b, _ACT[act], residual, out=buf, want="f32")[:, :N]
+    return native.linear_split(a, _split(w), b, _ACT[act], residual, out=out, out_split=out_split, want=want)
+
+
+def leaky_mlp3_s(seq, a, want="f32", out=None, out_split=None):
+    """leaky_mlp3 on a SplitAct: the two hidden activations stay in the split format, the last layer writes `want`."""
+    a = linear_s(a, seq[0].weight, seq[0].bias, act="leaky", want="split")
+    a = linear_s(a, seq[2].weight, seq[2].bias, act="leaky", want="split")
+    return linear_s(a, seq[4].weight, seq[4].bias, want=want, out=out, out_split=out_split)
+
+
+def split_cat(parts, device=None):
+    """SplitAct of torch.cat(parts, 1) without materialising the fp32 concatenation (column offsets must be multiples of 8)."""
+    K = sum(p.shape[1] for p in parts)
+    out = native.SplitAct.empty(parts[0].shape[0], K, parts[0].device)
+    c = 0
+    for p_ in parts:
+        assert c % 8 == 0 and p_.shape[1] % 4 == 0
+        native.split_rows(p_, out=out.cols(c, c + p_.shape[1]))
+        c += p_.shape[1]
+    if out.t.shape[2] > K:
+        out.t[:, :, K:].zero_()
+    return out
+
+
 def layer_norm(x, ln):
     return F.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
 

@@ -309,3 +309,64 @@ def test_octattn_logits_vs_reference(dev, octattn, name):
     e = np.abs(o - z["out"]).max()
     print(f"{name}: max|dlogit| = {e:.3e}")
     assert e <= LOGIT_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,act,res", [(1000, 256, 256, 0, True), (257, 300, 64, 3, False), (700, 255, 512, 1, False),
+                                           (513, 240, 240, 0, False), (2049, 1024, 256, 2, False), (300, 128, 448, 1, True)])
+def test_linear_split_matches_fp32_activation_kernel(M, N, K, act, res):
+    """scp_linear_split (both operands pre-split, LDS-DMA staging) is bit-identical to scp_linear_bf16x3 (activation split while
+    staging) in every tile configuration, for fp32 and for split outputs, and zero-fills the K padding of its split output."""
+    from scp_amd import native
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((M, K), generator=g).to(dev)
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    r = torch.randn((M, N), generator=g).to(dev) if res else None
+    sw = native.SplitWeight(w)
+    ref = native.linear_bf16x3(a, sw, b, act, r)
+    sa = native.split_rows(a)
+    hi = a.bfloat16()
+    assert torch.equal(sa.t[0, :, :K], hi) and torch.equal(sa.t[1, :, :K], (a - hi.float()).bfloat16())
+    assert (sa.t[:, :, K:] == 0).all()
+    ld = -(-N // 4) * 4
+    for cfg in (0, 1, 2, 3):
+        buf = torch.full((M, ld), float("nan"), device=dev)
+        out = native.linear_split(sa, sw, b, act, r, out=buf, cfg=cfg)[:, :N]
+        assert torch.equal(out, ref), cfg
+        o = native.linear_split(sa, sw, b, act, r, want="split", cfg=cfg)
+        want = native.split_rows(ref.contiguous())
+        assert torch.equal(o.t[:, :, :N], want.t[:, :, :N]) and (o.t[:, :, N:] == 0).all(), cfg
+    # gathered split with the zero-row sentinel
+    idx = torch.tensor([0, M - 1, M, 5], device=dev)
+    gs = native.split_rows(a, idx=idx)
+    assert torch.equal(gs.float()[[0, 1, 3]], sa.float()[[0, M - 1, 5]]) and (gs.t[:, 2] == 0).all()
+
+
+@pytest.mark.gpu
+def test_split_producers_match_fp32_forms():
+    """LayerNorm and window attention writing the split format = split_rows of their fp32 outputs, bit for bit."""
+    from scp_amd import native
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((1024, 256), generator=g).to(dev)
+    gam, bet = torch.randn(256, generator=g).to(dev), torch.randn(256, generator=g).to(dev)
+    valid = (torch.rand(1024, generator=g) > 0.1).float().to(dev)
+    y = native.layernorm_rows(x, gam, bet, 1e-5, valid=valid)
+    ys = native.layernorm_rows(x, gam, bet, 1e-5, valid=valid, split=True)
+    assert torch.equal(ys.t, native.split_rows(y).t)
+    ia = torch.arange(0, 1024, 2, device=dev)
+    ib = ia + 1
+    ib[-1] = 1024
+    g2, b2 = torch.randn(512, generator=g).to(dev), torch.randn(512, generator=g).to(dev)
+    y = native.layernorm_rows(x, g2, b2, 1e-5, ia=ia, ib=ib)
+    ys = native.layernorm_rows(x, g2, b2, 1e-5, ia=ia, ib=ib, split=True)
+    assert torch.equal(ys.t, native.split_rows(y).t)
+    qkv = torch.randn((1536, 768), generator=g).to(dev)
+    table = (0.5 * torch.randn((1023, 4), generator=g)).to(dev)
+    wtab = torch.tensor([[0, 1024], [0, 1024], [1024, 512]], dtype=torch.int32, device=dev)
+    for shift in (0, 256):
+        o = native.swin_attention_packed(qkv[:, :256], qkv[:, 256:512], qkv[:, 512:], table, wtab, shift)
+        os_ = native.swin_attention_packed(qkv[:, :256], qkv[:, 256:512], qkv[:, 512:], table, wtab, shift, split=True)
+        assert torch.equal(os_.t, native.split_rows(o).t)
