@@ -143,6 +143,10 @@ SCP_API int scp_knn_topk(const float *x, int32_t B, int32_t n, int32_t C, int32_
 /* packed ("varlen") form for many windows in one launch: x [total_rows][C], every sequence padded to a multiple of 512 rows;
  * ctab[2c] = first row of the sequence owning 512-row chunk c, ctab[2c+1] = its real length; idx [total_rows][20] holds GLOBAL rows */
 SCP_API int scp_knn_topk_packed(const float *x, const int32_t *ctab, int32_t total_rows, int32_t C, int32_t *idx, void *stream);
+/* numerics of the 144- / 192-feature searches: 1 (default) = "f16x3" (rows scaled by a power of two, two f16 terms, three
+ * f16 MFMA products, fp32 accumulate: distance values within ~1e-6 relative of the fp32 chain), 0 = exact fp32 MFMA chain
+ * (bit-identical distance values to PyTorch-CPU).  The 3-feature position search is always exact. */
+SCP_API int scp_set_knn_mode(int32_t f16x3);
 
 /* edge-conv tail: out[b][i][c] = lrelu_0.2( scale[c] * (sel_j u[b][idx[b][i][j]][c] + v[b][i][c]) + shift[c] ),
  * sel = max when scale[c] >= 0 else min  (== max over j of BN(conv(edge feature)), dgcnn.py:62-71,132-134) */

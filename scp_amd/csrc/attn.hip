@@ -29,7 +29,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_split4(__bf16 *hi, __bf16 *lo, float a, float b, float c, float d) {
-    const float f[4] = {a, b, c, d};
+    float f[4] = {a, b, c, d};
+    // materialise the rounded fp32 values: without this the compiler may contract (o * inv) - hi into one FMA and the planes
+    // would no longer be the split of the fp32 output
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(f[u]));
     bf16x4s vh, vl;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

@@ -54,9 +54,11 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float *__rest
             bf16x4 vh, vl;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const __bf16 hh = (__bf16)y[u];
+                float yy = y[u];
+                asm volatile("" : "+v"(yy));   // the rounded fp32 value, not an FMA-contracted (.. * keep) - hi
+                const __bf16 hh = (__bf16)yy;
                 vh[u] = hh;
-                vl[u] = (__bf16)(y[u] - (float)hh);
+                vl[u] = (__bf16)(yy - (float)hh);
             }
             *(bf16x4 *)(ohi + r * ldo + p * 256 + 4 * lane) = vh;
             *(bf16x4 *)(olo + r * ldo + p * 256 + 4 * lane) = vl;

@@ -9,16 +9,16 @@
 // the distance VALUES are bit-identical to the reference's; only exactly tied distances can be ordered differently
 // (this kernel: lower index first; the reference: whatever its top-k implementation does).
 //
-// Layout (specialised kernel, K = C rounded up to 4, KS = K/2 MFMA steps):
-//   workgroup = 4 waves = 128 queries, a wave owns 32 queries; B operand = the wave's query features, KS registers
-//   per lane, loaded once; A operand = a 32-candidate tile staged in LDS de-interleaved as [cand][even k | odd k] so a
-//   lane reads its KS values with ds_read_b128; tiles are double buffered through registers (issue the next tile's
-//   global loads, run KS MFMAs on the current one, then write LDS: one barrier per tile).
+// Layout (specialised kernels, K = 4 / 144 / 192 features):
+//   workgroup = 4 waves = 128 queries, a wave owns 32 queries; B operand = the wave's query features in registers, loaded
+//   once; A operand = 32-candidate tiles staged in LDS by LDS-DMA, double buffered (the DMA of the next stage runs under the
+//   MFMAs of the current one: one barrier per stage; a stage is 32 candidates, or 512 for K = 4).
 //   D[cand][query]: a lane ends up with 16 candidates of ONE query and keeps a private sorted top-20 (value, index)
 //   list in registers; the two lanes of a query share their pruning threshold and merge through LDS at the end.
 //   Tiles are visited outwards from the queries' own position: octree siblings are Morton neighbours, so the
 //   threshold tightens immediately and later insertions are rare.
 #include <float.h>
+#include <stdlib.h>
 #include <limits.h>
 #include "scp_internal.h"
 
@@ -46,162 +46,17 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float *__restrict__ x
     xx[i] = s;
 }
 
-// ------------------------------------------------------------------------------------------------ specialised kernel
-template <int KS>   // MFMA k-steps = padded C / 2
-__global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xx, int n, int C, int k,
-                                                         int *__restrict__ idx, const int *__restrict__ ctab /* packed mode: per 512-row chunk (seq base row, seq n) */) {
-    constexpr int K = 2 * KS;                       // padded feature count (multiple of 4)
-    constexpr int LD = (K % 8 == 0) ? K + 4 : K;    // LDS row stride in floats: LD/4 odd -> conflict-free ds_read_b128
-    constexpr int F4 = K / 4;                       // float4 per candidate row
-    constexpr int PER_T = (32 * F4 + 255) / 256;    // float4 global loads per thread per tile
-    constexpr int TILE_F = 2 * 32 * LD, MERGE_F = 2 * 128 * 2 * TK;          // floats
-    constexpr int POOL_F = TILE_F > MERGE_F ? TILE_F : MERGE_F;
-    __shared__ __attribute__((aligned(16))) float pool[POOL_F];                // tiles during the sweep, merge lists after it
-    __shared__ float txx[2][32];
-    float (*tile)[32 * LD] = (float (*)[32 * LD])pool;
-    float *mval = pool;
-    int *midx = (int *)(pool + 128 * 2 * TK);
+// ------------------------------------------------------------------------------------------------ specialised kernels
+// Candidate tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no VALU, no branches around the
+// loads) in their natural row order; the XOR swizzle that makes the fragment reads conflict-free is applied to the per-lane
+// SOURCE address (the LDS image of one DMA instruction is lane-linear).
+typedef __attribute__((address_space(3))) void *knn_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *knn_glb_ptr_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, col = lane & 31, h = lane >> 5;
-    // dense mode: blockIdx.y = batch item with n points.  packed mode: sequences padded to x512 rows lie back to back; the chunk
-    // table says which sequence (first row, real length) the 128 query rows of this workgroup belong to; indices come out GLOBAL
-    // and always TK per row (rows of sequences shorter than TK repeat their nearest neighbour, harmless under the max-pool).
-    size_t row0 = (size_t)blockIdx.y * n;
-    int q0 = blockIdx.x * 128;
-    if (ctab) {
-        const int ch = (blockIdx.x * 128) >> 9;
-        row0 = (size_t)ctab[2 * ch];
-        n = ctab[2 * ch + 1];
-        q0 = blockIdx.x * 128 - (int)row0;
-        if (q0 >= n) return;   // workgroup entirely inside the padding of its sequence
-    }
-    const float *xb = x + row0 * C;
-    const float *xxb = xx + row0;
-    const int qi = q0 + w * 32 + col;
-    const int nt = (n + 31) >> 5;
-
-    // ---- query fragment: features 2*s + h, s = 0..KS-1 ------------------------------------------------------
-    float qf[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int c = 2 * s + h;
-        qf[s] = (qi < n && c < C) ? xb[(size_t)qi * C + c] : 0.f;
-    }
-    const float xxi = (qi < n) ? xxb[qi] : 0.f;
-
-    float v[TK];
-    int id[TK];
-#pragma unroll
-    for (int t = 0; t < TK; ++t) { v[t] = -INFINITY; id[t] = INT_MAX; }
-
-    // ---- tile staging helpers ---------------------------------------------------------------------------------
-    f32x4 pre[PER_T];
-    float prexx = 0.f;
-    auto issue = [&](int t) {   // global -> registers
-        const int c0 = t * 32;
-#pragma unroll
-        for (int i = 0; i < PER_T; ++i) {
-            const int e = tid + i * 256;
-            const int r = e / F4, g = e - r * F4;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (e < 32 * F4 && c0 + r < n) {
-                const float *src = xb + (size_t)(c0 + r) * C + 4 * g;
-                if ((C & 3) == 0) val = *(const f32x4 *)src;
-                else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) if (4 * g + u < C) val[u] = src[u];
-                }
-            }
-            pre[i] = val;
-        }
-        if (tid < 32) prexx = (c0 + tid < n) ? xxb[c0 + tid] : 0.f;
-    };
-    auto commit = [&](int buf) {   // registers -> LDS, de-interleaved: even features first, odd features second
-#pragma unroll
-        for (int i = 0; i < PER_T; ++i) {
-            const int e = tid + i * 256;
-            const int r = e / F4, g = e - r * F4;
-            if (e < 32 * F4) {
-                float *row = tile[buf] + r * LD;
-                *(float2 *)(row + 2 * g) = make_float2(pre[i][0], pre[i][2]);
-                *(float2 *)(row + KS + 2 * g) = make_float2(pre[i][1], pre[i][3]);
-            }
-        }
-        if (tid < 32) txx[buf][tid] = prexx;
-    };
-
-    // outward tile order starting at the first tile of this workgroup's own queries
-    const int own = q0 >> 5;
-    int lo = own - 1, hi = own + 1, cur = own < nt ? own : nt - 1;
-    if (own >= nt) { lo = nt - 2; hi = nt; }
-    issue(cur);
-    commit(0);
-    __syncthreads();
-
-    for (int s = 0; s < nt; ++s) {
-        const int buf = s & 1;
-        // choose and prefetch the next tile
-        int nxt = -1;
-        if (s + 1 < nt) {
-            if ((s & 1) == 0) { if (hi < nt) nxt = hi++; else nxt = lo--; }
-            else { if (lo >= 0) nxt = lo--; else nxt = hi++; }
-            issue(nxt);
-        }
-        // ---- distances of 32 candidates x 32 queries ----------------------------------------------------------
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float *arow = tile[buf] + col * LD + h * KS;
-        if constexpr (KS % 4 == 0) {
-#pragma unroll
-            for (int g = 0; g < KS / 4; ++g) {
-                const f32x4 a = *(const f32x4 *)(arow + 4 * g);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], qf[4 * g], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], qf[4 * g + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], qf[4 * g + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], qf[4 * g + 3], acc, 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < KS / 2; ++g) {
-                const float2 a = *(const float2 *)(arow + 2 * g);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[2 * g], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[2 * g + 1], acc, 0, 0, 0);
-            }
-        }
-        // ---- selection: this lane holds candidates row = (r&3) + 8(r>>2) + 4h of the tile for query qi ------------
-        // Pass 1 (cheap, branch-free): distances + a bit mask of the candidates that beat the current 20th best.
-        // Pass 2: lanes pop their survivors one at a time, so the wavefront pays for max-over-lanes survivors (1-3 per
-        // tile) instead of for all 16 slots as soon as any lane has a hit in each of them.
-        const int c0 = cur * 32;
-        const float thr = fmaxf(v[TK - 1], __shfl_xor(v[TK - 1], 32));   // both lanes of a query prune with the tighter bound
-        float dd[16];
-        unsigned pend = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int j = c0 + cl;
-            dd[r] = (2.f * acc[r] - txx[buf][cl]) - xxi;
-            const bool pass = j < n && dd[r] >= thr && ((dd[r] > v[TK - 1]) || (dd[r] == v[TK - 1] && j < id[TK - 1]));
-            pend |= pass ? (1u << r) : 0u;
-        }
-        while (__any(pend != 0u)) {   // wave-uniform loop; lanes without a survivor insert a harmless (-inf, INT_MAX)
-            const bool act = pend != 0u;
-            const int r = act ? (__ffs(pend) - 1) : 0;
-            pend &= pend - 1u;
-            float d = dd[0];
-#pragma unroll
-            for (int rr = 1; rr < 16; ++rr) d = (rr == r) ? dd[rr] : d;
-            d = act ? d : -INFINITY;
-            const int j = act ? (c0 + (r & 3) + 8 * (r >> 2) + 4 * h) : INT_MAX;
-            topk_insert(v, id, d, j);   // a survivor that no longer qualifies simply falls off the end
-        }
-        if (nxt >= 0) commit(buf ^ 1);
-        cur = nxt;
-        __syncthreads();
-    }
-
-    // ---- merge the two partial lists of every query -----------------------------------------------------------------
+// ---- shared tail: merge the two partial lists of every query (lane halves h = 0 / 1) and write the indices -------------------
+__device__ __forceinline__ void knn_merge_write(const float (&v)[TK], const int (&id)[TK], float *mval, int *midx, int tid, int w, int col, int h,
+                                                int q0, int n, int k, size_t row0, const int *ctab, int *idx) {
     {
         const int ql = w * 32 + col;
 #pragma unroll
@@ -228,6 +83,344 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
                 if (takea) ++h0; else ++h1;
             } else out[o] = first;
         }
+    }
+}
+
+// ---- selection step shared by both kernels: this lane holds candidates row = (r&3) + 8(r>>2) + 4h of a 32-tile for its query ---
+// Pass 1 (cheap, branch-free): a bit mask of the candidates that beat the current 20th best.  Pass 2: lanes pop their
+// survivors one at a time, so the wavefront pays for max-over-lanes survivors instead of for all 16 slots.
+__device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, float xxi, int c0, int n, int h, float (&v)[TK], int (&id)[TK]) {
+    const float thr = fmaxf(v[TK - 1], __shfl_xor(v[TK - 1], 32));   // both lanes of a query prune with the tighter bound
+    unsigned pend = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int j = c0 + cl;
+        const float d = (2.f * acc[r] - sxx[cl]) - xxi;
+        const bool pass = j < n && d >= thr && ((d > v[TK - 1]) || (d == v[TK - 1] && j < id[TK - 1]));
+        pend |= pass ? (1u << r) : 0u;
+    }
+    while (__any(pend != 0u)) {   // wave-uniform loop; lanes without a survivor insert a harmless (-inf, INT_MAX)
+        const bool act = pend != 0u;
+        const int r = act ? (__ffs(pend) - 1) : 0;
+        pend &= pend - 1u;
+        float a = acc[0];
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr) a = (rr == r) ? acc[rr] : a;
+        const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float d = act ? ((2.f * a - sxx[cl]) - xxi) : -INFINITY;
+        const int j = act ? (c0 + cl) : INT_MAX;
+        topk_insert(v, id, d, j);   // a survivor that no longer qualifies simply falls off the end
+    }
+}
+
+// ---- exact fp32 kernel: v_mfma_f32_32x32x2_f32, k-ordered chain (bit-identical distance values to PyTorch-CPU) ----------------
+// rows of K floats; chunk q of row c at position q ^ (c & 15) (K = 192) / q ^ ((c >> 2) & 3) (K = 144); a lane reads four
+// consecutive features and feeds two of them (k = 4g + h, 4g + 2 + h) to two MFMA steps: lane half h still supplies feature
+// 2 * step + h, the k order of the chain is untouched.
+template <int KS, int NSUB>   // MFMA k-steps = C / 2; 32 * NSUB candidates per LDS stage
+__global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xx, int n, int C, int k,
+                                                         int *__restrict__ idx, const int *__restrict__ ctab /* packed mode: per 512-row chunk (seq base row, seq n) */) {
+    constexpr int K = 2 * KS;                       // feature count (multiple of 4) = row length in floats, rows are 16-byte aligned
+    constexpr int R = K / 4;                        // 16-byte chunks per row
+    constexpr int SC = 32 * NSUB;                   // candidates per stage
+    constexpr int STAGE_F = SC * K;                 // floats per stage
+    constexpr int NDMA = (SC * R + 63) / 64;        // 1 KiB DMA instructions per stage
+    constexpr int NDMA_W = (NDMA + 3) / 4;          // per wave
+    constexpr int MERGE_F = 2 * 128 * 2 * TK;
+    constexpr int TILES_F = 2 * STAGE_F + 2 * SC;   // two stages + their |x|^2
+    constexpr int POOL_F = TILES_F > MERGE_F ? TILES_F : MERGE_F;
+    static_assert((SC * R) % 64 == 0, "stage is a whole number of DMA instructions");
+    __shared__ __attribute__((aligned(1024))) float pool[POOL_F];              // stages during the sweep, merge lists after it
+    float *txx = pool + 2 * STAGE_F;                // [2][SC]
+
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // dense mode: blockIdx.y = batch item with n points.  packed mode: sequences padded to x512 rows lie back to back; the chunk
+    // table says which sequence (first row, real length) the 128 query rows of this workgroup belong to; indices come out GLOBAL
+    // and always TK per row (rows of sequences shorter than TK repeat their nearest neighbour, harmless under the max-pool).
+    size_t row0 = (size_t)blockIdx.y * n;
+    int q0 = blockIdx.x * 128;
+    if (ctab) {
+        const int ch = (blockIdx.x * 128) >> 9;
+        row0 = (size_t)ctab[2 * ch];
+        n = ctab[2 * ch + 1];
+        q0 = blockIdx.x * 128 - (int)row0;
+        if (q0 >= n) return;   // workgroup entirely inside the padding of its sequence
+    }
+    const float *xb = x + row0 * K;
+    const float *xxb = xx + row0;
+    const int qi = q0 + w * 32 + col;
+    const int nt = (n + SC - 1) / SC;               // stages
+
+    float qf[KS];                                   // query fragment: features 2*s + h
+    {
+        const int qc = qi < n ? qi : n - 1;         // clamped row: lanes beyond n compute garbage that is never written
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[s] = xb[(size_t)qc * K + 2 * s + h];
+    }
+    const float xxi = (qi < n) ? xxb[qi] : 0.f;
+
+    float v[TK];
+    int id[TK];
+#pragma unroll
+    for (int t = 0; t < TK; ++t) { v[t] = -INFINITY; id[t] = INT_MAX; }
+
+    auto issue = [&](int t, int buf) {   // candidates [t * SC, t * SC + SC) -> stage buf (rows beyond n: clamped, masked later)
+        const int c0 = t * SC;
+        char *sb = (char *)(pool + buf * STAGE_F);
+        // opaque copy of the lane id: keeps the per-DMA address arithmetic INSIDE the loop - hoisted, those loop invariants get
+        // spilled next to the query fragment, and every reload waits vmcnt(0), i.e. for the previous DMA to land
+        int ln;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));
+#pragma unroll
+        for (int j = 0; j < NDMA_W; ++j) {
+            const int ii = w + 4 * j;
+            if (ii < NDMA) {             // wave-uniform
+                const int ci = ii * 64 + ln;      // this lane fills chunk ci of the stage = row ci / R, position ci % R
+                const int r = ci / R, p = ci - r * R;
+                int q = p;
+                if (R % 16 == 0) q = p ^ (r & 15);
+                else if (R % 4 == 0 && R > 4) q = p ^ ((r >> 2) & 3);
+                int c = c0 + r;
+                c = c < n ? c : n - 1;
+                __builtin_amdgcn_global_load_lds((knn_glb_ptr_t)(xb + (size_t)c * K + 4 * q), (knn_lds_ptr_t)(sb + ii * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int e0 = 0; e0 < SC; e0 += 256) {
+            if (e0 + w * 64 < SC) {      // wave-uniform
+                const int e = e0 + w * 64 + ln;
+                if (e < SC) {
+                    int c = c0 + e;
+                    c = c < n ? c : n - 1;
+                    __builtin_amdgcn_global_load_lds((knn_glb_ptr_t)(xxb + c), (knn_lds_ptr_t)((char *)(txx + buf * SC) + (e0 + w * 64) * 4), 4, 0, 0);
+                }
+            }
+        }
+    };
+
+    const int swz = (R % 16 == 0) ? (col & 15) : ((R % 4 == 0 && R > 4) ? ((col >> 2) & 3) : 0);
+
+    // outward stage order starting at the stage that holds this workgroup's own queries
+    const int own = q0 / SC;
+    int lo = own - 1, hi = own + 1, cur = own < nt ? own : nt - 1;
+    if (own >= nt) { lo = nt - 2; hi = nt; }
+    issue(cur, 0);
+
+    for (int s = 0; s < nt; ++s) {
+        const int buf = s & 1;
+        __syncthreads();   // stage s has landed (the fence waits vmcnt 0) and every wave is done with the other stage
+        int nxt = -1;
+        if (s + 1 < nt) {
+            if ((s & 1) == 0) { if (hi < nt) nxt = hi++; else nxt = lo--; }
+            else { if (lo >= 0) nxt = lo--; else nxt = hi++; }
+            issue(nxt, buf ^ 1);
+        }
+        const float *stage = pool + buf * STAGE_F;
+        const float *sxx = txx + buf * SC;
+#pragma unroll 1
+        for (int sub = 0; sub < NSUB; ++sub) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float *arow = stage + (sub * 32 + col) * K;
+#pragma unroll
+            for (int g = 0; g < R; ++g) {
+                const f32x4 a = *(const f32x4 *)(arow + 4 * (g ^ swz));
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a[1] : a[0], qf[2 * g], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a[3] : a[2], qf[2 * g + 1], acc, 0, 0, 0);
+            }
+            knn_select(acc, sxx + sub * 32, xxi, cur * SC + sub * 32, n, h, v, id);
+        }
+        cur = nxt;
+    }
+    __syncthreads();   // everybody is done with the stages: the pool becomes the merge area
+    knn_merge_write(v, id, pool, (int *)(pool + 128 * 2 * TK), tid, w, col, h, q0, n, k, row0, ctab, idx);
+}
+
+// positions (C <= 4 features) padded to rows of 4 floats for the K = 4 specialisation
+__global__ __launch_bounds__(256) void pad4_kernel(const float *__restrict__ x, int64_t npts, int C, float *__restrict__ x4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npts) return;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) o[c] = x[i * C + c];
+    *(f32x4 *)(x4 + 4 * i) = o;
+}
+
+// ---- fp32-faithful kernel on f16 MFMA ("f16x3") -----------------------------------------------------------------------------
+// split2_kernel scales every row by its own power of two (largest |feature| into [2^13, 2^14): exact, keeps f16 clear of
+// overflow and of its subnormal range for everything that matters) and writes it as two f16 terms x ~= xa + xb (11 + 11
+// significant bits, residual < 2^-22 |x|).  A dot product keeps the three partial products down to 2^-11 relative size,
+//     x.y ~= xb.ya + xa.yb + xa.ya,          dropped: xb.yb < 2^-22 |x||y|,
+// accumulated in fp32 by v_mfma_f32_32x32x16_f16, small terms first, then multiplied by the two rows' inverse scales (powers
+// of two, exact).  Three f16 MFMAs cover 16 features in 96 cycles where the fp32 MFMA needs 512.  The distance values agree
+// with the fp32 chain to about its own rounding error (worst case 7e-7 of sum |x_i y_i|; the k-ordered fp32 chain itself
+// carries up to K 2^-24 of it), so the two kernels select the same neighbours except among candidates whose distances are
+// closer than that - the same class of difference as the ordering of exact ties (measured: tests/test_gpu_model.py).
+// SCP_KNN=f32 selects the exact kernel instead.
+// Data: planes [row][2][K] f16 = rows of 4K bytes; swizzle as in the fp32 kernel (K = 192: q ^ (c & 15), K = 144: q ^ ((c >> 2) & 3)).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__restrict__ planes, const float *__restrict__ xx,
+                                                          const float *__restrict__ inv_scale, int n, int k, int *__restrict__ idx,
+                                                          const int *__restrict__ ctab) {
+    constexpr int RB = 4 * K;                       // bytes per row
+    constexpr int R = RB / 16;                      // chunks per row (48 / 36)
+    constexpr int NC = K / 16;                      // k-chunks of 16 features
+    constexpr int STAGE_B = 32 * RB;                // bytes per stage (32 candidates)
+    constexpr int NDMA = STAGE_B / 1024;            // 1 KiB DMA instructions per stage (24 / 18)
+    constexpr int NDMA_W = (NDMA + 3) / 4;
+    constexpr int MERGE_B = 2 * 128 * 2 * TK * 4;
+    constexpr int TILES_B = 2 * STAGE_B + 2 * 64 * 4;
+    constexpr int POOL_B = TILES_B > MERGE_B ? TILES_B : MERGE_B;
+    static_assert(STAGE_B % 1024 == 0, "layout");
+    __shared__ __attribute__((aligned(1024))) char pool[POOL_B];
+    float *txx = (float *)(pool + 2 * STAGE_B);     // [2][64]: |x|^2 of the 32 candidates, then their inverse scales
+
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    size_t row0 = (size_t)blockIdx.y * n;
+    int q0 = blockIdx.x * 128;
+    if (ctab) {
+        const int ch = (blockIdx.x * 128) >> 9;
+        row0 = (size_t)ctab[2 * ch];
+        n = ctab[2 * ch + 1];
+        q0 = blockIdx.x * 128 - (int)row0;
+        if (q0 >= n) return;
+    }
+    const char *pb = (const char *)planes + row0 * RB;
+    const float *xxb = xx + row0, *isb = inv_scale + row0;
+    const int qi = q0 + w * 32 + col;
+    const int nt = (n + 31) >> 5;
+
+    // query fragments (B operand): plane p, chunk c: features 16c + 8h .. + 7
+    f16x8 qa[NC], qb[NC];
+    const int qc = qi < n ? qi : n - 1;
+    {
+        const char *src = pb + (size_t)qc * RB + 16 * h;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            qa[c] = *(const f16x8 *)(src + 32 * c);
+            qb[c] = *(const f16x8 *)(src + 2 * K + 32 * c);
+        }
+    }
+    const float xxi = (qi < n) ? xxb[qi] : 0.f;
+    const float isq2 = 2.f * isb[qc];               // 2 / scale of the query row (exact)
+
+    float v[TK];
+    int id[TK];
+#pragma unroll
+    for (int t = 0; t < TK; ++t) { v[t] = -INFINITY; id[t] = INT_MAX; }
+
+    auto issue = [&](int t, int buf) {
+        const int c0 = t * 32;
+        char *sb = pool + buf * STAGE_B;
+        int ln;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));   // see knn_mfma_kernel
+#pragma unroll
+        for (int j = 0; j < NDMA_W; ++j) {
+            const int ii = w + 4 * j;
+            if (ii < NDMA) {
+                const int ci = ii * 64 + ln;
+                const int r = ci / R, p = ci - r * R;
+                const int q = (R % 16 == 0) ? (p ^ (r & 15)) : (p ^ ((r >> 2) & 3));
+                int c = c0 + r;
+                c = c < n ? c : n - 1;
+                __builtin_amdgcn_global_load_lds((knn_glb_ptr_t)(pb + (size_t)c * RB + 16 * q), (knn_lds_ptr_t)(sb + ii * 1024), 16, 0, 0);
+            }
+        }
+        if (w == 0) {   // lanes 0..31: |x|^2, lanes 32..63: inverse scale of candidate lane & 31
+            int c = c0 + (ln & 31);
+            c = c < n ? c : n - 1;
+            const float *src = (ln < 32 ? xxb : isb) + c;
+            __builtin_amdgcn_global_load_lds((knn_glb_ptr_t)src, (knn_lds_ptr_t)((char *)(txx + buf * 64)), 4, 0, 0);
+        }
+    };
+
+    const int swz = (R % 16 == 0) ? (col & 15) : ((col >> 2) & 3);
+    const int own = q0 >> 5;
+    int lo = own - 1, hi = own + 1, cur = own < nt ? own : nt - 1;
+    if (own >= nt) { lo = nt - 2; hi = nt; }
+    issue(cur, 0);
+
+    for (int s = 0; s < nt; ++s) {
+        const int buf = s & 1;
+        __syncthreads();
+        int nxt = -1;
+        if (s + 1 < nt) {
+            if ((s & 1) == 0) { if (hi < nt) nxt = hi++; else nxt = lo--; }
+            else { if (lo >= 0) nxt = lo--; else nxt = hi++; }
+            issue(nxt, buf ^ 1);
+        }
+        const char *arow = pool + buf * STAGE_B + col * RB;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            // candidate fragments (A operand): chunk index inside the row = plane * (K / 8) + 2c + h
+            const f16x8 ca = *(const f16x8 *)(arow + 16 * ((2 * c + h) ^ swz));
+            const f16x8 cb = *(const f16x8 *)(arow + 16 * ((K / 8 + 2 * c + h) ^ swz));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cb, qa[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, qb[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, qa[c], acc, 0, 0, 0);
+        }
+        // un-scale: acc * (2 / s_query) * (1 / s_candidate) = 2 x.y (powers of two: exact); knn_select then forms (2 x.y - xx_j) - xx_i
+        const float *sxx = txx + buf * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+            acc[r] = 0.5f * ((acc[r] * isq2) * sxx[32 + cl]);
+        }
+        knn_select(acc, sxx, xxi, cur * 32, n, h, v, id);
+        cur = nxt;
+    }
+    __syncthreads();
+    knn_merge_write(v, id, (float *)pool, (int *)(pool + 128 * 2 * TK * 4), tid, w, col, h, q0, n, k, row0, ctab, idx);
+}
+
+// fp32 rows -> row scale 2^e (largest |x| into [2^13, 2^14)), two f16 planes of the scaled row ([row][2][K]), 1 / scale, and
+// |x|^2 of the UNscaled row (same summation as sqnorm_kernel).  One wavefront per row.
+__global__ __launch_bounds__(256) void split2_kernel(const float *__restrict__ x, int64_t npts, int K, _Float16 *__restrict__ planes,
+                                                    float *__restrict__ xx, float *__restrict__ inv_scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= npts) return;
+    const float *p = x + row * K;
+    float a[3];
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int c = lane + 64 * u;
+        a[u] = c < K ? p[c] : 0.f;
+        m = fmaxf(m, fabsf(a[u]));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    // scale = 2^(13 - floor(log2 m)), clamped so that scale and 1 / scale stay normal floats; m == 0 (or non-finite): scale 1
+    int e = 0;
+    if (m > 0.f && m < INFINITY) {
+        e = 13 - (((int)(__float_as_uint(m) >> 23) & 255) - 127);
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    }
+    const float sc = __uint_as_float((unsigned)(127 + e) << 23), isc = __uint_as_float((unsigned)(127 - e) << 23);
+    _Float16 *o = planes + row * 2 * K;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int c = lane + 64 * u;
+        if (c < K) {
+            const float t = a[u] * sc;                 // exact
+            const _Float16 ta = (_Float16)t;
+            o[c] = ta;
+            o[K + c] = (_Float16)(t - (float)ta);
+        }
+    }
+    if (lane == 0) {
+        float s = 0.f;
+        for (int c = 0; c < K; ++c) s = s + p[c] * p[c];   // -ffp-contract=off: two roundings per term
+        xx[row] = s;
+        inv_scale[row] = isc;
     }
 }
 
@@ -320,23 +513,54 @@ __global__ __launch_bounds__(256) void knn_generic_kernel(const float *__restric
     }
 }
 
-static DevBuf g_xx;   // |x|^2 scratch, grown on demand
+static DevBuf g_xx;   // |x|^2 scratch + the padded / split copy of the input, grown on demand
+
+static int g_knn_mode = -1;
+static int knn_mode() {   // 1 = f16x3 (default), 0 = exact fp32 MFMA (SCP_KNN=f32 or scp_set_knn_mode(0))
+    if (g_knn_mode < 0) { const char *e = getenv("SCP_KNN"); g_knn_mode = (e && e[0] == 'f') ? 0 : 1; }
+    return g_knn_mode;
+}
+extern "C" SCP_API int scp_set_knn_mode(int32_t f16x3) { g_knn_mode = f16x3 ? 1 : 0; return SCP_OK; }
+
+static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int k, int *idx, const int *ctab, hipStream_t st) {
+    const size_t xx_bytes = ((size_t)npts * sizeof(float) + 1023) & ~(size_t)1023;
+    const bool split = (C == 144 || C == 192) && knn_mode() == 1;
+    const int RB = C * 4;
+    int rc = g_xx.reserve(xx_bytes * (split ? 2 : 1) + (C <= 4 ? (size_t)npts * 16 : (split ? (size_t)npts * RB : 0)));
+    if (rc) return rc;
+    float *xx = g_xx.as<float>();
+    void *aux = (char *)g_xx.p + xx_bytes;
+    if (split) {
+        float *isc = (float *)aux;
+        _Float16 *pl = (_Float16 *)((char *)aux + xx_bytes);
+        hipLaunchKernelGGL(split2_kernel, dim3((unsigned)cdiv64(npts, 4)), dim3(256), 0, st, x, npts, C, pl, xx, isc);
+        if (C == 144) hipLaunchKernelGGL(knn_f16x3_kernel<144>, grid, dim3(256), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, n, k, idx, ctab);
+        else hipLaunchKernelGGL(knn_f16x3_kernel<192>, grid, dim3(256), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, n, k, idx, ctab);
+        LAUNCH_CHECK();
+        return SCP_OK;
+    }
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)cdiv64(npts, 256)), dim3(256), 0, st, x, npts, C, xx);
+    if (C <= 4) {
+        hipLaunchKernelGGL(pad4_kernel, dim3((unsigned)cdiv64(npts, 256)), dim3(256), 0, st, x, npts, C, (float *)aux);
+        hipLaunchKernelGGL((knn_mfma_kernel<2, 16>), grid, dim3(256), 0, st, (const float *)aux, (const float *)xx, n, 4, k, idx, ctab);
+    } else if (C == 144) hipLaunchKernelGGL((knn_mfma_kernel<72, 1>), grid, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, ctab);
+    else hipLaunchKernelGGL((knn_mfma_kernel<96, 1>), grid, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, ctab);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
 
 extern "C" int scp_knn_topk(const float *x, int32_t B, int32_t n, int32_t C, int32_t k, int32_t *idx, void *stream) {
     if (!x || !idx || B <= 0 || n <= 0 || C <= 0 || k <= 0 || k > TK || k > n) return SCP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int64_t npts = (int64_t)B * n;
+    if (C <= 4 || ((C == 144 || C == 192) && ((uintptr_t)x & 15) == 0))
+        return knn_launch(x, npts, C, dim3((n + 127) / 128, B), n, k, idx, nullptr, st);
     int rc = g_xx.reserve((size_t)npts * sizeof(float));
     if (rc) return rc;
     float *xx = g_xx.as<float>();
     hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)cdiv64(npts, 256)), dim3(256), 0, st, x, npts, C, xx);
     LAUNCH_CHECK();
-    const dim3 grid2((n + 127) / 128, B);
-    const int *none = nullptr;
-    if (C <= 4) hipLaunchKernelGGL(knn_mfma_kernel<2>, grid2, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, none);
-    else if (C == 144) hipLaunchKernelGGL(knn_mfma_kernel<72>, grid2, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, none);
-    else if (C == 192) hipLaunchKernelGGL(knn_mfma_kernel<96>, grid2, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, none);
-    else {
+    {
         const int Cpad = (C + 3) & ~3;
         int ldC = Cpad;
         while ((ldC & 3) != 2) ++ldC;   // ldC/2 odd: the 16 candidate rows of a fragment read hit 16 distinct even banks
@@ -357,17 +581,7 @@ extern "C" int scp_knn_topk(const float *x, int32_t B, int32_t n, int32_t C, int
 // packed ("varlen") form: x [total_rows][C] with sequences padded to multiples of 512 rows, ctab[2*c] = first row of the sequence owning
 // 512-row chunk c, ctab[2*c+1] = its real length; idx [total_rows][20] GLOBAL row indices (rows beyond a sequence's length are not written).
 extern "C" SCP_API int scp_knn_topk_packed(const float *x, const int32_t *ctab, int32_t total_rows, int32_t C, int32_t *idx, void *stream) {
-    if (!x || !ctab || !idx || total_rows <= 0 || (total_rows & 511) || (C != 144 && C != 192 && C > 4)) return SCP_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    int rc = g_xx.reserve((size_t)total_rows * sizeof(float));
-    if (rc) return rc;
-    float *xx = g_xx.as<float>();
-    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)cdiv64(total_rows, 256)), dim3(256), 0, st, x, (int64_t)total_rows, C, xx);
-    LAUNCH_CHECK();
-    const dim3 grid(total_rows / 128, 1);
-    if (C <= 4) hipLaunchKernelGGL(knn_mfma_kernel<2>, grid, dim3(256), 0, st, x, (const float *)xx, 0, C, TK, idx, ctab);
-    else if (C == 144) hipLaunchKernelGGL(knn_mfma_kernel<72>, grid, dim3(256), 0, st, x, (const float *)xx, 0, C, TK, idx, ctab);
-    else hipLaunchKernelGGL(knn_mfma_kernel<96>, grid, dim3(256), 0, st, x, (const float *)xx, 0, C, TK, idx, ctab);
-    LAUNCH_CHECK();
-    return SCP_OK;
+    if (!x || !ctab || !idx || total_rows <= 0 || (total_rows & 511) || (C != 144 && C != 192 && C > 4) || (C > 4 && ((uintptr_t)x & 15)))
+        return SCP_EINVAL;
+    return knn_launch(x, (int64_t)total_rows, C, dim3(total_rows / 128, 1), 0, TK, idx, ctab, (hipStream_t)stream);
 }

@@ -71,6 +71,7 @@ def lib():
         "scp_swin_attention_packed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp]),
         "scp_swin_attention_packed_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, i64, _vp]),
         "scp_set_attention_mode": (C.c_int, [i32]),
+        "scp_set_knn_mode": (C.c_int, [i32]),
         "scp_edge_gather_max": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_swin_attention": (C.c_int, [_vp, _vp, _vp, _vp, i32, i32, i32, i32, i32, _vp, _vp]),
         "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
@@ -267,6 +268,11 @@ def swin_attention_packed(q, k, v, bias_table, wtab, shift, split=False):
                                          _dev(wtab, torch.int32), T // 512, shift, q.stride(0), k.stride(0), _dev(out), _stream())
     _check(rc, "scp_swin_attention_packed")
     return out
+
+
+def set_knn_mode(f16x3):
+    """True (default): f16x3 distances for the 144-/192-feature searches; False: exact fp32 MFMA chain."""
+    _check(lib().scp_set_knn_mode(1 if f16x3 else 0), "scp_set_knn_mode")
 
 
 def edge_gather_max(u, v, idx, scale, shift, out=None):
