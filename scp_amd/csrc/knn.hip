@@ -87,30 +87,75 @@ __device__ __forceinline__ void knn_merge_write(const float (&v)[TK], const int 
 }
 
 // ---- selection step shared by both kernels: this lane holds candidates row = (r&3) + 8(r>>2) + 4h of a 32-tile for its query ---
-// Pass 1 (cheap, branch-free): a bit mask of the candidates that beat the current 20th best.  Pass 2: lanes pop their
-// survivors one at a time, so the wavefront pays for max-over-lanes survivors instead of for all 16 slots.
-__device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, float xxi, int c0, int n, int h, float (&v)[TK], int (&id)[TK]) {
-    const float thr = fmaxf(v[TK - 1], __shfl_xor(v[TK - 1], 32));   // both lanes of a query prune with the tighter bound
-    unsigned pend = 0;
+// `acc[r]` = x_i . x_j (SCALED: multiplied by `usc` and the candidate's entry of `sis` when SCALED).
+// Pass 1 (branch-free, ~6 VALU per candidate): d = (2 x.y - xx_j) - xx_i and a bit mask of the candidates that beat the pruning
+// bound thr = the tighter 20th best of the two lanes of the query: d > thr passes; d == thr (rare: collected as one wave-wide
+// scalar flag, resolved in a slow path) passes if it beats this lane's own 20th best under the (value desc, index asc) order.
+// Pass 2: lanes pop their survivors one at a time (the wavefront pays for max-over-lanes survivors, not for all 16 slots);
+// the 20-step insertion skips the leading 5-step segments that no lane's survivor reaches - late in the sweep a survivor
+// almost always lands near the end of the list.
+template <int T0>
+__device__ __forceinline__ void topk_insert_seg(float (&v)[TK], int (&id)[TK], float &d, int &j) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int t = T0; t < T0 + 5; ++t) {
+        const bool better = (d > v[t]) || (d == v[t] && j < id[t]);
+        const float nv = better ? d : v[t], od = better ? v[t] : d;
+        const int ni = better ? j : id[t], oj = better ? id[t] : j;
+        v[t] = nv; d = od; id[t] = ni; j = oj;
+    }
+}
+
+template <bool SCALED>
+__device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, const float *sis, float usc, float xxi, int c0, int n, int h,
+                                           float (&v)[TK], int (&id)[TK]) {
+    const float thr = fmaxf(v[TK - 1], __shfl_xor(v[TK - 1], 32));   // both lanes of a query prune with the tighter bound
+    const bool full = c0 + 32 <= n;                                   // wave-uniform: every candidate of the tile exists
+    unsigned pend = 0, eqm = 0;
+    unsigned long long anyeq = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 xj = *(const f32x4 *)(sxx + 8 * g + 4 * h);      // candidates (r & 3) + 8 g + 4 h, r & 3 = 0..3
+        f32x4 sj = {1.f, 1.f, 1.f, 1.f};
+        if (SCALED) sj = *(const f32x4 *)(sis + 8 * g + 4 * h);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = 4 * g + u;
+            float t = acc[r];
+            if (SCALED) t = (t * usc) * sj[u];                        // powers of two: exact
+            float d = (2.f * t - xj[u]) - xxi;
+            if (!full) d = (c0 + u + 8 * g + 4 * h < n) ? d : -INFINITY;
+            pend |= (d > thr) ? (1u << r) : 0u;
+            anyeq |= __ballot(d == thr);
+        }
+    }
+    // the distance of slot r again (pass 2 and the tie path; same arithmetic, so the same value)
+    auto dist = [&](int r) {
+        float a = acc[0];
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr) a = (rr == r) ? acc[rr] : a;
         const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int j = c0 + cl;
-        const float d = (2.f * acc[r] - sxx[cl]) - xxi;
-        const bool pass = j < n && d >= thr && ((d > v[TK - 1]) || (d == v[TK - 1] && j < id[TK - 1]));
-        pend |= pass ? (1u << r) : 0u;
+        if (SCALED) a = (a * usc) * sis[cl];
+        const float d = (2.f * a - sxx[cl]) - xxi;
+        return (full || c0 + cl < n) ? d : -INFINITY;
+    };
+    if (anyeq) {   // some lane has a candidate exactly on the bound (rare): admit it if it beats the lane's own 20th best
+        for (int r = 0; r < 16; ++r) {
+            const float d = dist(r);
+            const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool pass = d == thr && d > -INFINITY && ((d > v[TK - 1]) || j < id[TK - 1]);
+            eqm |= pass ? (1u << r) : 0u;
+        }
+        pend |= eqm;
     }
     while (__any(pend != 0u)) {   // wave-uniform loop; lanes without a survivor insert a harmless (-inf, INT_MAX)
         const bool act = pend != 0u;
         const int r = act ? (__ffs(pend) - 1) : 0;
         pend &= pend - 1u;
-        float a = acc[0];
-#pragma unroll
-        for (int rr = 1; rr < 16; ++rr) a = (rr == r) ? acc[rr] : a;
-        const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float d = act ? ((2.f * a - sxx[cl]) - xxi) : -INFINITY;
-        const int j = act ? (c0 + cl) : INT_MAX;
-        topk_insert(v, id, d, j);   // a survivor that no longer qualifies simply falls off the end
+        float d = dist(r);
+        d = act ? d : -INFINITY;
+        int j = act ? (c0 + (r & 3) + 8 * (r >> 2) + 4 * h) : INT_MAX;
+        // a survivor that no longer qualifies simply falls off the end
+        topk_insert(v, id, d, j);
     }
 }
 
@@ -231,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a[1] : a[0], qf[2 * g], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a[3] : a[2], qf[2 * g + 1], acc, 0, 0, 0);
             }
-            knn_select(acc, sxx + sub * 32, xxi, cur * SC + sub * 32, n, h, v, id);
+            knn_select<false>(acc, sxx + sub * 32, nullptr, 1.f, xxi, cur * SC + sub * 32, n, h, v, id);
         }
         cur = nxt;
     }
@@ -307,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
         }
     }
     const float xxi = (qi < n) ? xxb[qi] : 0.f;
-    const float isq2 = 2.f * isb[qc];               // 2 / scale of the query row (exact)
+    const float isq = isb[qc];                      // 1 / scale of the query row (a power of two)
 
     float v[TK];
     int id[TK];
@@ -367,14 +412,9 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, qb[c], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, qa[c], acc, 0, 0, 0);
         }
-        // un-scale: acc * (2 / s_query) * (1 / s_candidate) = 2 x.y (powers of two: exact); knn_select then forms (2 x.y - xx_j) - xx_i
+        // un-scaling (acc / s_query / s_candidate, powers of two: exact) happens inside the selection
         const float *sxx = txx + buf * 64;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
-            acc[r] = 0.5f * ((acc[r] * isq2) * sxx[32 + cl]);
-        }
-        knn_select(acc, sxx, xxi, cur * 32, n, h, v, id);
+        knn_select<true>(acc, sxx, sxx + 32, isq, xxi, cur * 32, n, h, v, id);
         cur = nxt;
     }
     __syncthreads();
@@ -382,45 +422,60 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
 }
 
 // fp32 rows -> row scale 2^e (largest |x| into [2^13, 2^14)), two f16 planes of the scaled row ([row][2][K]), 1 / scale, and
-// |x|^2 of the UNscaled row (same summation as sqnorm_kernel).  One wavefront per row.
+// |x|^2 of the UNscaled row (same sequential summation as sqnorm_kernel).  A workgroup stages 64 rows in LDS (coalesced
+// 16-byte loads; row stride K + 1 floats so that one thread per row can walk its row without bank conflicts), then one
+// wavefront per row reduces the maximum and writes the planes.
 __global__ __launch_bounds__(256) void split2_kernel(const float *__restrict__ x, int64_t npts, int K, _Float16 *__restrict__ planes,
                                                     float *__restrict__ xx, float *__restrict__ inv_scale) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= npts) return;
-    const float *p = x + row * K;
-    float a[3];
-    float m = 0.f;
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const int c = lane + 64 * u;
-        a[u] = c < K ? p[c] : 0.f;
-        m = fmaxf(m, fabsf(a[u]));
+    __shared__ float tile[64 * 193];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int nr = (int)((npts - r0) < 64 ? (npts - r0) : 64);
+    const int LDT = K + 1;
+    const float *src = x + r0 * K;
+    for (int e = tid; e < nr * (K / 4); e += 256) {
+        const f32x4 val = *(const f32x4 *)(src + 4 * e);
+        const int r = (4 * e) / K, c = 4 * e - r * K;
+        float *d = tile + r * LDT + c;
+        d[0] = val[0]; d[1] = val[1]; d[2] = val[2]; d[3] = val[3];
     }
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    // scale = 2^(13 - floor(log2 m)), clamped so that scale and 1 / scale stay normal floats; m == 0 (or non-finite): scale 1
-    int e = 0;
-    if (m > 0.f && m < INFINITY) {
-        e = 13 - (((int)(__float_as_uint(m) >> 23) & 255) - 127);
-        e = e > 100 ? 100 : (e < -100 ? -100 : e);
-    }
-    const float sc = __uint_as_float((unsigned)(127 + e) << 23), isc = __uint_as_float((unsigned)(127 - e) << 23);
-    _Float16 *o = planes + row * 2 * K;
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const int c = lane + 64 * u;
-        if (c < K) {
-            const float t = a[u] * sc;                 // exact
-            const _Float16 ta = (_Float16)t;
-            o[c] = ta;
-            o[K + c] = (_Float16)(t - (float)ta);
-        }
-    }
-    if (lane == 0) {
+    __syncthreads();
+    if (tid < nr) {
+        const float *p = tile + tid * LDT;
         float s = 0.f;
         for (int c = 0; c < K; ++c) s = s + p[c] * p[c];   // -ffp-contract=off: two roundings per term
-        xx[row] = s;
-        inv_scale[row] = isc;
+        xx[r0 + tid] = s;
+    }
+    for (int rr = w; rr < nr; rr += 4) {
+        const float *p = tile + rr * LDT;
+        float a[3];
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = lane + 64 * u;
+            a[u] = c < K ? p[c] : 0.f;
+            m = fmaxf(m, fabsf(a[u]));
+        }
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        // scale = 2^(13 - floor(log2 m)), clamped so that scale and 1 / scale stay normal floats; m == 0 (or non-finite): scale 1
+        int e = 0;
+        if (m > 0.f && m < INFINITY) {
+            e = 13 - (((int)(__float_as_uint(m) >> 23) & 255) - 127);
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        }
+        const float sc = __uint_as_float((unsigned)(127 + e) << 23), isc = __uint_as_float((unsigned)(127 - e) << 23);
+        _Float16 *o = planes + (r0 + rr) * 2 * K;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = lane + 64 * u;
+            if (c < K) {
+                const float t = a[u] * sc;                 // exact
+                const _Float16 ta = (_Float16)t;
+                o[c] = ta;
+                o[K + c] = (_Float16)(t - (float)ta);
+            }
+        }
+        if (lane == 0) inv_scale[r0 + rr] = isc;
     }
 }
 
@@ -533,7 +588,7 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
     if (split) {
         float *isc = (float *)aux;
         _Float16 *pl = (_Float16 *)((char *)aux + xx_bytes);
-        hipLaunchKernelGGL(split2_kernel, dim3((unsigned)cdiv64(npts, 4)), dim3(256), 0, st, x, npts, C, pl, xx, isc);
+        hipLaunchKernelGGL(split2_kernel, dim3((unsigned)cdiv64(npts, 64)), dim3(256), 0, st, x, npts, C, pl, xx, isc);
         if (C == 144) hipLaunchKernelGGL(knn_f16x3_kernel<144>, grid, dim3(256), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, n, k, idx, ctab);
         else hipLaunchKernelGGL(knn_f16x3_kernel<192>, grid, dim3(256), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, n, k, idx, ctab);
         LAUNCH_CHECK();
