@@ -40,31 +40,50 @@ def parse():
 
 
 def measure_dominant_kernel(enc, xyz_dev):
-    """Live HIP-event timing of the dominant kernel (gemm_bf16x3_kernel, all epilogue variants) over one frame, on the stream
-    it is launched on (torch's current stream, which is where the C ABI launches it)."""
+    """Live HIP-event timing over one frame, on the stream the kernels are launched on (torch's current stream, which is where
+    the C ABI launches them): the dominant kernel (gemm_split_kernel, all tile / epilogue variants) and, for the secondary
+    roofline entries, the window attention and the feature-space kNN searches.  ALGORITHMIC flops only."""
     from scp_amd import native
-    recs = []
-    orig = native.linear_bf16x3
+    recs = {"gemm": [], "attn": [], "knn": []}
 
-    def timed(x, sw, bias=None, act=0, residual=None, out=None):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        y = orig(x, sw, bias, act, residual, out)
-        e.record()
-        M = x.numel() // x.shape[-1]
-        recs.append((s, e, 2.0 * M * sw.N * sw.K))
+    def ev():
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    o_lin, o_att, o_knn = native.linear_split, native.swin_attention_packed, native.knn_topk_packed
+
+    def lin(a, sw, *args, **kw):
+        s, e = ev(); s.record(); y = o_lin(a, sw, *args, **kw); e.record()
+        recs["gemm"].append((s, e, 2.0 * a.M * sw.N * sw.K))
         return y
 
-    native.linear_bf16x3 = timed
+    def att(q, *args, **kw):
+        s, e = ev(); s.record(); y = o_att(q, *args, **kw); e.record()
+        recs["attn"].append((s, e, q.shape[0] * 2.0 * 2.0 * 512 * 256))      # per row: QK^T and PV over 512 keys x 256 channels
+        return y
+
+    def knn(x, ktab):
+        s, e = ev(); s.record(); y = o_knn(x, ktab); e.record()
+        n = ktab[:, 1].double()
+        recs["knn"].append((s, e, float((n * 512).sum().item()) * 2.0 * max(4, x.shape[1]), x.shape[1]))   # sum over 512-row chunks of n * 512 pairs
+        return y
+
+    native.linear_split, native.swin_attention_packed, native.knn_topk_packed = lin, att, knn
     try:
         enc.encode(xyz_dev)
         torch.cuda.synchronize()
     finally:
-        native.linear_bf16x3 = orig
-    ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-    flops = sum(f for _, _, f in recs)
-    return dict(launches=len(recs), avg_launch_us=1e3 * ms / max(1, len(recs)), flops_per_launch=flops / max(1, len(recs)),
-                tflops=flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, total_ms=ms)
+        native.linear_split, native.swin_attention_packed, native.knn_topk_packed = o_lin, o_att, o_knn
+
+    def summ(rs):
+        ms = sum(r[0].elapsed_time(r[1]) for r in rs)
+        fl = sum(r[2] for r in rs)
+        return dict(launches=len(rs), avg_launch_us=1e3 * ms / max(1, len(rs)), flops_per_launch=fl / max(1, len(rs)),
+                    tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, total_ms=ms)
+    out = summ(recs["gemm"])
+    out["attn"] = summ(recs["attn"])
+    out["knn_feat"] = summ([r for r in recs["knn"] if r[3] > 4])
+    out["knn_pos"] = summ([r for r in recs["knn"] if r[3] <= 4])
+    return out
 
 
 def cpu_baseline(level, n_nodes_frame, xyz):
@@ -168,15 +187,15 @@ def main():
         bytes_C = n_nodes * (255 * 4 + 4)
         traffic = None
         try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (collected separately, see the file's note)
-            with open(os.path.join(ROOT, "profiles", "r1c_pmc_traffic.json")) as f:
-                traffic = json.load(f)["gemm_bf16x3_all_variants"]["hbm_bytes_per_launch"]
+            with open(os.path.join(ROOT, "profiles", "r1j_pmc_traffic.json")) as f:
+                traffic = json.load(f)["gemm_split_all_variants"]["hbm_bytes_per_launch"]
         except Exception:
             pass
         out = {
             "metric": "KITTI frames/sec encode (SCP-EHEM, level 16) + bpp match vs ref",
             "value": world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (dense layers as bf16x3 split on bf16 MFMA with fp32 accumulate; kNN / attention / CDF in fp32)", "data": "synthetic",
+            "dtype": "f32 (dense layers and attention as bf16x3 split on bf16 MFMA, feature kNN as f16x3 split on f16 MFMA, fp32 accumulate; position kNN / CDF in fp32)", "data": "synthetic",
             "config": {"workload": f"SCP-EHEM KITTI-like synthetic 120k-pt frames, --spher --mullevel lidar_level={args.level} "
                                    "(BASELINE.json configs[2]), seeded random weights", "nodes_per_frame": int(n_nodes),
                        "windows_per_frame": len(__import__("scp_amd.encoder", fromlist=["EncodePlan"]).EncodePlan(
@@ -186,12 +205,24 @@ def main():
             "stage_ms": {k: round(1e3 * v, 3) for k, v in st.items()},
             # dominant kernel: the bf16x3 dense layer.  `achieved` counts ALGORITHMIC flops (2*M*N*K of the fp32 product it
             # replaces); the kernel spends three bf16 MFMAs per product, so its own ceiling is a third of the dense bf16 peak.
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16x3_kernel (dense layers: 3x v_mfma_f32_32x32x16_bf16 per fp32-class product)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_split_kernel (dense layers, both operands pre-split: 3x v_mfma_f32_32x32x16_bf16 per fp32-class product)",
                          "achieved": dom["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
                          "frac": dom["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 3.0), "traffic": traffic,
                          "peak_note": "2500 TFLOP/s dense bf16 MFMA / 3 products; the fp32 MFMA peak this replaces is 157.3",
                          "launches_per_frame": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
                          "flops_per_launch": dom["flops_per_launch"]},
+            # secondary kernels, same convention (algorithmic flops of the fp32 product / measured time; ceiling = dense 16-bit MFMA
+            # peak / 3 products); the position search (3 features) is selection-bound, its MFMA share is negligible
+            "roofline_kernels": {
+                "swin_attn_bf16x3_kernel": {"bound": "mfma", "achieved": dom["attn"]["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
+                                            "frac": dom["attn"]["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 3.0), "launches_per_frame": dom["attn"]["launches"],
+                                            "avg_launch_us": dom["attn"]["avg_launch_us"]},
+                "knn_f16x3_kernel": {"bound": "mfma", "achieved": dom["knn_feat"]["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
+                                     "frac": dom["knn_feat"]["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 3.0), "launches_per_frame": dom["knn_feat"]["launches"],
+                                     "avg_launch_us": dom["knn_feat"]["avg_launch_us"],
+                                     "note": "fused distance + top-20 selection; the selection (VALU) is about half of the time"},
+                "knn_mfma_kernel<2,16> (positions)": {"bound": "valu", "launches_per_frame": dom["knn_pos"]["launches"],
+                                                      "avg_launch_us": dom["knn_pos"]["avg_launch_us"]}},
             "roofline_stages": {
                 "G": {"bound": "hbm", "achieved": bytes_G / st["geom"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": bytes_G / st["geom"] / 1e9 / HBM_PEAK_GBS, "bytes": bytes_G,

@@ -239,26 +239,38 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bf16x3_kernel(const float *_
     for (int kt = 0; kt < WIN / KT; ++kt) {
         __syncthreads();
         // stage 64 keys: K as [key][d] planes, V transposed as [d][pi(key)] planes; pi swaps bits 2 and 3 of the key index
+        {
+            const int c4 = tid & 15, kg = tid >> 4;
+            // K: rows kg + 16 it, head dims 4 c4 .. 4 c4 + 3: one 8-byte store per plane
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int e = tid + it * 256;
-            const int r = e >> 4, c4 = e & 15;
-            const int ktok = (wnd * WIN + kt * KT + r + shift) % Lp;
-            const size_t g = kbase + (size_t)ktok * ldkv + 4 * c4;
-            const float4 kv = *(const float4 *)(k + g);
-            const float4 vv = *(const float4 *)(v + g);
-            const float kf[4] = {kv.x, kv.y, kv.z, kv.w}, vf[4] = {vv.x, vv.y, vv.z, vv.w};
-            bf16x4 khi, klo;
+            for (int it = 0; it < 4; ++it) {
+                const int r = kg + 16 * it;
+                const int ktok = (wnd * WIN + kt * KT + r + shift) % Lp;
+                const float4 kv = *(const float4 *)(k + kbase + (size_t)ktok * ldkv + 4 * c4);
+                const float kf[4] = {kv.x, kv.y, kv.z, kv.w};
+                bf16x4 khi, klo;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const __bf16 hh = (__bf16)kf[u]; khi[u] = hh; klo[u] = (__bf16)(kf[u] - (float)hh); }
-            *(bf16x4 *)(Kh + r * LDB + 4 * c4) = khi;
-            *(bf16x4 *)(Kl + r * LDB + 4 * c4) = klo;
-            const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+                for (int u = 0; u < 4; ++u) { const __bf16 hh = (__bf16)kf[u]; khi[u] = hh; klo[u] = (__bf16)(kf[u] - (float)hh); }
+                *(bf16x4 *)(Kh + r * LDB + 4 * c4) = khi;
+                *(bf16x4 *)(Kl + r * LDB + 4 * c4) = klo;
+            }
+            // V: a 4-key x 4-dim block per thread (keys 4 kg .. 4 kg + 3: pi keeps them adjacent), transposed in registers:
+            // 8-byte stores of 4 consecutive permuted keys per head dim instead of sixteen 2-byte ones
+            float vf[4][4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ktok = (wnd * WIN + kt * KT + 4 * kg + kk + shift) % Lp;
+                const float4 vv = *(const float4 *)(v + kbase + (size_t)ktok * ldkv + 4 * c4);
+                vf[kk][0] = vv.x; vf[kk][1] = vv.y; vf[kk][2] = vv.z; vf[kk][3] = vv.w;
+            }
+            const int pr = 4 * ((kg & ~3) | ((kg & 1) << 1) | ((kg >> 1) & 1));
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const __bf16 hh = (__bf16)vf[u];
-                Vh[(4 * c4 + u) * LDB + pr] = hh;
-                Vl[(4 * c4 + u) * LDB + pr] = (__bf16)(vf[u] - (float)hh);
+                bf16x4 vhi, vlo;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { const __bf16 hh = (__bf16)vf[kk][u]; vhi[kk] = hh; vlo[kk] = (__bf16)(vf[kk][u] - (float)hh); }
+                *(bf16x4 *)(Vh + (4 * c4 + u) * LDB + pr) = vhi;
+                *(bf16x4 *)(Vl + (4 * c4 + u) * LDB + pr) = vlo;
             }
         }
         __syncthreads();
@@ -294,8 +306,10 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bf16x3_kernel(const float *_
             ps += __shfl_xor(ps, 32);
             l_run = l_run * alpha + ps;
             m_run = m_new;
+            if (__any(alpha != 1.f)) {   // the running maximum moved for some query of this wavefront (rare after the first tiles)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            }
             // O^T += V^T . P^T; chunk c consumes accumulator registers 8c..8c+7 = keys 16c + {0..3, 8..11} + 4h = LDS columns 16c + 8h + j
 #pragma unroll
             for (int c = 0; c < 2; ++c) {

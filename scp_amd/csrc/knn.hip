@@ -185,12 +185,13 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
     // table says which sequence (first row, real length) the 128 query rows of this workgroup belong to; indices come out GLOBAL
     // and always TK per row (rows of sequences shorter than TK repeat their nearest neighbour, harmless under the max-pool).
     size_t row0 = (size_t)blockIdx.y * n;
-    int q0 = blockIdx.x * 128;
+    const int bx = blockIdx.x;   // (an XCD-contiguous order was tried: the uneven window lengths cost more in balance than L2 locality gains)
+    int q0 = bx * 128;
     if (ctab) {
-        const int ch = (blockIdx.x * 128) >> 9;
+        const int ch = (bx * 128) >> 9;
         row0 = (size_t)ctab[2 * ch];
         n = ctab[2 * ch + 1];
-        q0 = blockIdx.x * 128 - (int)row0;
+        q0 = bx * 128 - (int)row0;
         if (q0 >= n) return;   // workgroup entirely inside the padding of its sequence
     }
     const float *xb = x + row0 * K;
@@ -327,12 +328,13 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     size_t row0 = (size_t)blockIdx.y * n;
-    int q0 = blockIdx.x * 128;
+    const int bx = blockIdx.x;   // (an XCD-contiguous order was tried: the uneven window lengths cost more in balance than L2 locality gains)
+    int q0 = bx * 128;
     if (ctab) {
-        const int ch = (blockIdx.x * 128) >> 9;
+        const int ch = (bx * 128) >> 9;
         row0 = (size_t)ctab[2 * ch];
         n = ctab[2 * ch + 1];
-        q0 = blockIdx.x * 128 - (int)row0;
+        q0 = bx * 128 - (int)row0;
         if (q0 >= n) return;
     }
     const char *pb = (const char *)planes + row0 * RB;
