@@ -260,6 +260,13 @@ SCP_API scp_legacy_node *Nodes_get(void *level, int i);
 SCP_API int int_size(void *codes);
 SCP_API int int_get(void *codes, int i);
 
+/* ---- distortion metrics of the quantiser -------------------------------------------------------------
+ * d2[i] = min_j |a_i - b_j|^2 in float64 (device pointers, row-major [n][3]).  Replaces the KD-tree nearest-neighbour queries
+ * of data_preproc/pt.py:88-95 (distChamfer) and of the MPEG pc_error tool behind the D1 PSNR (pt.py:13-85,
+ * utils/__init__.py:3-15); the host side (scp_amd/metrics.py) forms chamfer = max(mean sqrt d2_ab, mean sqrt d2_ba) and
+ * PSNR = 10 log10(3 peak^2 / max(mean d2_ab, mean d2_ba)). */
+SCP_API int scp_nn_sqdist_f64(const double *a, int64_t na, const double *b, int64_t nb, double *d2, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

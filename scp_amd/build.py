@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libscp_hip.so")
 SOURCES = ["api.cpp", "geom.hip", "sort_u64.hip", "cdf.hip", "rangecoder.cpp", "legacy_octree.cpp",
-           "knn.hip", "edge.hip", "attn.hip", "octattn.hip", "gemm.hip", "gemm_split.hip", "fused.hip"]
+           "knn.hip", "edge.hip", "attn.hip", "octattn.hip", "gemm.hip", "gemm_split.hip", "fused.hip", "metrics.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fvisibility=hidden", "-x", "hip"]
@@ -16,7 +16,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # bit-exact kernels: numpy / torch evaluate a*a + b*b as two roundings, so FMA contraction must be off there
 # (HIP's __fmul_rn / __fadd_rn are plain operators and do NOT stop the contraction).
 EXTRA = {"geom.hip": ["-ffp-contract=off"], "knn.hip": ["-ffp-contract=off"], "cdf.hip": ["-ffp-contract=off"],
-         "edge.hip": ["-ffp-contract=off"]}
+         "edge.hip": ["-ffp-contract=off"], "metrics.hip": ["-ffp-contract=off"]}
 
 
 def _stale(target, deps):

@@ -7,8 +7,8 @@ same stdout block per frame, same summary file.  Differences, all additive:
   * the hydra run directory is read with a plain YAML loader; `--random_weights SEED` replaces the checkpoint for
     smoke runs (no trained checkpoint can be fetched offline);
   * `--test_files` accepts a glob, a directory or a list (the reference's `glob.glob(list)` cannot work, SURVEY B-3).
-PSNR / chamfer are side inputs (`--metrics_from <dir>` with the reference's `_meta.npy`) - distortion of the quantiser is
-not part of the codec path.
+  * `--metrics`: chamfer distance and D1 PSNR of every frame, computed on the device (scp_amd/metrics.py; the reference
+    shells out to pc_error and a CPU KD-tree for these) - they enter the per-frame block and the all-reduced summary.
 """
 import argparse
 import glob
@@ -70,6 +70,7 @@ def get_args(argv=None, mullevel=False):
     p.add_argument("--model", type=str, default=None, choices=[None, "EHEM", "OctAttention"])
     p.add_argument("--random_weights", type=int, default=None)
     p.add_argument("--out_dir", type=str, default=None)
+    p.add_argument("--metrics", action="store_true", help="chamfer distance + D1 PSNR per frame (computed on the device)")
     return p.parse_args(argv)
 
 
@@ -150,7 +151,13 @@ def main(argv=None, mullevel=False):
         print("total binsize               :", res["bits"])
         print("bit per oct                 :", res["bits"] / res["n_nodes"])
         print("bit per pixel               :", res["bpp"])
-        sums = [sums[0] + res["bpp"], sums[1], sums[2], sums[3] + elapsed, sums[4] + 1]
+        dist = None
+        if args.metrics and name != "OctAttention" and not args.preproc_path:
+            dist = enc.distortion(torch.from_numpy(np.ascontiguousarray(xyz[:, :3], np.float32)).to(dev))
+            print("chamfer distance            :", dist["chamfer"])
+            print("PSNR (D1)                   :", dist["psnr"])
+        sums = [sums[0] + res["bpp"], sums[1] + (dist["psnr"] if dist else 0.0), sums[2] + (dist["chamfer"] if dist else 0.0),
+                sums[3] + elapsed, sums[4] + 1]
     total = D.reduce_summary(sums, dev)
     m = D.summary_means(total)
     if rank == 0:

@@ -103,7 +103,19 @@ class FrameEncoder:
                                        0.0 if self.mullevel else self.cart_offset)
             qs.append(q)
             infos.append(qi)
+        self._infos = infos
         return qs, infos[0].bin_num, (infos[0].offset[2] if self.cylin else 0.0)
+
+    def distortion(self, xyz_dev, infos=None):
+        """Chamfer distance and D1 PSNR of the frame just encoded (the octree of the last `encode` / `preprocess` call) against
+        its input cloud, on the device - what the reference gets from distChamfer + the pc_error tool
+        (encode_dataset_ehem.py:170-171, encode_dataset_ehem_mullevel.py:141-144; scp_amd/metrics.py)."""
+        from . import metrics
+        pts = []
+        for s, info in enumerate(infos or self._infos):   # infos: per shell, anything with .qs[3] and .offset[3] (tests: the oracle's)
+            pts.append(metrics.dequantize(self.geom.leaves(s), info.qs, info.offset, spher=self.spher, cylin=self.cylin,
+                                          f32=not self.mullevel).double())
+        return metrics.chamfer_psnr(xyz_dev, torch.cat(pts), metrics.PEAK.get(self.data_type, 1.0))
 
     def preprocess(self, xyz_dev):
         qs, bin_num, z_off = self.quantize(xyz_dev)

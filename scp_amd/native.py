@@ -72,6 +72,7 @@ def lib():
         "scp_swin_attention_packed_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, i64, _vp]),
         "scp_set_attention_mode": (C.c_int, [i32]),
         "scp_set_knn_mode": (C.c_int, [i32]),
+        "scp_nn_sqdist_f64": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp]),
         "scp_edge_gather_max": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_swin_attention": (C.c_int, [_vp, _vp, _vp, _vp, i32, i32, i32, i32, i32, _vp, _vp]),
         "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
@@ -268,6 +269,21 @@ def swin_attention_packed(q, k, v, bias_table, wtab, shift, split=False):
                                          _dev(wtab, torch.int32), T // 512, shift, q.stride(0), k.stride(0), _dev(out), _stream())
     _check(rc, "scp_swin_attention_packed")
     return out
+
+
+def nn_sqdist(a, b):
+    """a [na,3], b [nb,3] float64 device tensors -> float64 [na]: squared distance of every a to its nearest b (exhaustive)."""
+    a = _dev_f64(a)
+    b = _dev_f64(b)
+    out = torch.empty((a.shape[0],), dtype=torch.float64, device=a.device)
+    _check(lib().scp_nn_sqdist_f64(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(), _stream()), "scp_nn_sqdist_f64")
+    return out
+
+
+def _dev_f64(t):
+    if not t.is_cuda:
+        raise ScpError("device tensor required (there is no CPU path in the product)")
+    return t.to(torch.float64).contiguous()
 
 
 def set_knn_mode(f16x3):

@@ -651,7 +651,55 @@ def gen_keys():
         json.dump(out, f)
 
 
-GROUPS = {"keys": gen_keys, "xform": gen_xform, "oct": gen_oct, "ctx": gen_ctx, "logits": gen_logits, "swin": gen_swin,
+# ----------------------------------------------------------------------------- metrics
+def gen_metrics():
+    """Chamfer distance through the reference's `distChamfer` (data_preproc/pt.py:88-95) and D1 PSNR through the reference's
+    `pcerror` + `get_psnr` (pt.py:13-85, utils/__init__.py:3-15), which shell out to the MPEG `pc_error` binary shipped under
+    /root/reference/utils (no exec bit on this mount: a temporary copy is made executable).  Inputs are re-derivable from seeds
+    (synthetic frames + the reference quantiser), so the fixture holds the de-quantised clouds' hashes and the numbers only."""
+    import shutil
+    import stat
+    from data_preproc import pt as RPT
+    from utils import get_psnr
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "pc_error")
+        shutil.copy("/root/reference/utils/pc_error", exe)
+        os.chmod(exe, os.stat(exe).st_mode | stat.S_IXUSR)
+        os.makedirs(os.path.join(tmp, "temp", "data"), exist_ok=True)
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            def measure(pc, q, peak):
+                res = os.path.join(tmp, "temp", "r.txt")
+                RPT.pcerror(pc.copy(), q.copy(), None, "-r " + peak, res, pcerror_path=exe)
+                psnr = get_psnr(res)[0]
+                return float(RPT.distChamfer(pc.copy(), q.copy())), float(psnr)
+            rng = np.random.default_rng(0)
+            a = (rng.random((2000, 3)) * 50).astype(np.float32)
+            b = np.round(a[::2].astype(np.float64) / 0.37) * 0.37
+            ch, ps = measure(a, b, "59.70")
+            out["random_2000_vs_1000"] = dict(chamfer=ch, psnr=ps, peak=59.70)
+            for name, seed, L, mode in (("spher_L12_s0", 0, 12, "spher"), ("cart_L10_s1", 1, 10, "cart"), ("cylin_L12_s2", 2, 12, "cylin")):
+                xyz = frame5k(seed) if mode == "cart" else synth_frame(seed)
+                binf = os.path.join(tmp, "seq", name + ".bin")
+                os.makedirs(os.path.dirname(binf), exist_ok=True)
+                write_kitti_bin(binf, xyz)
+                res = RDP.proc_pc(binf, os.path.join(tmp, "pp"), name, qs=400 / (2 ** L - 1), test=True, spher=(mode == "spher"),
+                                  cylin=(mode == "cylin"), **({} if mode != "cart" else {"offset": -200}))
+                q, pc = res[1], res[2]
+                ch, ps = measure(pc, q, "59.70")
+                out[name] = dict(chamfer=ch, psnr=ps, peak=59.70, seed=seed, level=L, mode=mode, n_pc=int(pc.shape[0]), n_quant=int(q.shape[0]),
+                                 sub=(mode == "cart"))
+                print("  ", name, out[name])
+        finally:
+            os.chdir(cwd)
+    with open(os.path.join(HERE, "metrics.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("  wrote metrics.json")
+
+
+GROUPS = {"metrics": gen_metrics, "keys": gen_keys, "xform": gen_xform, "oct": gen_oct, "ctx": gen_ctx, "logits": gen_logits, "swin": gen_swin,
           "cdf": gen_cdf, "ac": gen_ac, "e2e": gen_e2e, "facts": gen_facts}
 
 if __name__ == "__main__":

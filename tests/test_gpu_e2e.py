@@ -233,3 +233,68 @@ def test_preproc_path_files_and_flow(enc_parts, orc, tmp_path, mullevel):
     assert a["bytes"] == b["bytes"] and a["level_sizes"] == b["level_sizes"]
     assert np.array_equal(a["pos_mm"], b["pos_mm"])
     assert os.path.exists(pp + "_quant.ply") and os.path.exists(pp + sfx[0] + "_loc.npy")   # data_preprocess.py:78,153
+
+
+# ----------------------------------------------------------------------------------------------- 8f-3: distortion metrics on the device
+@pytest.mark.gpu
+def test_nn_sqdist_is_exhaustive_float64():
+    from scipy.spatial import cKDTree
+    from scp_amd import native
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    for na, nb in ((1, 1), (7, 3000), (5000, 1), (2500, 4097), (30000, 20000)):
+        a, b = rng.random((na, 3)) * 10, rng.random((nb, 3)) * 10
+        b[0] = a[0]                                   # an exact hit
+        got = native.nn_sqdist(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
+        want, _ = cKDTree(b).query(a)
+        assert got[0] == 0.0 and np.array_equal(np.sqrt(got), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["spher_L12_s0", "cart_L10_s1", "cylin_L12_s2"])
+def test_device_chamfer_psnr_vs_reference_tools(orc, name):
+    """FrameEncoder.distortion (device NN search) against the numbers the reference's distChamfer / pc_error produced
+    (tests/golden/metrics.json) and against the CPU oracle on the same frame."""
+    import json
+    from cfgs import ehem_cfg
+    from scp_amd.encoder import FrameEncoder
+    from scp_amd.models import EHEM
+    from scp_amd.synth import synth_frame
+    e = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "metrics.json")))[name]
+    dev = torch.device("cuda:0")
+    xyz = synth_frame(e["seed"])[::24].copy() if e["sub"] else synth_frame(e["seed"])
+    enc = FrameEncoder(EHEM(ehem_cfg()).to(dev), "kitti", e["level"], spher=e["mode"] == "spher", cylin=e["mode"] == "cylin", device=dev)
+    x = torch.from_numpy(xyz).to(dev)
+    # strict comparison: the oracle's quantised integers (on synthetic rings a whole beam can sit on a rounding boundary of
+    # theta / qs, where numpy's float32 SIMD acos and the device's correctly rounded one disagree - DESIGN.md, float -> int boundary)
+    from types import SimpleNamespace
+    r = orc.proc_pc(xyz, 400 / (2 ** e["level"] - 1), e["mode"])
+    qsv = np.broadcast_to(np.asarray(r["qsv"], np.float64).reshape(-1), (3,))
+    off = np.broadcast_to(np.asarray(r["offset"], np.float64).reshape(-1), (3,))
+    enc.preprocess_ints([torch.from_numpy(r["pts"].astype(np.int32)).to(dev)], r["bin_num"], r["z_offset"], xyz.shape[0])
+    d = enc.distortion(x, infos=[SimpleNamespace(qs=qsv, offset=off)])
+    assert abs(d["chamfer"] - e["chamfer"]) < 2e-5 * e["chamfer"] and abs(d["psnr"] - e["psnr"]) < 3e-3, (d, e)
+    ch, ps = orc.chamfer_psnr(xyz, r["quant_pc"], e["peak"])
+    assert abs(d["chamfer"] - ch) < 2e-5 * ch and abs(d["psnr"] - ps) < 1e-3
+    # and end to end on the device's own quantiser: the same metric up to the boundary points
+    enc.preprocess(x)
+    d2 = enc.distortion(x)
+    assert abs(d2["chamfer"] - ch) < 0.02 * ch and abs(d2["psnr"] - ps) < 0.2
+
+
+@pytest.mark.gpu
+def test_device_metrics_mullevel_vs_oracle(orc):
+    from cfgs import ehem_cfg
+    from scp_amd.encoder import FrameEncoder
+    from scp_amd.models import EHEM
+    from scp_amd.synth import synth_frame
+    dev = torch.device("cuda:0")
+    xyz = synth_frame(3)[::6].copy()
+    enc = FrameEncoder(EHEM(ehem_cfg()).to(dev), "kitti", 14, spher=True, mullevel=True, device=dev)
+    x = torch.from_numpy(xyz).to(dev)
+    enc.preprocess(x)
+    d = enc.distortion(x)
+    shells = orc.mullevel_shells(xyz, 14, "spher")
+    q = np.vstack([s["quant_pc"] for s in shells])
+    ch, ps = orc.chamfer_psnr(xyz, q, 59.70)
+    assert abs(d["chamfer"] - ch) < 0.02 * ch and abs(d["psnr"] - ps) < 0.2, (d, ch, ps)

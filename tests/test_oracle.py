@@ -168,3 +168,24 @@ def test_coding_plan(orc):
     _, os_ = orc.ehem_coding_plan([1, 4, 1, 3], 8192, mullevel=False)
     assert os_.tolist() == [0, 1, 3, 2, 4, 0, 6, 8, 7]   # encode.py:122 quirk: no coded_cnt
     assert orc.ehem_outfile("a/b", 10, 820.0, 0, True, False) == "a/b_spher_10_820_0.bin"
+
+
+def test_chamfer_psnr_matches_reference_tools(orc):
+    """oracle.chamfer_psnr against the reference's distChamfer and the pc_error binary (tests/golden/metrics.json)."""
+    import json
+    from scp_amd.synth import synth_frame
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "metrics.json")))
+    rng = np.random.default_rng(0)
+    a = (rng.random((2000, 3)) * 50).astype(np.float32)
+    b = np.round(a[::2].astype(np.float64) / 0.37) * 0.37
+    ch, ps = orc.chamfer_psnr(a, b, 59.70)
+    assert abs(ch - g["random_2000_vs_1000"]["chamfer"]) < 1e-12 and abs(ps - g["random_2000_vs_1000"]["psnr"]) < 2e-3
+    for name in ("spher_L12_s0", "cart_L10_s1", "cylin_L12_s2"):
+        e = g[name]
+        xyz = synth_frame(e["seed"])[::24].copy() if e["sub"] else synth_frame(e["seed"])
+        r = orc.proc_pc(xyz, 400 / (2 ** e["level"] - 1), e["mode"])
+        assert r["quant_pc"].shape[0] == e["n_quant"]
+        ch, ps = orc.chamfer_psnr(xyz, r["quant_pc"], e["peak"])
+        # the de-quantised cloud goes through float32 sin/cos (numpy SIMD, ulp-level differences between builds) and pc_error
+        # reads its inputs from a 6-digit ascii ply: both far below these tolerances
+        assert abs(ch - e["chamfer"]) < 1e-6 * e["chamfer"] and abs(ps - e["psnr"]) < 2e-3, (name, ch, ps, e)
