@@ -137,7 +137,7 @@ def main(argv=None, mullevel=False):
             recs = [np.load(pp + sfx + ".npy") for sfx in (("_0_0", "_0_1", "_1") if mullevel else ("",))]
             res = enc.encode_records(recs, float(meta[0]), float(meta[2]) if len(meta) > 2 else 0.0, len(xyz))
         else:
-            res = enc.encode(xyz)
+            res = enc.encode(xyz, sequential=True) if (args.sequential and name == "OctAttention") else enc.encode(xyz)
         elapsed = time.time() - t0
         outfile = enc.outfile(out_root + stem, res)
         with open(outfile, "wb") as f:

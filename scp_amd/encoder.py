@@ -326,15 +326,33 @@ class OctAttnFrameEncoder:
         self.geom = native.Geom()
         self.cart_offset = -200.0 if data_type == KITTI else -float(2 ** 17)
 
-    def encode(self, xyz, timing=False):
+    def encode(self, xyz, timing=False, sequential=False):
         t0 = time.perf_counter()
         if isinstance(xyz, np.ndarray):
             xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
         xyz_dev = xyz.to(self.device)
         q, qi, _ = native.quantize(xyz_dev, self.mode, level_qs(self.data_type, self.lidar_level), self.cart_offset)
-        return self.encode_ints(q, qi.bin_num, xyz_dev.shape[0], t0)
+        return self.encode_ints(q, qi.bin_num, xyz_dev.shape[0], t0, sequential=sequential)
 
-    def encode_ints(self, q, bin_num, n_points, t0=None):
+    def _sequential_table(self, seq_ctx, seq_pos, N):
+        """`--sequential` (encode.py:38-41,55-56): a window starts at EVERY row of the padded sequence and only the prediction
+        of its last position is kept, i.e. node r is predicted from its full 1023-node history (window r .. r + 1023).
+        The reference's loop runs past the last full window with shrinking windows that all end at the last node and
+        overwrite its row; the last one (that node alone) wins - reproduced.  ~context_size x the model calls of the default
+        mode: batches of `max_batch` windows are gathered with a strided view, one forward each."""
+        cs = self.context_size
+        table = torch.empty((N, 255), dtype=torch.float32, device=self.device)
+        wc = seq_ctx.unfold(0, cs, 1).permute(0, 2, 1)               # [N, cs, 12] view: window i = rows i .. i + cs - 1
+        wp = seq_pos.unfold(0, cs, 1).permute(0, 3, 1, 2)            # [N, cs, 4, 3]
+        for b0 in range(0, N, self.max_batch):
+            b1 = min(N, b0 + self.max_batch)
+            out = self.model(wc[b0:b1].reshape(b1 - b0, cs, 4, 3), wp[b0:b1].contiguous())
+            table[b0:b1] = out[:, -1]
+        if cs > 1:
+            table[N - 1] = self.model(seq_ctx[-1:].reshape(1, 1, 4, 3), seq_pos[-1:].reshape(1, 1, 4, 3))[0, -1]
+        return table
+
+    def encode_ints(self, q, bin_num, n_points, t0=None, sequential=False):
         t0 = t0 or time.perf_counter()
         if isinstance(q, np.ndarray):
             q = torch.from_numpy(np.ascontiguousarray(q, np.int32))
@@ -349,6 +367,9 @@ class OctAttnFrameEncoder:
         total = N + cs - 1
         table = torch.empty((N, 255), dtype=torch.float32, device=self.device)
         n_full = total // cs
+        if sequential:
+            table = self._sequential_table(seq_ctx, seq_pos, N)
+            n_full = 0
         for b0 in range(0, n_full, self.max_batch):
             b1 = min(n_full, b0 + self.max_batch)
             d = seq_ctx[b0 * cs:b1 * cs].reshape(b1 - b0, cs, 4, 3)
@@ -357,7 +378,7 @@ class OctAttnFrameEncoder:
             lo = max(b0 * cs - (cs - 1), 0)                     # first real node covered by this batch
             skip = lo + (cs - 1) - b0 * cs                      # pad rows at the head of the first window
             table[lo:b1 * cs - (cs - 1)] = out[skip:]
-        if total % cs:
+        if total % cs and not sequential:
             d = seq_ctx[n_full * cs:].reshape(1, -1, 4, 3)
             p = seq_pos[n_full * cs:].reshape(1, -1, 4, 3)
             out = self.model(d, p)[0]

@@ -298,3 +298,41 @@ def test_device_metrics_mullevel_vs_oracle(orc):
     q = np.vstack([s["quant_pc"] for s in shells])
     ch, ps = orc.chamfer_psnr(xyz, q, 59.70)
     assert abs(d["chamfer"] - ch) < 0.02 * ch and abs(d["psnr"] - ps) < 0.2, (d, ch, ps)
+
+
+# ----------------------------------------------------------------------------------------------- 8f-4: --sequential (OctAttention)
+@pytest.mark.gpu
+def test_octattn_sequential_mode_vs_oracle(orc):
+    """encode.py:38-41,55-56: one window per node, only the last position's prediction kept (and the reference's overwrite of
+    the last node by the trailing short windows).  Small context so that the CPU oracle can afford the N model calls."""
+    from cfgs import octattn_cfg
+    from oracle import models_ref
+    from scp_amd.encoder import OctAttnFrameEncoder
+    from scp_amd.models import OctAttention
+    from scp_amd.synth import synth_frame
+    from scp_amd.weights import fill_weights
+    dev = torch.device("cuda:0")
+    cfg = octattn_cfg()
+    cfg["model"]["context_size"] = 32
+    model = fill_weights(OctAttention(cfg), 1).to(dev)
+    xyz = synth_frame(2)[::800].copy()
+    _, bin_num, _, _, pt = orc.quantise(xyz, 400 / (2 ** 12 - 1), "spher")
+    pt = np.unique(pt, axis=0)
+    enc = OctAttnFrameEncoder(model, "kitti", 12, spher=True, device=dev, max_batch=7)
+    res = enc.encode_ints(np.ascontiguousarray(pt, np.int32), bin_num, len(xyz), sequential=True)
+    N, cs = res["n_nodes"], 32
+    rec = orc.octree_build(pt.astype(np.int64)).krecords()
+    _, pos, data, _ = orc.octattn_context(rec, cs)
+    data, pos = torch.from_numpy(data), torch.from_numpy(pos)
+    assert data.shape[0] == N + cs - 1
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    want = torch.empty((N, 255))
+    with torch.no_grad():
+        for i in range(N + cs - 1):                                    # the reference's loop, verbatim
+            o = models_ref.octattn_forward(sd, data[None, i:i + cs].long(), pos[None, i:i + cs])
+            want[min(i, N - 1)] = o[0, -1]
+    got = res["_debug"]["table"].cpu()
+    assert (got - want).abs().max() < 1e-3, (got - want).abs().max()
+    # and the default mode differs from it (sanity: the flag does something)
+    res2 = enc.encode_ints(np.ascontiguousarray(pt, np.int32), bin_num, len(xyz))
+    assert (res2["_debug"]["table"].cpu() - want).abs().max() > 1e-2
