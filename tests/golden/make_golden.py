@@ -699,7 +699,29 @@ def gen_metrics():
     print("  wrote metrics.json")
 
 
-GROUPS = {"metrics": gen_metrics, "keys": gen_keys, "xform": gen_xform, "oct": gen_oct, "ctx": gen_ctx, "logits": gen_logits, "swin": gen_swin,
+# ----------------------------------------------------------------------------- training dataset
+def gen_trainset():
+    """dataloaders/ehem_dataset.py EHEMDataset on two synthetic record files, torch seed 7: the first 9 items."""
+    from dataloaders.ehem_dataset import EHEMDataset
+    from types import SimpleNamespace
+    rng = np.random.default_rng(3)
+    with tempfile.TemporaryDirectory() as tmp:
+        recs = {}
+        for name, n in (("a", 100), ("b", 57)):
+            r = rng.integers(1, 256, size=(n, 4, 6)).astype(np.int64)
+            r[:, :, 1] = rng.integers(1, 13, size=(n, 4))
+            r[:, :, 2] = rng.integers(1, 9, size=(n, 4))
+            r[:, :, 3:] = rng.integers(0, 4096, size=(n, 4, 3))
+            np.save(os.path.join(tmp, f"{name}_{n}.npy"), r)
+            recs[name] = r
+        ds = EHEMDataset(SimpleNamespace(root=os.path.join(tmp, "*.npy"), context_size=16, extra_pos=False))
+        torch.manual_seed(7)
+        items = [ds[i] for i in (0, 1, 2, 3, 4, 5, 6, 7, 8)]
+        save("trainset", rec_a=recs["a"], rec_b=recs["b"], length=np.int64(len(ds)),
+             data=np.stack([it[0] for it in items]), pos=np.stack([it[1] for it in items]), label=np.stack([it[2] for it in items]))
+
+
+GROUPS = {"trainset": gen_trainset, "metrics": gen_metrics, "keys": gen_keys, "xform": gen_xform, "oct": gen_oct, "ctx": gen_ctx, "logits": gen_logits, "swin": gen_swin,
           "cdf": gen_cdf, "ac": gen_ac, "e2e": gen_e2e, "facts": gen_facts}
 
 if __name__ == "__main__":

@@ -118,3 +118,21 @@ def test_product_refuses_cpu_tensors():
         m(torch.zeros((1, 4, 4, 3), dtype=torch.int64), torch.zeros((1, 3, 4)))
     with pytest.raises(native.ScpError):
         native.knn_topk(torch.zeros((1, 4, 3)), 2)
+
+
+def test_training_dataset_matches_reference(tmp_path):
+    """scp_amd.dataloaders.EHEMDataset reproduces the reference class item for item (fixture: tests/golden/trainset.npz,
+    produced by dataloaders/ehem_dataset.py with the same files, indices and torch seed)."""
+    from types import SimpleNamespace
+    from conftest import golden
+    from scp_amd.dataloaders import EHEMDataset
+    z = golden("trainset")
+    np.save(tmp_path / "a_100.npy", z["rec_a"])
+    np.save(tmp_path / "b_57.npy", z["rec_b"])
+    ds = EHEMDataset(SimpleNamespace(root=str(tmp_path / "*.npy"), context_size=16, extra_pos=False))
+    assert len(ds) == int(z["length"])
+    torch.manual_seed(7)
+    for k, i in enumerate((0, 1, 2, 3, 4, 5, 6, 7, 8)):
+        d, p, lab = ds[i]
+        assert np.array_equal(d, z["data"][k]) and np.array_equal(p, z["pos"][k]) and np.array_equal(lab, z["label"][k])
+        assert d.dtype == np.int64 and p.dtype == np.float32 and p.shape == (3, 16)
