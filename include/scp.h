@@ -147,6 +147,11 @@ SCP_API int scp_knn_topk_packed(const float *x, const int32_t *ctab, int32_t tot
  * f16 MFMA products, fp32 accumulate: distance values within ~1e-6 relative of the fp32 chain), 0 = exact fp32 MFMA chain
  * (bit-identical distance values to PyTorch-CPU).  The 3-feature position search is always exact. */
 SCP_API int scp_set_knn_mode(int32_t f16x3);
+/* scp_knn_topk_packed with an a-priori pruning bound per row: thr0[row] = a value of (2 x.y - |x|^2 - |y|^2) that at least 20
+ * candidates of the row's sequence are known to reach (e.g. the 20th best over last layer's neighbours); same result, fewer
+ * list insertions.  thr0 may be NULL. */
+SCP_API int scp_knn_topk_packed_bounded(const float *x, const int32_t *ctab, int32_t total_rows, int32_t C, const float *thr0,
+                                int32_t *idx, void *stream);
 
 /* edge-conv tail: out[b][i][c] = lrelu_0.2( scale[c] * (sel_j u[b][idx[b][i][j]][c] + v[b][i][c]) + shift[c] ),
  * sel = max when scale[c] >= 0 else min  (== max over j of BN(conv(edge feature)), dgcnn.py:62-71,132-134) */

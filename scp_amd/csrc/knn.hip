@@ -107,8 +107,10 @@ __device__ __forceinline__ void topk_insert_seg(float (&v)[TK], int (&id)[TK], f
 
 template <bool SCALED>
 __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, const float *sis, float usc, float xxi, int c0, int n, int h,
-                                           float (&v)[TK], int (&id)[TK]) {
-    const float thr = fmaxf(v[TK - 1], __shfl_xor(v[TK - 1], 32));   // both lanes of a query prune with the tighter bound
+                                           float (&v)[TK], int (&id)[TK], float thr0) {
+    // both lanes of a query prune with the tighter of their bounds, and with the caller's a-priori bound thr0 (a distance that at
+    // least 20 candidates are known to beat: nothing below it can be among the 20 best; -inf when there is none)
+    const float thr = fmaxf(fmaxf(v[TK - 1], __shfl_xor(v[TK - 1], 32)), thr0);
     const bool full = c0 + 32 <= n;                                   // wave-uniform: every candidate of the tile exists
     unsigned pend = 0, eqm = 0;
     unsigned long long anyeq = 0;
@@ -165,7 +167,8 @@ __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, 
 // 2 * step + h, the k order of the chain is untouched.
 template <int KS, int NSUB>   // MFMA k-steps = C / 2; 32 * NSUB candidates per LDS stage
 __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ xx, int n, int C, int k,
-                                                         int *__restrict__ idx, const int *__restrict__ ctab /* packed mode: per 512-row chunk (seq base row, seq n) */) {
+                                                         int *__restrict__ idx, const int *__restrict__ ctab /* packed mode: per 512-row chunk (seq base row, seq n) */,
+                                                         const float *__restrict__ thr0) {
     constexpr int K = 2 * KS;                       // feature count (multiple of 4) = row length in floats, rows are 16-byte aligned
     constexpr int R = K / 4;                        // 16-byte chunks per row
     constexpr int SC = 32 * NSUB;                   // candidates per stage
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
         for (int s = 0; s < KS; ++s) qf[s] = xb[(size_t)qc * K + 2 * s + h];
     }
     const float xxi = (qi < n) ? xxb[qi] : 0.f;
+    const float thr0v = (thr0 && qi < n) ? thr0[row0 + qi] : -INFINITY;
 
     float v[TK];
     int id[TK];
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a[1] : a[0], qf[2 * g], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a[3] : a[2], qf[2 * g + 1], acc, 0, 0, 0);
             }
-            knn_select<false>(acc, sxx + sub * 32, nullptr, 1.f, xxi, cur * SC + sub * 32, n, h, v, id);
+            knn_select<false>(acc, sxx + sub * 32, nullptr, 1.f, xxi, cur * SC + sub * 32, n, h, v, id, thr0v);
         }
         cur = nxt;
     }
@@ -311,7 +315,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <int K>
 __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__restrict__ planes, const float *__restrict__ xx,
                                                           const float *__restrict__ inv_scale, int n, int k, int *__restrict__ idx,
-                                                          const int *__restrict__ ctab) {
+                                                          const int *__restrict__ ctab, const float *__restrict__ thr0) {
     constexpr int RB = 4 * K;                       // bytes per row
     constexpr int R = RB / 16;                      // chunks per row (48 / 36)
     constexpr int NC = K / 16;                      // k-chunks of 16 features
@@ -354,6 +358,7 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
         }
     }
     const float xxi = (qi < n) ? xxb[qi] : 0.f;
+    const float thr0v = (thr0 && qi < n) ? thr0[row0 + qi] : -INFINITY;
     const float isq = isb[qc];                      // 1 / scale of the query row (a power of two)
 
     float v[TK];
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
         }
         // un-scaling (acc / s_query / s_candidate, powers of two: exact) happens inside the selection
         const float *sxx = txx + buf * 64;
-        knn_select<true>(acc, sxx, sxx + 32, isq, xxi, cur * 32, n, h, v, id);
+        knn_select<true>(acc, sxx, sxx + 32, isq, xxi, cur * 32, n, h, v, id, thr0v);
         cur = nxt;
     }
     __syncthreads();
@@ -579,7 +584,8 @@ static int knn_mode() {   // 1 = f16x3 (default), 0 = exact fp32 MFMA (SCP_KNN=f
 }
 extern "C" SCP_API int scp_set_knn_mode(int32_t f16x3) { g_knn_mode = f16x3 ? 1 : 0; return SCP_OK; }
 
-static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int k, int *idx, const int *ctab, hipStream_t st) {
+static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int k, int *idx, const int *ctab, hipStream_t st,
+                      const float *thr0 = nullptr) {
     const size_t xx_bytes = ((size_t)npts * sizeof(float) + 1023) & ~(size_t)1023;
     const bool split = (C == 144 || C == 192) && knn_mode() == 1;
     const int RB = C * 4;
@@ -591,17 +597,17 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
         float *isc = (float *)aux;
         _Float16 *pl = (_Float16 *)((char *)aux + xx_bytes);
         hipLaunchKernelGGL(split2_kernel, dim3((unsigned)cdiv64(npts, 64)), dim3(256), 0, st, x, npts, C, pl, xx, isc);
-        if (C == 144) hipLaunchKernelGGL(knn_f16x3_kernel<144>, grid, dim3(256), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, n, k, idx, ctab);
-        else hipLaunchKernelGGL(knn_f16x3_kernel<192>, grid, dim3(256), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, n, k, idx, ctab);
+        if (C == 144) hipLaunchKernelGGL(knn_f16x3_kernel<144>, grid, dim3(256), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, n, k, idx, ctab, thr0);
+        else hipLaunchKernelGGL(knn_f16x3_kernel<192>, grid, dim3(256), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, n, k, idx, ctab, thr0);
         LAUNCH_CHECK();
         return SCP_OK;
     }
     hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)cdiv64(npts, 256)), dim3(256), 0, st, x, npts, C, xx);
     if (C <= 4) {
         hipLaunchKernelGGL(pad4_kernel, dim3((unsigned)cdiv64(npts, 256)), dim3(256), 0, st, x, npts, C, (float *)aux);
-        hipLaunchKernelGGL((knn_mfma_kernel<2, 16>), grid, dim3(256), 0, st, (const float *)aux, (const float *)xx, n, 4, k, idx, ctab);
-    } else if (C == 144) hipLaunchKernelGGL((knn_mfma_kernel<72, 1>), grid, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, ctab);
-    else hipLaunchKernelGGL((knn_mfma_kernel<96, 1>), grid, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, ctab);
+        hipLaunchKernelGGL((knn_mfma_kernel<2, 16>), grid, dim3(256), 0, st, (const float *)aux, (const float *)xx, n, 4, k, idx, ctab, thr0);
+    } else if (C == 144) hipLaunchKernelGGL((knn_mfma_kernel<72, 1>), grid, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, ctab, thr0);
+    else hipLaunchKernelGGL((knn_mfma_kernel<96, 1>), grid, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, ctab, thr0);
     LAUNCH_CHECK();
     return SCP_OK;
 }
@@ -641,4 +647,14 @@ extern "C" SCP_API int scp_knn_topk_packed(const float *x, const int32_t *ctab, 
     if (!x || !ctab || !idx || total_rows <= 0 || (total_rows & 511) || (C != 144 && C != 192 && C > 4) || (C > 4 && ((uintptr_t)x & 15)))
         return SCP_EINVAL;
     return knn_launch(x, (int64_t)total_rows, C, dim3(total_rows / 128, 1), 0, TK, idx, ctab, (hipStream_t)stream);
+}
+
+// the same with an a-priori pruning bound per row (thr0[row], in the kernel's distance convention 2 x.y - |x|^2 - |y|^2, i.e.
+// minus the squared distance): a value that at least 20 candidates of the row's sequence are known to reach.  Rows prune with
+// it from the first tile on instead of building their bound from scratch; the result is unchanged.
+extern "C" SCP_API int scp_knn_topk_packed_bounded(const float *x, const int32_t *ctab, int32_t total_rows, int32_t C, const float *thr0,
+                                                   int32_t *idx, void *stream) {
+    if (!x || !ctab || !idx || total_rows <= 0 || (total_rows & 511) || (C != 144 && C != 192 && C > 4) || (C > 4 && ((uintptr_t)x & 15)))
+        return SCP_EINVAL;
+    return knn_launch(x, (int64_t)total_rows, C, dim3(total_rows / 128, 1), 0, TK, idx, ctab, (hipStream_t)stream, thr0);
 }

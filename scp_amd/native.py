@@ -68,6 +68,7 @@ def lib():
         "scp_geom_context_octattn": (C.c_int, [_vp, i32, _vp, _vp, _vp, _vp]),
         "scp_knn_topk": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp]),
         "scp_knn_topk_packed": (C.c_int, [_vp, _vp, i32, i32, _vp, _vp]),
+        "scp_knn_topk_packed_bounded": (C.c_int, [_vp, _vp, i32, i32, _vp, _vp, _vp]),
         "scp_swin_attention_packed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp]),
         "scp_swin_attention_packed_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, i64, _vp]),
         "scp_set_attention_mode": (C.c_int, [i32]),
@@ -245,11 +246,16 @@ def knn_topk(x, k):
     return idx
 
 
-def knn_topk_packed(x, ctab):
-    """x cuda f32 [T,C] (T % 512 == 0), ctab cuda int32 [T/512, 2] = (sequence base row, real length) -> idx int32 [T,20] global."""
+def knn_topk_packed(x, ctab, thr0=None):
+    """x cuda f32 [T,C] (T % 512 == 0), ctab cuda int32 [T/512, 2] = (sequence base row, real length) -> idx int32 [T,20] global.
+    thr0: optional f32 [T] a-priori pruning bound per row (a value of 2 x.y - |x|^2 - |y|^2 that >= 20 candidates reach)."""
     T, Cc = x.shape
     idx = torch.zeros((T, 20), dtype=torch.int32, device=x.device)
-    _check(lib().scp_knn_topk_packed(_dev(x, torch.float32), _dev(ctab, torch.int32), T, Cc, _dev(idx), _stream()), "scp_knn_topk_packed")
+    if thr0 is None:
+        _check(lib().scp_knn_topk_packed(_dev(x, torch.float32), _dev(ctab, torch.int32), T, Cc, _dev(idx), _stream()), "scp_knn_topk_packed")
+    else:
+        _check(lib().scp_knn_topk_packed_bounded(_dev(x, torch.float32), _dev(ctab, torch.int32), T, Cc, _dev(thr0, torch.float32), _dev(idx),
+                                                 _stream()), "scp_knn_topk_packed_bounded")
     return idx
 
 

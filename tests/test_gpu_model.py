@@ -401,3 +401,27 @@ def test_knn_f16x3_agrees_with_exact_fp32_chain(dev, C):
     val = torch.gather(d, 2, got)
     scale = (x.double() ** 2).sum(2).max()
     assert (val >= kth - 2e-6 * scale).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [3, 144])
+def test_knn_packed_with_a_priori_bound_is_unchanged(dev, C):
+    """scp_knn_topk_packed_bounded: a valid pruning bound per row (here: slightly below the true 20th-best distance; -inf for some
+    rows) only skips list insertions - the neighbour lists are identical."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(C + 1)
+    lens = [1500, 8192, 30]
+    rows = sum(-(-n // 512) * 512 for n in lens)
+    x = torch.zeros((rows, C))
+    ktab, r0 = [], 0
+    for n in lens:
+        x[r0:r0 + n] = torch.cumsum(torch.randn((n, C), generator=g) * 0.1, 0) + torch.randn((n, C), generator=g) * 0.2
+        ktab += [[r0, n]] * (-(-n // 512))
+        r0 += -(-n // 512) * 512
+    x, ktab = x.to(dev), torch.tensor(ktab, dtype=torch.int32, device=dev)
+    idx = native.knn_topk_packed(x, ktab)
+    xx = (x * x).sum(1)
+    d = 2 * (x[idx.long()] * x[:, None]).sum(2) - xx[idx.long()] - xx[:, None]
+    thr = d.min(1)[0] - 1e-4 * xx.max()
+    thr[::7] = float("-inf")
+    assert torch.equal(native.knn_topk_packed(x, ktab, thr), idx)
