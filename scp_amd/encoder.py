@@ -203,21 +203,25 @@ class FrameEncoder:
         from .models.packed import PackedPlan
         table = torch.empty((plan.n_rows, 255), dtype=torch.float32, device=self.device)
         ctx, pos = pre["ctx"], pre["pos"]
-        ws = plan.windows
-        i = 0
+        for r0, tok, pp in (pre.get("packed_plans") or self.packed_plans(plan)):
+            ev, od = self.model.forward_packed(ctx[r0:r0 + tok], pos[r0:r0 + tok], None, plan=pp)
+            table[pp.d["even_dst"] + r0] = ev
+            if od.shape[0]:
+                table[pp.d["odd_dst"] + r0] = od
+        return table
+
+    def packed_plans(self, plan):
+        """The frame's windows cut into chunks of <= max_tokens tokens, each with its index maps: [(first row, tokens, PackedPlan)]."""
+        from .models.packed import PackedPlan
+        ws, out, i = plan.windows, [], 0
         while i < len(ws):
             j, tok = i, 0
             while j < len(ws) and (tok == 0 or tok + ws[j][1] <= self.max_tokens):
                 tok += ws[j][1]
                 j += 1
-            r0 = ws[i][0]
-            pp = PackedPlan([w[1] for w in ws[i:j]], device=self.device)
-            ev, od = self.model.forward_packed(ctx[r0:r0 + tok], pos[r0:r0 + tok], None, plan=pp)
-            table[pp.d["even_dst"] + r0] = ev
-            if od.shape[0]:
-                table[pp.d["odd_dst"] + r0] = od
+            out.append((ws[i][0], tok, PackedPlan([w[1] for w in ws[i:j]], device=self.device)))
             i = j
-        return table
+        return out
 
     def encode(self, xyz, timing=False):
         """xyz: numpy / torch float32 [P,3].  Returns dict(bytes, bits, bpp, n_nodes, n_points, bin_num, z_offset,
@@ -243,15 +247,27 @@ class FrameEncoder:
         t0 = time.perf_counter()
         if isinstance(xyz, np.ndarray):
             xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
-        pre = self.preprocess(xyz.to(self.device, non_blocking=True))
-        plan = EncodePlan(pre["level_sizes"], self.context_size)
-        table = self.logits_in_coding_order(pre, plan)
-        order = plan.coding_order_device(self.device)
-        sym_coded = pre["sym"][order].contiguous()
-        lohi = native.softmax_cdf(table, sym_coded)["lohi"]
         if not hasattr(self, "_pool"):
             self._pool = ThreadPoolExecutor(max_workers=2)
             self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._front_stream = torch.cuda.Stream(device=self.device)
+        # Front part on its own stream: stage G (with its small D2H syncs) and the ~600 tiny index-map kernels of the window plans
+        # are launch-bound; on a side stream they run under the previous frame's model kernels instead of in front of this
+        # frame's.  Everything allocated here stays referenced by the handle until finish(), i.e. past its last use on the
+        # main stream, so the caching allocator cannot hand it out again early.
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._front_stream):
+            pre = self.preprocess(xyz.to(self.device, non_blocking=True))
+            plan = EncodePlan(pre["level_sizes"], self.context_size)
+            if self.packed:
+                pre["packed_plans"] = self.packed_plans(plan)
+            order = plan.coding_order_device(self.device)
+            sym_coded = pre["sym"][order].contiguous()
+            ready = torch.cuda.Event()
+            ready.record()
+        main.wait_event(ready)
+        table = self.logits_in_coding_order(pre, plan)
+        lohi = native.softmax_cdf(table, sym_coded)["lohi"]
         done = torch.cuda.Event()
         done.record()
         host = torch.empty(lohi.shape, dtype=lohi.dtype, pin_memory=True)
@@ -267,7 +283,7 @@ class FrameEncoder:
             return native.ac_encode_lohi(host.numpy())
 
         fut = self._pool.submit(work)
-        return dict(future=fut, pre=pre, plan=plan, t0=t0)
+        return dict(future=fut, pre=pre, plan=plan, t0=t0, keep=(order, sym_coded, table, lohi))
 
     def finish(self, h):
         stream = h["future"].result()
