@@ -336,3 +336,83 @@ def test_octattn_sequential_mode_vs_oracle(orc):
     # and the default mode differs from it (sanity: the flag does something)
     res2 = enc.encode_ints(np.ascontiguousarray(pt, np.int32), bin_num, len(xyz))
     assert (res2["_debug"]["table"].cpu() - want).abs().max() > 1e-2
+
+
+# ----------------------------------------------------------------------------------------------- BASELINE.json configs[3] / [4] at full size
+@pytest.mark.gpu
+def test_ford_like_L17_mullevel_full_frame(enc_parts, orc):
+    """Ford-like frame (integer millimetres), level 17, --spher --mullevel (qs 2, 1, 0.5 mm), 760 k nodes.
+    Stage G on the oracle's integers must reproduce the oracle's three code streams bit for bit; the whole frame encodes
+    deterministically and every shell's node count equals the oracle's."""
+    from scp_amd.encoder import FrameEncoder
+    from scp_amd.synth import ford_like, synth_frame
+    model, dev = enc_parts
+    xyz = ford_like(synth_frame(0))
+    L = 17
+    enc = FrameEncoder(model, "ford", L, spher=True, mullevel=True, device=dev)
+    ints, shells = [], orc.mullevel_shells(xyz, L, "spher", data_type="ford")
+    for k in range(3):
+        _, bin_num, _, _, pt = orc.quantise(xyz, orc.ford_qs(L + k), "spher", cart_offset=0)
+        ints.append(torch.from_numpy(pt.astype(np.int32)).to(dev))
+        if k == 0:
+            bin0 = bin_num
+    pre = enc.preprocess_ints(ints, bin0, 0.0, xyz.shape[0])
+    occ = enc.geom.nodes(("occ",))["occ"].cpu().numpy()
+    total = 0
+    for k, sh in enumerate(shells):
+        i = enc.geom.info[k]
+        assert i.n_nodes == sh["tree"].n and enc.geom.rows(k) == sh["records"].shape[0]
+        assert np.array_equal(occ[i.node_base:i.node_base + i.n_nodes], sh["tree"].codes)
+        total += sh["records"].shape[0]
+    assert pre["ctx"].shape[0] == total and total > 700_000
+    print("F17-m nodes per shell:", [s["records"].shape[0] for s in shells])
+    r1 = enc.encode_ints(ints, bin0, 0.0, xyz.shape[0])
+    r2 = enc.encode_ints(ints, bin0, 0.0, xyz.shape[0])
+    assert r1["bytes"] == r2["bytes"] and r1["n_nodes"] == total and 0 < r1["bpp"] < 64
+    # the device quantiser on the same frame: same shells up to the float -> int boundary points
+    r3 = enc.encode(xyz)
+    assert abs(r3["n_nodes"] - total) < 0.01 * total
+
+
+@pytest.mark.gpu
+def test_octattn_L14_cylin_full_frame(orc):
+    """OctAttention, level 14, --cylin, 291 k nodes = 286 windows of 1024: stage G equals the oracle on its
+    integers, symbols = occupancy codes - 1, the coded stream is what the oracle's range coder produces from the device CDFs."""
+    from cfgs import octattn_cfg
+    from scp_amd import native
+    from scp_amd.encoder import OctAttnFrameEncoder
+    from scp_amd.models import OctAttention
+    from scp_amd.synth import synth_frame
+    from scp_amd.weights import fill_weights
+    dev = torch.device("cuda:0")
+    model = fill_weights(OctAttention(octattn_cfg()), 0).to(dev)
+    xyz = synth_frame(0)
+    _, bin_num, _, _, pt = orc.quantise(xyz, 400 / (2 ** 14 - 1), "cylin")
+    pt = np.unique(pt, axis=0)
+    tree = orc.octree_build(pt.astype(np.int64))
+    enc = OctAttnFrameEncoder(model, "kitti", 14, spher=False, cylin=True, device=dev)
+    res = enc.encode_ints(np.ascontiguousarray(pt, np.int32), bin_num, len(xyz))
+    assert res["n_nodes"] == tree.n == 291522
+    sym = res["_debug"]["sym_coded"].cpu().numpy()
+    assert np.array_equal(sym, tree.codes - 1)
+    cdf = native.softmax_cdf(res["_debug"]["table"], want_lohi=False, want_cdf=True)["cdf"].cpu().numpy().view(np.uint16)
+    assert orc.ac_encode(cdf, sym.astype(np.int16)) == res["bytes"]
+
+
+@pytest.mark.gpu
+def test_batch_of_16_L12_spher_frames(enc_parts, orc):
+    """16 frames (seeds 0..15), level 12 --spher, through the pipelined encoder; every frame's stream equals
+    the synchronous path's, and the octree of three of them equals the oracle's on the oracle's integers."""
+    from scp_amd.encoder import FrameEncoder
+    from scp_amd.synth import synth_frame
+    model, dev = enc_parts
+    enc = FrameEncoder(model, "kitti", 12, spher=True, device=dev)
+    frames = [synth_frame(s) for s in range(16)]
+    handles = [enc.encode_async(f) for f in frames]
+    res = [enc.finish(h) for h in handles]
+    assert len({r["bytes"] for r in res}) == 16 and all(100_000 < r["n_nodes"] < 130_000 for r in res)
+    for s in (0, 7, 15):
+        assert enc.encode(frames[s])["bytes"] == res[s]["bytes"]
+        r = orc.proc_pc(frames[s], 400 / (2 ** 12 - 1), "spher")
+        enc.preprocess_ints([torch.from_numpy(r["pts"].astype(np.int32)).to(dev)], r["bin_num"], 0.0, len(frames[s]))
+        assert np.array_equal(enc.geom.nodes(("occ",))["occ"].cpu().numpy(), r["tree"].codes)
