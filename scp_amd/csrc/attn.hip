@@ -209,11 +209,16 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bf16x3_kernel(const float *_
     const size_t qbase = seq_row * ldq + head * HD, kbase = seq_row * ldkv + head * HD;
     const bool masked = (shift > 0) && (wnd == nW - 1);
 
-    for (int i = tid; i < 2 * WIN - 1; i += 256) tab[i] = table[i * NH + head];
+    // scores are kept in the log2 domain (q pre-scaled by log2(e) / 8, bias table and mask by log2(e)): exp() is then one v_exp_f32
+    constexpr float LOG2E = 1.4426950408889634f;
+    for (int i = tid; i < 2 * WIN - 1; i += 256) tab[i] = table[i * NH + head] * LOG2E;
 
     // Q fragment (B operand of S^T): query qi, head dims 16c + 8h + j, pre-scaled by 1/8 (exact), split hi/lo
     const int qi = qtile * QT + w * 32 + col;
-    const int qtok = (wnd * WIN + qi + shift) % Lp;
+    // cyclic shift: window base + offset < Lp and shift < WIN <= Lp, so one conditional subtract replaces the modulo (an integer
+    // division by a run-time Lp costs ~10 instructions per staged row)
+    auto wrap = [&](int t) { return t >= Lp ? t - Lp : t; };
+    const int qtok = wrap(wnd * WIN + qi + shift);
     bf16x8 qh[4], ql[4];
     {
         const float *src = q + qbase + (size_t)qtok * ldq;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bf16x3_kernel(const float *_
             const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float x = f[j] * 0.125f;
+                const float x = f[j] * (0.125f * LOG2E);
                 const __bf16 hh = (__bf16)x;
                 qh[c][j] = hh;
                 ql[c][j] = (__bf16)(x - (float)hh);
@@ -236,45 +241,55 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bf16x3_kernel(const float *_
     float m_run = -INFINITY, l_run = 0.f;
     const int qreg = qi >> 8;
 
-    for (int kt = 0; kt < WIN / KT; ++kt) {
-        __syncthreads();
-        // stage 64 keys: K as [key][d] planes, V transposed as [d][pi(key)] planes; pi swaps bits 2 and 3 of the key index
-        {
-            const int c4 = tid & 15, kg = tid >> 4;
-            // K: rows kg + 16 it, head dims 4 c4 .. 4 c4 + 3: one 8-byte store per plane
+    // staging: 64 keys per tile, K as [key][d] planes, V transposed as [d][pi(key)] planes (pi swaps bits 2 and 3 of the key
+    // index).  The global loads of tile kt + 1 are issued BEFORE the MFMAs of tile kt and converted / written to LDS after them,
+    // so their latency hides behind the compute of the same workgroup.
+    const int c4 = tid & 15, kg = tid >> 4;
+    float4 kreg[4], vreg[4];
+    auto load_tile = [&](int kt) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int r = kg + 16 * it;
-                const int ktok = (wnd * WIN + kt * KT + r + shift) % Lp;
-                const float4 kv = *(const float4 *)(k + kbase + (size_t)ktok * ldkv + 4 * c4);
-                const float kf[4] = {kv.x, kv.y, kv.z, kv.w};
-                bf16x4 khi, klo;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const __bf16 hh = (__bf16)kf[u]; khi[u] = hh; klo[u] = (__bf16)(kf[u] - (float)hh); }
-                *(bf16x4 *)(Kh + r * LDB + 4 * c4) = khi;
-                *(bf16x4 *)(Kl + r * LDB + 4 * c4) = klo;
-            }
-            // V: a 4-key x 4-dim block per thread (keys 4 kg .. 4 kg + 3: pi keeps them adjacent), transposed in registers:
-            // 8-byte stores of 4 consecutive permuted keys per head dim instead of sixteen 2-byte ones
-            float vf[4][4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int ktok = (wnd * WIN + kt * KT + 4 * kg + kk + shift) % Lp;
-                const float4 vv = *(const float4 *)(v + kbase + (size_t)ktok * ldkv + 4 * c4);
-                vf[kk][0] = vv.x; vf[kk][1] = vv.y; vf[kk][2] = vv.z; vf[kk][3] = vv.w;
-            }
-            const int pr = 4 * ((kg & ~3) | ((kg & 1) << 1) | ((kg >> 1) & 1));
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                bf16x4 vhi, vlo;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { const __bf16 hh = (__bf16)vf[kk][u]; vhi[kk] = hh; vlo[kk] = (__bf16)(vf[kk][u] - (float)hh); }
-                *(bf16x4 *)(Vh + (4 * c4 + u) * LDB + pr) = vhi;
-                *(bf16x4 *)(Vl + (4 * c4 + u) * LDB + pr) = vlo;
-            }
+        for (int it = 0; it < 4; ++it) {   // K: rows kg + 16 it, head dims 4 c4 .. 4 c4 + 3
+            const int ktok = wrap(wnd * WIN + kt * KT + kg + 16 * it + shift);
+            kreg[it] = *(const float4 *)(k + kbase + (size_t)ktok * ldkv + 4 * c4);
         }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {   // V: a 4-key x 4-dim block per thread (keys 4 kg .. 4 kg + 3: pi keeps them adjacent)
+            const int ktok = wrap(wnd * WIN + kt * KT + 4 * kg + kk + shift);
+            vreg[kk] = *(const float4 *)(v + kbase + (size_t)ktok * ldkv + 4 * c4);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = kg + 16 * it;
+            const float kf[4] = {kreg[it].x, kreg[it].y, kreg[it].z, kreg[it].w};
+            bf16x4 khi, klo;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const __bf16 hh = (__bf16)kf[u]; khi[u] = hh; klo[u] = (__bf16)(kf[u] - (float)hh); }
+            *(bf16x4 *)(Kh + r * LDB + 4 * c4) = khi;
+            *(bf16x4 *)(Kl + r * LDB + 4 * c4) = klo;
+        }
+        // V transposed in registers: 8-byte stores of 4 consecutive permuted keys per head dim instead of sixteen 2-byte ones
+        const float vf[4][4] = {{vreg[0].x, vreg[0].y, vreg[0].z, vreg[0].w}, {vreg[1].x, vreg[1].y, vreg[1].z, vreg[1].w},
+                                {vreg[2].x, vreg[2].y, vreg[2].z, vreg[2].w}, {vreg[3].x, vreg[3].y, vreg[3].z, vreg[3].w}};
+        const int pr = 4 * ((kg & ~3) | ((kg & 1) << 1) | ((kg >> 1) & 1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bf16x4 vhi, vlo;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { const __bf16 hh = (__bf16)vf[kk][u]; vhi[kk] = hh; vlo[kk] = (__bf16)(vf[kk][u] - (float)hh); }
+            *(bf16x4 *)(Vh + (4 * c4 + u) * LDB + pr) = vhi;
+            *(bf16x4 *)(Vl + (4 * c4 + u) * LDB + pr) = vlo;
+        }
+    };
+
+    load_tile(0);
+    for (int kt = 0; kt < WIN / KT; ++kt) {
+        __syncthreads();            // everybody is done reading the previous tile
+        store_tile();
         __syncthreads();
-        const float madd = (masked && ((kt * KT) >> 8) != qreg) ? -100.f : 0.f;
+        if (kt + 1 < WIN / KT) load_tile(kt + 1);   // in flight during this tile's MFMAs
+        const float madd = (masked && ((kt * KT) >> 8) != qreg) ? -100.f * LOG2E : 0.f;   // uniform per lane and tile: folded into the max
 
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -294,15 +309,16 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bf16x3_kernel(const float *_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + (r & 3) + 8 * (r >> 2);
-                s[r] = s[r] + tab[qi - j + (WIN - 1)] + madd;
+                s[r] = s[r] + tab[qi - j + (WIN - 1)];
                 mx = fmaxf(mx, s[r]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = fmaxf(mx, __shfl_xor(mx, 32)) + madd;
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __expf(m_run - m_new);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            const float msub = m_new - madd;
             float ps = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_new); ps += s[r]; }
+            for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - msub); ps += s[r]; }
             ps += __shfl_xor(ps, 32);
             l_run = l_run * alpha + ps;
             m_run = m_new;
