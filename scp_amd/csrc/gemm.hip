@@ -252,10 +252,52 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float *__restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int nk = (K + FBK - 1) / FBK;
+    // staging: element (row, k) -> [row][(k & 1) * 16 + (k >> 1)].  Fast path (K % 4 == 0, 16-byte aligned rows): every thread
+    // moves 16-byte pieces - 4 of A and 2 of W per k-tile - and the pieces of tile kt + 1 are loaded into registers BEFORE the
+    // MFMAs of tile kt (written to LDS after them), so the global latency hides behind the workgroup's own compute.
+    const bool vec = ((K & 3) == 0) && ((lda & 3) == 0) && ((((uintptr_t)A | (uintptr_t)W) & 15) == 0);
+    const int pr = tid >> 3, pc = (tid & 7) * 4;          // piece p = tid + 256 i: row pr + 32 i, k columns pc .. pc + 3
+    f32x4 ra[4], rb[2];
+    auto load_tile = [&](int kt) {
+        const int kk = kt * FBK + pc;
+        const bool kin = kk < K;                           // K % 4 == 0: a piece is entirely inside or outside
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + pr + 32 * i;
+            const int mc = m < M ? m : M - 1, kc = kin ? kk : 0;
+            const f32x4 v = *(const f32x4 *)(A + (int64_t)mc * lda + kc);
+            ra[i] = (kin && m < M) ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = n0 + pr + 32 * i;
+            const int nc = n < N ? n : N - 1, kc = kin ? kk : 0;
+            const f32x4 v = *(const f32x4 *)(W + (int64_t)nc * K + kc);
+            rb[i] = (kin && n < N) ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tile = [&]() {
+        const int o = pc >> 1;                             // k = pc + u -> column (u & 1) * 16 + o + (u >> 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float *d = sA + (pr + 32 * i) * FLD;
+            *(float2 *)(d + o) = make_float2(ra[i][0], ra[i][2]);
+            *(float2 *)(d + 16 + o) = make_float2(ra[i][1], ra[i][3]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float *d = sB + (pr + 32 * i) * FLD;
+            *(float2 *)(d + o) = make_float2(rb[i][0], rb[i][2]);
+            *(float2 *)(d + 16 + o) = make_float2(rb[i][1], rb[i][3]);
+        }
+    };
+    if (vec) load_tile(0);
     for (int kt = 0; kt < nk; ++kt) {
         const int k0 = kt * FBK;
         __syncthreads();
-        // stage: element (row, k) -> [row][(k & 1) * 16 + (k >> 1)]
+        if (vec) {
+            store_tile();
+        } else {
         for (int e = tid; e < FBM * FBK; e += 256) {
             const int r = e >> 5, k = e & 31;
             const int m = m0 + r, kk = k0 + k;
@@ -266,7 +308,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float *__restric
             const int n = n0 + r, kk = k0 + k;
             sB[r * FLD + (k & 1) * 16 + (k >> 1)] = (n < N && kk < K) ? W[(int64_t)n * K + kk] : 0.f;
         }
+        }
         __syncthreads();
+        if (vec && kt + 1 < nk) load_tile(kt + 1);
         const float *ar = sA + (w * 32 + col) * FLD + h * 16;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
