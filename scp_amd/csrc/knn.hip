@@ -54,13 +54,40 @@ typedef __attribute__((address_space(3))) void *knn_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *knn_glb_ptr_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// ---- sorted top-20 lists of the specialised kernels: ONE 64-bit key per entry ---------------------------------------------------
+// key = sortable(d) << 32 | (2^32 - 1 - j): the order (value desc, index asc) is a single unsigned 64-bit compare, so an insertion
+// step is v_cmp_gt_u64 + four v_cndmask instead of three compares, two scalar ops and four v_cndmask.  sortable() maps float
+// order to unsigned order (negative values: all bits flipped; others: sign bit set).  Empty slots hold KEY_EMPTY = (-inf, no index).
+typedef unsigned long long u64;
+#define KEY_EMPTY 0x007FFFFF00000000ull
+__device__ __forceinline__ unsigned knn_sortable(float d) {
+    const unsigned u = __float_as_uint(d);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float knn_unsortable(unsigned s) {
+    return __uint_as_float((s & 0x80000000u) ? (s ^ 0x80000000u) : ~s);
+}
+__device__ __forceinline__ u64 knn_key(float d, int j) { return ((u64)knn_sortable(d) << 32) | (u64)(0xFFFFFFFFu - (unsigned)j); }
+__device__ __forceinline__ float knn_key_val(u64 k) { return knn_unsortable((unsigned)(k >> 32)); }
+__device__ __forceinline__ int knn_key_idx(u64 k) { const unsigned lo = (unsigned)k; return lo == 0u ? INT_MAX : (int)(0xFFFFFFFFu - lo); }
+
+__device__ __forceinline__ void key_insert(u64 (&key)[TK], u64 kc) {
+#pragma unroll
+    for (int t = 0; t < TK; ++t) {
+        const bool better = kc > key[t];
+        const u64 nk = better ? kc : key[t];
+        kc = better ? key[t] : kc;
+        key[t] = nk;
+    }
+}
+
 // ---- shared tail: merge the two partial lists of every query (lane halves h = 0 / 1) and write the indices -------------------
-__device__ __forceinline__ void knn_merge_write(const float (&v)[TK], const int (&id)[TK], float *mval, int *midx, int tid, int w, int col, int h,
+__device__ __forceinline__ void knn_merge_write(const u64 (&key)[TK], float *mval, int *midx, int tid, int w, int col, int h,
                                                 int q0, int n, int k, size_t row0, const int *ctab, int *idx) {
     {
         const int ql = w * 32 + col;
 #pragma unroll
-        for (int t = 0; t < TK; ++t) { mval[(ql * 2 + h) * TK + t] = v[t]; midx[(ql * 2 + h) * TK + t] = id[t]; }
+        for (int t = 0; t < TK; ++t) { mval[(ql * 2 + h) * TK + t] = knn_key_val(key[t]); midx[(ql * 2 + h) * TK + t] = knn_key_idx(key[t]); }
     }
     __syncthreads();
     if (tid < 128 && q0 + tid < n) {
@@ -94,23 +121,13 @@ __device__ __forceinline__ void knn_merge_write(const float (&v)[TK], const int 
 // Pass 2: lanes pop their survivors one at a time (the wavefront pays for max-over-lanes survivors, not for all 16 slots);
 // the 20-step insertion skips the leading 5-step segments that no lane's survivor reaches - late in the sweep a survivor
 // almost always lands near the end of the list.
-template <int T0>
-__device__ __forceinline__ void topk_insert_seg(float (&v)[TK], int (&id)[TK], float &d, int &j) {
-#pragma unroll
-    for (int t = T0; t < T0 + 5; ++t) {
-        const bool better = (d > v[t]) || (d == v[t] && j < id[t]);
-        const float nv = better ? d : v[t], od = better ? v[t] : d;
-        const int ni = better ? j : id[t], oj = better ? id[t] : j;
-        v[t] = nv; d = od; id[t] = ni; j = oj;
-    }
-}
-
 template <bool SCALED>
 __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, const float *sis, float usc, float xxi, int c0, int n, int h,
-                                           float (&v)[TK], int (&id)[TK], float thr0) {
+                                           u64 (&key)[TK], float thr0) {
     // both lanes of a query prune with the tighter of their bounds, and with the caller's a-priori bound thr0 (a distance that at
     // least 20 candidates are known to beat: nothing below it can be among the 20 best; -inf when there is none)
-    const float thr = fmaxf(fmaxf(v[TK - 1], __shfl_xor(v[TK - 1], 32)), thr0);
+    const float v19 = knn_key_val(key[TK - 1]);
+    const float thr = fmaxf(fmaxf(v19, __shfl_xor(v19, 32)), thr0);
     const bool full = c0 + 32 <= n;                                   // wave-uniform: every candidate of the tile exists
     unsigned pend = 0, eqm = 0;
     unsigned long long anyeq = 0;
@@ -144,7 +161,7 @@ __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, 
         for (int r = 0; r < 16; ++r) {
             const float d = dist(r);
             const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool pass = d == thr && d > -INFINITY && ((d > v[TK - 1]) || j < id[TK - 1]);
+            const bool pass = d == thr && d > -INFINITY && knn_key(d, j) > key[TK - 1];
             eqm |= pass ? (1u << r) : 0u;
         }
         pend |= eqm;
@@ -153,11 +170,10 @@ __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, 
         const bool act = pend != 0u;
         const int r = act ? (__ffs(pend) - 1) : 0;
         pend &= pend - 1u;
-        float d = dist(r);
-        d = act ? d : -INFINITY;
-        int j = act ? (c0 + (r & 3) + 8 * (r >> 2) + 4 * h) : INT_MAX;
-        // a survivor that no longer qualifies simply falls off the end
-        topk_insert(v, id, d, j);
+        const float d = dist(r);
+        const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        // a survivor that no longer qualifies simply falls off the end; 0 is below every key, KEY_EMPTY included
+        key_insert(key, act ? knn_key(d, j) : 0ull);
     }
 }
 
@@ -211,10 +227,9 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
     const float xxi = (qi < n) ? xxb[qi] : 0.f;
     const float thr0v = (thr0 && qi < n) ? thr0[row0 + qi] : -INFINITY;
 
-    float v[TK];
-    int id[TK];
+    u64 key[TK];
 #pragma unroll
-    for (int t = 0; t < TK; ++t) { v[t] = -INFINITY; id[t] = INT_MAX; }
+    for (int t = 0; t < TK; ++t) key[t] = KEY_EMPTY;
 
     auto issue = [&](int t, int buf) {   // candidates [t * SC, t * SC + SC) -> stage buf (rows beyond n: clamped, masked later)
         const int c0 = t * SC;
@@ -281,12 +296,12 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a[1] : a[0], qf[2 * g], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a[3] : a[2], qf[2 * g + 1], acc, 0, 0, 0);
             }
-            knn_select<false>(acc, sxx + sub * 32, nullptr, 1.f, xxi, cur * SC + sub * 32, n, h, v, id, thr0v);
+            knn_select<false>(acc, sxx + sub * 32, nullptr, 1.f, xxi, cur * SC + sub * 32, n, h, key, thr0v);
         }
         cur = nxt;
     }
     __syncthreads();   // everybody is done with the stages: the pool becomes the merge area
-    knn_merge_write(v, id, pool, (int *)(pool + 128 * 2 * TK), tid, w, col, h, q0, n, k, row0, ctab, idx);
+    knn_merge_write(key, pool, (int *)(pool + 128 * 2 * TK), tid, w, col, h, q0, n, k, row0, ctab, idx);
 }
 
 // positions (C <= 4 features) padded to rows of 4 floats for the K = 4 specialisation
@@ -361,10 +376,9 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
     const float thr0v = (thr0 && qi < n) ? thr0[row0 + qi] : -INFINITY;
     const float isq = isb[qc];                      // 1 / scale of the query row (a power of two)
 
-    float v[TK];
-    int id[TK];
+    u64 key[TK];
 #pragma unroll
-    for (int t = 0; t < TK; ++t) { v[t] = -INFINITY; id[t] = INT_MAX; }
+    for (int t = 0; t < TK; ++t) key[t] = KEY_EMPTY;
 
     auto issue = [&](int t, int buf) {
         const int c0 = t * 32;
@@ -421,11 +435,11 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
         }
         // un-scaling (acc / s_query / s_candidate, powers of two: exact) happens inside the selection
         const float *sxx = txx + buf * 64;
-        knn_select<true>(acc, sxx, sxx + 32, isq, xxi, cur * 32, n, h, v, id, thr0v);
+        knn_select<true>(acc, sxx, sxx + 32, isq, xxi, cur * 32, n, h, key, thr0v);
         cur = nxt;
     }
     __syncthreads();
-    knn_merge_write(v, id, (float *)pool, (int *)(pool + 128 * 2 * TK * 4), tid, w, col, h, q0, n, k, row0, ctab, idx);
+    knn_merge_write(key, (float *)pool, (int *)(pool + 128 * 2 * TK * 4), tid, w, col, h, q0, n, k, row0, ctab, idx);
 }
 
 // fp32 rows -> row scale 2^e (largest |x| into [2^13, 2^14)), two f16 planes of the scaled row ([row][2][K]), 1 / scale, and
