@@ -124,7 +124,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
     for (int d = ((((blockIdx.x >> 3) & 1)) + 2 * ((blockIdx.x >> 8) & 1)) * a.stagger; d > 0; --d) __builtin_amdgcn_s_sleep(127);
     // two waves share a SIMD (w and w + 4): the upper half always wins MFMA arbitration, so the pair falls out of phase - one
     // runs its MFMA batch while the other waits for its fragment reads - instead of both stalling on LDS at the same time
-    if (a.prio && w >= 4) __builtin_amdgcn_s_setprio(1);
+
     int m0, n0;
     tile_coords(tile, m0, n0);
     stage_issue(0, m0, n0, 0);
@@ -181,7 +181,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                     acc[p * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ab][i], Bh[bb][j], acc[p * HM + i][j], 0, 0, 0);
         };
 
-        __syncthreads();   // DMA of step 0 landed (the fence waits vmcnt 0); every wave is past the previous tile's epilogue
+        SCP_WAIT_DMA(0);
+        __syncthreads();   // DMA of step 0 landed; every wave is past the previous tile's epilogue
         if (nk > 1) stage_issue(1, m0, n0, 1);
         load_b(0, 0, 0);
         load_a(0, 0, 0, 0);
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
             mfma_sub(0, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (kt + 1 < nk) {
+                SCP_WAIT_DMA(0);   // the DMA of step kt + 1 (issued a k-step ago) has landed
                 __syncthreads();
                 if (kt + 2 < nk) stage_issue(kt & 1, m0, n0, kt + 2);
                 load_b(0, sbn, 0);
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
             mfma_sub(1, 1, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        SCP_WAIT_DMA(0);
         __syncthreads();   // every wave is done with both stages
         const int cm0 = m0, cn0 = n0;
         if (tile + (int)gridDim.x < ntiles) {   // first step of the next tile: in flight during the epilogue (stage 0)
@@ -385,7 +388,7 @@ extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_
     if (nco > ldo) nco = (N + 3) & ~3;
     ga.ncols_out = nco;
     ga.stagger = (cfg >> 8) & 255;
-    ga.prio = (cfg & 0x40000) ? 1 : 0;
+    ga.prio = 0;
     if (cfg & 0x10000) ga.lda = 0;                                   // DEBUG timing probes (results wrong): all A rows = row 0
     if (cfg & 0x20000) { ga.C = nullptr; ga.Ohi = ga.Olo = nullptr; ga.res = nullptr; }   // no epilogue traffic
     cfg &= 255;

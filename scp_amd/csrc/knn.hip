@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
 
     for (int s = 0; s < nt; ++s) {
         const int buf = s & 1;
-        __syncthreads();   // stage s has landed (the fence waits vmcnt 0) and every wave is done with the other stage
+        SCP_WAIT_DMA(0);
+        __syncthreads();   // stage s has landed and every wave is done with the other stage
         int nxt = -1;
         if (s + 1 < nt) {
             if ((s & 1) == 0) { if (hi < nt) nxt = hi++; else nxt = lo--; }
@@ -413,7 +414,8 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
 
     for (int s = 0; s < nt; ++s) {
         const int buf = s & 1;
-        __syncthreads();
+        SCP_WAIT_DMA(0);
+        __syncthreads();   // stage s has landed and every wave is done with the other stage
         int nxt = -1;
         if (s + 1 < nt) {
             if ((s & 1) == 0) { if (hi < nt) nxt = hi++; else nxt = lo--; }

@@ -22,6 +22,11 @@ extern int g_scp_last_hip_error;
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// LDS-DMA (global_load_lds_*) completes on the VM counter.  hipcc usually drains it in front of a __syncthreads(), but whether it
+// does depends on the surrounding code (observed: adding an unrelated, never-executed DMA to a loop removed the wait) - so every
+// barrier that publishes DMA data is preceded by an explicit wait.  N = DMA instructions of THIS wave that may stay in flight.
+#define SCP_WAIT_DMA(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
 // growable device buffer owned by a handle
 struct DevBuf {
     void *p = nullptr;

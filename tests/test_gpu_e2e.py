@@ -416,3 +416,29 @@ def test_batch_of_16_L12_spher_frames(enc_parts, orc):
         r = orc.proc_pc(frames[s], 400 / (2 ** 12 - 1), "spher")
         enc.preprocess_ints([torch.from_numpy(r["pts"].astype(np.int32)).to(dev)], r["bin_num"], 0.0, len(frames[s]))
         assert np.array_equal(enc.geom.nodes(("occ",))["occ"].cpu().numpy(), r["tree"].codes)
+
+
+@pytest.mark.gpu
+def test_full_frame_packed_forward_is_batch_invariant(enc_parts):
+    """BASELINE.json configs[2] at full size (L16 --spher --mullevel, 577 k nodes, 100 windows): the rows the one-launch-sequence
+    packed forward produces for a window must be BIT-identical to that window pushed through the same kernels alone (what the
+    decoder does).  590 k rows mean several GEMM tiles per persistent workgroup, full kNN / attention grids: a race or a tiling
+    bug at scale shows up here, and so would any dependence of a row's result on the rest of the launch."""
+    from scp_amd.encoder import EncodePlan, FrameEncoder
+    from scp_amd.models.packed import PackedPlan
+    from scp_amd.synth import synth_frame
+    model, dev = enc_parts
+    enc = FrameEncoder(model, "kitti", 16, spher=True, mullevel=True, device=dev)
+    pre = enc.preprocess(torch.from_numpy(synth_frame(0)).to(dev))
+    plan = EncodePlan(pre["level_sizes"], 8192)
+    assert plan.n_rows > 500_000 and len(plan.windows) >= 100
+    table = enc.logits_in_coding_order(pre, plan)
+    assert torch.equal(table, enc.logits_in_coding_order(pre, plan))          # run to run
+    picks = sorted({0, 3, 6, 7, 8, len(plan.windows) // 2, len(plan.windows) - 2, len(plan.windows) - 1})
+    for wi in picks:
+        start, c, coded = plan.windows[wi]
+        ev, od = model.forward_packed(pre["ctx"][start:start + c], pre["pos"][start:start + c], None, plan=PackedPlan([c], device=dev))
+        ne = (c + 1) // 2
+        assert torch.equal(table[coded:coded + ne], ev), (wi, c)
+        if c > 1:
+            assert torch.equal(table[coded + ne:coded + c], od), (wi, c)

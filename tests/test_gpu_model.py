@@ -313,10 +313,13 @@ def test_octattn_logits_vs_reference(dev, octattn, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K,act,res", [(1000, 256, 256, 0, True), (257, 300, 64, 3, False), (700, 255, 512, 1, False),
-                                           (513, 240, 240, 0, False), (2049, 1024, 256, 2, False), (300, 128, 448, 1, True)])
+                                           (513, 240, 240, 0, False), (2049, 1024, 256, 2, False), (300, 128, 448, 1, True),
+                                           (70001, 256, 256, 0, True), (140000, 512, 64, 2, False)])
 def test_linear_split_matches_fp32_activation_kernel(M, N, K, act, res):
     """scp_linear_split (both operands pre-split, LDS-DMA staging) is bit-identical to scp_linear_bf16x3 (activation split while
-    staging) in every tile configuration, for fp32 and for split outputs, and zero-fills the K padding of its split output."""
+    staging) in every tile configuration, for fp32 and for split outputs, and zero-fills the K padding of its split output.
+    The two large cases give more tiles than CUs, i.e. they exercise the persistent loop (several tiles per workgroup, the next
+    tile's first DMA in flight during the epilogue)."""
     from scp_amd import native
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(M + N + K)
