@@ -272,6 +272,19 @@ SCP_API int int_get(void *codes, int i);
  * PSNR = 10 log10(3 peak^2 / max(mean d2_ab, mean d2_ba)). */
 SCP_API int scp_nn_sqdist_f64(const double *a, int64_t na, const double *b, int64_t nb, double *d2, void *stream);
 
+/* ---- index maps of the packed ("varlen") EHEM forward ------------------------------------------------------------------
+ * lengths[W] (host): the window lengths of one packed chunk (encode.py:109-136 cuts every level into windows of <= 8192 nodes).
+ * scp_packed_plan_sizes: rows of the 11 layouts (self stages 0..4, cross stages 0..3, even outputs, odd outputs; every window
+ * padded to x512 rows per Swin stage).  scp_packed_plan: writes all 47 maps in one launch; outs[] = device buffers in this order:
+ *   inmap i64[rows0]; a1map, a2map i64[rowsX0]; even_rows i64[E]; odd_rows i64[O]; even_dst i64[E]; odd_dst i64[O];
+ *   self merge (even, odd) i64[rows s+1] for s = 0..3; cross merge (even, odd) for s = 0..2; self concat i64[rows0] for s = 1..4;
+ *   cross concat i64[rowsX0] for s = 1..3; window tables i32[rows/512][2] (base, padded length) of the 9 stage layouts;
+ *   kNN table i32[rows0/512][2] (base, real length); valid f32[rows] of the 9 stage layouts.
+ * Replaces the per-window Python bookkeeping of models/ehem.py:88-136 / swin_transformer.py:350-367,638-641 in the packed forward;
+ * tables_dev: int64 scratch of 36 * W entries. */
+SCP_API int scp_packed_plan_sizes(const int64_t *lengths, int32_t W, int64_t *rows_out);
+SCP_API int scp_packed_plan(const int64_t *lengths, int32_t W, int64_t *tables_dev, void *const *outs, int32_t n_outs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -250,7 +250,7 @@ class FrameEncoder:
         if not hasattr(self, "_pool"):
             self._pool = ThreadPoolExecutor(max_workers=2)
             self._copy_stream = torch.cuda.Stream(device=self.device)
-            self._front_stream = torch.cuda.Stream(device=self.device)
+            self._front_stream = torch.cuda.Stream(device=self.device, priority=-1)   # high priority: its tiny kernels slip in between the model's
         # Front part on its own stream: stage G (with its small D2H syncs) and the ~600 tiny index-map kernels of the window plans
         # are launch-bound; on a side stream they run under the previous frame's model kernels instead of in front of this
         # frame's.  Everything allocated here stays referenced by the handle until finish(), i.e. past its last use on the

@@ -79,8 +79,16 @@ class PackedPlan:
     """All index maps for one list of window lengths, built ON THE DEVICE from the (tiny) list of lengths with a few dozen
     vectorised index ops - the host never touches a per-token array."""
 
-    def __init__(self, lengths, n_self=5, n_cross=4, device=None):
+    def __init__(self, lengths, n_self=5, n_cross=4, device=None, use_native=True):
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device(dev)
+        if use_native and dev.type == "cuda" and n_self == 5 and n_cross == 4:
+            # one kernel launch for all 47 maps (csrc/plan.hip); the torch construction below is its executable specification
+            # (tests/test_host_logic.py checks it on the CPU, tests/test_gpu_model.py checks the kernel against it)
+            self.c = torch.as_tensor(np.asarray(lengths, np.int64))
+            self.n_tokens = int(np.asarray(lengths, np.int64).sum())
+            self.rows, self.d = native.packed_plan(lengths, dev)
+            return
         c = torch.as_tensor(np.asarray(lengths, np.int64), device=dev)
         self.c = c
         e = c + (c & 1)                                   # ehem.py:92-99: odd windows get one pad token

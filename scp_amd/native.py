@@ -74,6 +74,8 @@ def lib():
         "scp_set_attention_mode": (C.c_int, [i32]),
         "scp_set_knn_mode": (C.c_int, [i32]),
         "scp_nn_sqdist_f64": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp]),
+        "scp_packed_plan_sizes": (C.c_int, [_vp, i32, _vp]),
+        "scp_packed_plan": (C.c_int, [_vp, i32, _vp, _vp, i32, _vp]),
         "scp_edge_gather_max": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_swin_attention": (C.c_int, [_vp, _vp, _vp, _vp, i32, i32, i32, i32, i32, _vp, _vp]),
         "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
@@ -290,6 +292,38 @@ def _dev_f64(t):
     if not t.is_cuda:
         raise ScpError("device tensor required (there is no CPU path in the product)")
     return t.to(torch.float64).contiguous()
+
+
+def packed_plan(lengths, device):
+    """All index maps of the packed forward for one list of window lengths, ONE kernel launch (csrc/plan.hip).
+    Returns (rows[11], dict of device tensors keyed like models/packed.py: PackedPlan.d)."""
+    import numpy as np
+    c = np.ascontiguousarray(np.asarray(lengths, np.int64))
+    W = int(c.shape[0])
+    rows = np.zeros(11, np.int64)
+    _check(lib().scp_packed_plan_sizes(c.ctypes.data, W, rows.ctypes.data), "scp_packed_plan_sizes")
+    r = [int(x) for x in rows]
+    i64, i32, f32 = torch.int64, torch.int32, torch.float32
+    spec = [("inmap", i64, (r[0],)), ("a1map", i64, (r[5],)), ("a2map", i64, (r[5],)), ("even_rows", i64, (r[9],)), ("odd_rows", i64, (r[10],)),
+            ("even_dst", i64, (r[9],)), ("odd_dst", i64, (r[10],))]
+    for s_ in range(4):
+        spec += [(f"sme{s_}", i64, (r[s_ + 1],)), (f"smo{s_}", i64, (r[s_ + 1],))]
+    for s_ in range(3):
+        spec += [(f"cme{s_}", i64, (r[6 + s_],)), (f"cmo{s_}", i64, (r[6 + s_],))]
+    spec += [(f"sc{s_}", i64, (r[0],)) for s_ in range(1, 5)] + [(f"cc{s_}", i64, (r[5],)) for s_ in range(1, 4)]
+    spec += [(f"tab{l}", i32, (r[l] // 512, 2)) for l in range(9)] + [("knn_tab", i32, (r[0] // 512, 2))]
+    spec += [(f"valid{l}", f32, (r[l], 1)) for l in range(9)]
+    t = {name: torch.empty(shape, dtype=dt, device=device) for name, dt, shape in spec}
+    ptrs = (C.c_void_p * len(spec))(*[t[name].data_ptr() for name, _, _ in spec])
+    scratch = torch.empty((36 * W,), dtype=torch.int64, device=device)
+    _check(lib().scp_packed_plan(c.ctypes.data, W, scratch.data_ptr(), ptrs, len(spec), _stream()), "scp_packed_plan")
+    d = dict(inmap=t["inmap"], a1map=t["a1map"], a2map=t["a2map"], even_rows=t["even_rows"], odd_rows=t["odd_rows"],
+             even_dst=t["even_dst"], odd_dst=t["odd_dst"],
+             self_merge=[(t[f"sme{s_}"], t[f"smo{s_}"]) for s_ in range(4)], cross_merge=[(t[f"cme{s_}"], t[f"cmo{s_}"]) for s_ in range(3)],
+             self_concat=[t[f"sc{s_}"] for s_ in range(1, 5)], cross_concat=[t[f"cc{s_}"] for s_ in range(1, 4)],
+             self_tab=[t[f"tab{l}"] for l in range(5)], cross_tab=[t[f"tab{l}"] for l in range(5, 9)], knn_tab=t["knn_tab"],
+             self_valid=[t[f"valid{l}"] for l in range(5)], cross_valid=[t[f"valid{l}"] for l in range(5, 9)])
+    return r, d
 
 
 def set_knn_mode(f16x3):

@@ -428,3 +428,26 @@ def test_knn_packed_with_a_priori_bound_is_unchanged(dev, C):
     thr = d.min(1)[0] - 1e-4 * xx.max()
     thr[::7] = float("-inf")
     assert torch.equal(native.knn_topk_packed(x, ktab, thr), idx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lengths", [[1], [1, 6, 20, 56, 208, 1372, 5605, 8192, 4938, 7, 2, 513, 1], [8192] * 5 + [3], [2, 1, 1, 1, 4096]])
+def test_packed_plan_kernel_equals_torch_construction(dev, lengths):
+    """csrc/plan.hip (all index maps of the packed forward in one launch) against the vectorised torch construction in
+    models/packed.py, entry for entry."""
+    from scp_amd.models.packed import PackedPlan
+    a = PackedPlan(lengths, device=dev)                       # native kernel
+    b = PackedPlan(lengths, device=dev, use_native=False)     # torch index ops
+    assert a.n_tokens == b.n_tokens
+    for k, vb in b.d.items():
+        va = a.d[k]
+        if isinstance(vb, (list, tuple)):
+            assert len(va) == len(vb), k
+            for xa, xb in zip(va, vb):
+                if isinstance(xb, (list, tuple)):
+                    for ya, yb in zip(xa, xb):
+                        assert ya.dtype == yb.dtype and torch.equal(ya, yb), k
+                else:
+                    assert xa.dtype == xb.dtype and xa.shape == xb.shape and torch.equal(xa, xb), k
+        else:
+            assert va.dtype == vb.dtype and va.shape == vb.shape and torch.equal(va, vb), k
