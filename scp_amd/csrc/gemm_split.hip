@@ -18,6 +18,7 @@
 //   Epilogue: accumulators -> wave-private LDS slice (32 x 64 fp32, rows of 256 B = one bank sweep) -> 16-byte rows:
 //   + bias, activation, + residual, written as fp32 and/or as hi/lo planes (columns N .. round32(N) are zero filled: the next
 //   layer's K padding).
+#include <stdlib.h>
 #include "scp_internal.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -74,8 +75,6 @@ struct GemmSplitArgs {
     float *C; int64_t ldc;                       // fp32 output or null
     __bf16 *Ohi, *Olo; int64_t ldo;              // split output planes or null
     int M, N;
-    int prio;
-    int stagger;                                 // start delay units (x s_sleep 127) per (workgroup >> 3) & 3: de-phases the CUs
     int vec_ok;                                  // fp32 rows of C / residual are 16-byte aligned
     int ncols_out;                               // split output: columns written (N rounded up to 32, <= ldo): zero filled beyond N
 };
@@ -139,7 +138,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
-    for (int d = ((((blockIdx.x >> 3) & 1)) + 2 * ((blockIdx.x >> 8) & 1)) * a.stagger; d > 0; --d) __builtin_amdgcn_s_sleep(127);
     // two waves share a SIMD (w and w + 4): the upper half always wins MFMA arbitration, so the pair falls out of phase - one
     // runs its MFMA batch while the other waits for its fragment reads - instead of both stalling on LDS at the same time
 
@@ -405,10 +403,15 @@ extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_
     int nco = (N + 31) & ~31;
     if (nco > ldo) nco = (N + 3) & ~3;
     ga.ncols_out = nco;
-    ga.stagger = (cfg >> 8) & 255;
-    ga.prio = 0;
-    if (cfg & 0x10000) ga.lda = 0;                                   // DEBUG timing probes (results wrong): all A rows = row 0
-    if (cfg & 0x20000) { ga.C = nullptr; ga.Ohi = ga.Olo = nullptr; ga.res = nullptr; }   // no epilogue traffic
+    if (cfg & ~0xff) {
+        // timing probes of tools/mb_gemm_split.py (RESULTS ARE WRONG with them): 0x10000 = every activation row reads row 0 (operands
+        // cache resident), 0x20000 = no output traffic.  Only honoured when SCP_GEMM_PROBE is set; an error otherwise.
+        static int probe = -1;
+        if (probe < 0) probe = getenv("SCP_GEMM_PROBE") ? 1 : 0;
+        if (!probe || (cfg & ~0x300ff)) return SCP_EINVAL;
+        if (cfg & 0x10000) ga.lda = 0;
+        if (cfg & 0x20000) { ga.C = nullptr; ga.Ohi = ga.Olo = nullptr; ga.res = nullptr; }
+    }
     cfg &= 255;
     ga.vec_ok = !((C && ((ldc & 3) || ((uintptr_t)C & 15))) || (residual && ((ldr & 3) || ((uintptr_t)residual & 15))));
     hipStream_t st = (hipStream_t)stream;

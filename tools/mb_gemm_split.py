@@ -1,4 +1,4 @@
-"""A/B the split-operand GEMM against the fp32-activation bf16x3 GEMM on the frame's main shapes: bitwise equality + time."""
+"""(set SCP_GEMM_PROBE=1 for the cfg probe bits 0x10000 / 0x20000)  A/B the split-operand GEMM against the fp32-activation bf16x3 GEMM on the frame's main shapes: bitwise equality + time."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from scp_amd import native
@@ -38,4 +38,4 @@ for (M, N, K, act, res) in shapes:
         t_sp = timeit(lambda: native.linear_split(sa, sw, b, act, r, want="split", out_split=o2, cfg=cfg))
         line += f" | cfg{cfg:#x} {t_new:8.1f} us ({6.0*M*N*K/t_new/1e6:6.0f} TF) split-out {t_sp:8.1f} eq={ok},{ok2},{padz}" + ("" if ok else f" maxdiff {(out-ref).abs().max().item():.3e}")
     print(line, flush=True)
-    del a, w, b, r, ref, out, sa, o2
+    del a, w, b, r, ref, out, sa
