@@ -136,7 +136,6 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__rest
     if (nk > 1) issue(1, pa2[1], pbh2[1], pbl2[1]);
     commit(0, pa2[0], pbh2[0], pbl2[0]);
     __syncthreads();
-#pragma unroll 2
     for (int kt = 0; kt < nk; ++kt) {
         // register set (kt & 1) is free again (tile kt went to LDS one iteration ago): refill it with tile kt + 2
         if (kt + 2 < nk) { if (kt & 1) issue(kt + 2, pa2[1], pbh2[1], pbl2[1]); else issue(kt + 2, pa2[0], pbh2[0], pbl2[0]); }
