@@ -272,6 +272,13 @@ SCP_API int int_get(void *codes, int i);
  * PSNR = 10 log10(3 peak^2 / max(mean d2_ab, mean d2_ba)). */
 SCP_API int scp_nn_sqdist_f64(const double *a, int64_t na, const double *b, int64_t nb, double *d2, void *stream);
 
+/* Input stage of the packed EHEM forward: embeddings of dgcnn.py:121-128 fused with the packed layout's input gather.
+ * ctx u8 [T][12] = 4 x (level, octant, occ) (scp_geom_context_ehem), pos f32 [T][3], inmap i64 [rows] (== n_tokens: pad token);
+ * tables occ_enc [256][16], level_enc [*][4], octant_enc [*][4]; out x f32 [rows][80], pos_out f32 [rows][3], occ_self i64 [rows]. */
+SCP_API int scp_embed_gather(const uint8_t *ctx, const float *pos, const int64_t *inmap, int64_t n_tokens, const float *occ_enc,
+                     const float *level_enc, const float *octant_enc, float *x, float *pos_out, int64_t *occ_self, int64_t rows,
+                     void *stream);
+
 /* ---- index maps of the packed ("varlen") EHEM forward ------------------------------------------------------------------
  * lengths[W] (host): the window lengths of one packed chunk (encode.py:109-136 cuts every level into windows of <= 8192 nodes).
  * scp_packed_plan_sizes: rows of the 11 layouts (self stages 0..4, cross stages 0..3, even outputs, odd outputs; every window

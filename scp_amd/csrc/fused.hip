@@ -115,3 +115,56 @@ extern "C" SCP_API int scp_gather_rows(const float *src, int64_t lds, const int6
     LAUNCH_CHECK();
     return SCP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Input stage of the packed EHEM forward (dgcnn.py:121-128 embeddings + the packed layout's input gather) in one kernel:
+//   row r of the packed layout takes token t = inmap[r] of the frame arrays (t == n_tokens: the pad token (level 0, octant 0,
+//   occ 255) x 4, position 0) and gets
+//   x[r]   = [occ_enc[occ of ancestors 0..2] (3 x 16) | level_enc[level of rows 0..3] (4 x 4) | octant_enc[octant 0..3] (4 x 4)]
+//   pos[r] = position of the token, occ_self[r] = its own occupancy symbol (int64, for the even-token embedding of phase 2).
+// ctx is the compact context of stage G: uint8 [T][12] = 4 x (level, octant, occ).  One thread per 16-byte piece of x.
+__global__ __launch_bounds__(256) void embed_gather_kernel(const unsigned char *__restrict__ ctx, const float *__restrict__ pos,
+                                                          const int64_t *__restrict__ inmap, int64_t n_tokens, const float *__restrict__ occ_enc,
+                                                          const float *__restrict__ level_enc, const float *__restrict__ octant_enc,
+                                                          float *__restrict__ x, float *__restrict__ pos_out, int64_t *__restrict__ occ_self,
+                                                          int64_t rows) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= rows * 20) return;
+    const int64_t r = g / 20;
+    const int p = (int)(g - r * 20);
+    const int64_t t = inmap[r];
+    const bool pad = t >= n_tokens;
+    const unsigned char *c = ctx + (pad ? 0 : t) * 12;
+    f32x4 v;
+    if (p < 12) {            // occupancy embedding of ancestor a = p / 4 (context column 3 a + 2), 16 floats = 4 pieces
+        const int a = p >> 2;
+        const int occ = pad ? 255 : c[3 * a + 2];
+        v = *(const f32x4 *)(occ_enc + occ * 16 + 4 * (p & 3));
+    } else if (p < 16) {     // level embedding of context row a = p - 12
+        const int lv = pad ? 0 : c[3 * (p - 12)];
+        v = *(const f32x4 *)(level_enc + lv * 4);
+    } else {                 // octant embedding of context row a = p - 16
+        const int oc = pad ? 0 : c[3 * (p - 16) + 1];
+        v = *(const f32x4 *)(octant_enc + oc * 4);
+    }
+    *(f32x4 *)(x + r * 80 + 4 * p) = v;
+    if (p == 0) {
+        occ_self[r] = pad ? 255 : c[11];
+        pos_out[3 * r] = pad ? 0.f : pos[3 * t];
+        pos_out[3 * r + 1] = pad ? 0.f : pos[3 * t + 1];
+        pos_out[3 * r + 2] = pad ? 0.f : pos[3 * t + 2];
+    }
+}
+
+extern "C" SCP_API int scp_embed_gather(const uint8_t *ctx, const float *pos, const int64_t *inmap, int64_t n_tokens, const float *occ_enc,
+                                        const float *level_enc, const float *octant_enc, float *x, float *pos_out, int64_t *occ_self,
+                                        int64_t rows, void *stream) {
+    if (!ctx || !pos || !inmap || !occ_enc || !level_enc || !octant_enc || !x || !pos_out || !occ_self || rows < 0 || n_tokens <= 0 ||
+        (((uintptr_t)occ_enc | (uintptr_t)level_enc | (uintptr_t)octant_enc | (uintptr_t)x) & 15))
+        return SCP_EINVAL;
+    if (rows == 0) return SCP_OK;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)cdiv64(rows * 20, 256)), dim3(256), 0, (hipStream_t)stream, ctx, pos, inmap, n_tokens,
+                       occ_enc, level_enc, octant_enc, x, pos_out, occ_self, rows);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}

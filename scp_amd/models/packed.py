@@ -202,13 +202,20 @@ def ehem_phase1_packed(model, ctx, pos, plan):
     d = plan.d
     g = model.geo_feat_generator
     dev = ctx.device
-    pad_ctx = torch.tensor([[0, 0, 255] * 4], dtype=ctx.dtype, device=dev)
-    ctx0 = torch.cat((ctx, pad_ctx))[d["inmap"]].long()                      # [P0,12]
-    pos0 = torch.cat((pos, torch.zeros((1, 3), dtype=pos.dtype, device=dev)))[d["inmap"]].contiguous()
-    P0 = ctx0.shape[0]
-    x = torch.cat((F.embedding(ctx0[:, 2:11:3], g.occ_enc.weight).reshape(P0, -1),
-                   F.embedding(ctx0[:, 0::3], g.level_enc.weight).reshape(P0, -1),
-                   F.embedding(ctx0[:, 1::3], g.octant_enc.weight).reshape(P0, -1)), 1)
+    fused_in = (ctx.dtype == torch.uint8 and g.occ_enc.weight.shape[1] == 16 and g.level_enc.weight.shape[1] == 4
+                and g.octant_enc.weight.shape[1] == 4)
+    if fused_in:   # gather into the packed layout + the three embedding lookups in one kernel
+        x, pos0, occ_self = native.embed_gather(ctx, pos, d["inmap"], g.occ_enc.weight, g.level_enc.weight, g.octant_enc.weight)
+        P0 = x.shape[0]
+    else:
+        pad_ctx = torch.tensor([[0, 0, 255] * 4], dtype=ctx.dtype, device=dev)
+        ctx0 = torch.cat((ctx, pad_ctx))[d["inmap"]].long()                      # [P0,12]
+        pos0 = torch.cat((pos, torch.zeros((1, 3), dtype=pos.dtype, device=dev)))[d["inmap"]].contiguous()
+        P0 = ctx0.shape[0]
+        x = torch.cat((F.embedding(ctx0[:, 2:11:3], g.occ_enc.weight).reshape(P0, -1),
+                       F.embedding(ctx0[:, 0::3], g.level_enc.weight).reshape(P0, -1),
+                       F.embedding(ctx0[:, 1::3], g.octant_enc.weight).reshape(P0, -1)), 1)
+        occ_self = ctx0[:, 11]
     ktab = d["knn_tab"]
     pos1 = _edge_conv_packed(g.conv1, pos0, ktab)
     pos2 = _edge_conv_packed(g.conv2, torch.cat((pos1, x), 1), ktab)
@@ -229,7 +236,7 @@ def ehem_phase1_packed(model, ctx, pos, plan):
     a1 = native.split_rows(feat_a, idx=d["a1map"])
     a2 = native.gather_rows(feat_a, d["a2map"], torch.empty((Q0, 256), dtype=torch.float32, device=dev))
     prob1 = leaky_mlp3_s(model.prob_pred_mlp1, a1)
-    return prob1[d["even_rows"]], dict(a1=a1, a2=a2, pre_occ=ctx0[d["a1map"], 11])
+    return prob1[d["even_rows"]], dict(a1=a1, a2=a2, pre_occ=occ_self[d["a1map"]])
 
 
 @torch.no_grad()

@@ -74,6 +74,7 @@ def lib():
         "scp_set_attention_mode": (C.c_int, [i32]),
         "scp_set_knn_mode": (C.c_int, [i32]),
         "scp_nn_sqdist_f64": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp]),
+        "scp_embed_gather": (C.c_int, [_vp, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp]),
         "scp_packed_plan_sizes": (C.c_int, [_vp, i32, _vp]),
         "scp_packed_plan": (C.c_int, [_vp, i32, _vp, _vp, i32, _vp]),
         "scp_edge_gather_max": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
@@ -292,6 +293,19 @@ def _dev_f64(t):
     if not t.is_cuda:
         raise ScpError("device tensor required (there is no CPU path in the product)")
     return t.to(torch.float64).contiguous()
+
+
+def embed_gather(ctx, pos, inmap, occ_enc, level_enc, octant_enc):
+    """ctx uint8 [T,12], pos f32 [T,3], inmap int64 [rows] -> (x f32 [rows,80], pos f32 [rows,3], occ_self int64 [rows])."""
+    rows = inmap.shape[0]
+    dev = ctx.device
+    x = torch.empty((rows, 80), dtype=torch.float32, device=dev)
+    p = torch.empty((rows, 3), dtype=torch.float32, device=dev)
+    o = torch.empty((rows,), dtype=torch.int64, device=dev)
+    _check(lib().scp_embed_gather(_dev(ctx, torch.uint8), _dev(pos, torch.float32), _dev(inmap, torch.int64), ctx.shape[0], _dev(occ_enc),
+                                  _dev(level_enc), _dev(octant_enc), x.data_ptr(), p.data_ptr(), o.data_ptr(), rows, _stream()),
+           "scp_embed_gather")
+    return x, p, o
 
 
 def packed_plan(lengths, device):
