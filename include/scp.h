@@ -157,6 +157,10 @@ SCP_API int scp_knn_topk_packed_bounded(const float *x, const int32_t *ctab, int
  * sel = max when scale[c] >= 0 else min  (== max over j of BN(conv(edge feature)), dgcnn.py:62-71,132-134) */
 SCP_API int scp_edge_gather_max(const float *u, const float *v, const int32_t *idx, const float *scale, const float *shift,
                         int32_t B, int32_t n, int32_t Cout, int32_t k, float *out, int32_t out_stride, void *stream);
+/* the same with explicit row strides of u and v (floats): the two halves of one [n][2 Cout] product need no copies */
+SCP_API int scp_edge_gather_max_ld(const float *u, int64_t ldu, const float *v, int64_t ldv, const int32_t *idx, const float *scale,
+                           const float *shift, int32_t B, int32_t n, int32_t Cout, int32_t k, float *out, int32_t out_stride,
+                           void *stream);
 
 /* 1-D Swin window attention (window 512, 4 heads x 64): q [B][Lp][ldq], k,v [B][Lp][ldkv] already projected
  * (row strides in floats, >= 256: the operands may be column slices of a fused QKV buffer), Lp a

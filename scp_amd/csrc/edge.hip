@@ -11,23 +11,24 @@
 __global__ __launch_bounds__(256) void edge_gather_max_kernel(const float *__restrict__ u, const float *__restrict__ v,
                                                              const int *__restrict__ idx, const float *__restrict__ scale,
                                                              const float *__restrict__ shift, int n, int Cout, int k,
-                                                             float *__restrict__ out, int out_stride, int64_t total /* B*n*Cout/4 */) {
+                                                             float *__restrict__ out, int out_stride, int64_t total /* B*n*Cout/4 */,
+                                                             int64_t ldu, int64_t ldv) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= total) return;
     const int c4 = Cout >> 2;
     const int64_t pt = g / c4;          // global point index b*n + i
     const int c = (int)(g - pt * c4) * 4;
     const int64_t b = pt / n;
-    const float *ub = u + b * (int64_t)n * Cout;
+    const float *ub = u + b * (int64_t)n * ldu;
     const int *nb = idx + pt * k;
     float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
     for (int j = 0; j < k; ++j) {
-        const float4 a = *(const float4 *)(ub + (int64_t)nb[j] * Cout + c);
+        const float4 a = *(const float4 *)(ub + (int64_t)nb[j] * ldu + c);
         mx.x = fmaxf(mx.x, a.x); mx.y = fmaxf(mx.y, a.y); mx.z = fmaxf(mx.z, a.z); mx.w = fmaxf(mx.w, a.w);
         mn.x = fminf(mn.x, a.x); mn.y = fminf(mn.y, a.y); mn.z = fminf(mn.z, a.z); mn.w = fminf(mn.w, a.w);
     }
-    const float4 vi = *(const float4 *)(v + pt * Cout + c);
+    const float4 vi = *(const float4 *)(v + pt * ldv + c);
     const float4 sc = *(const float4 *)(scale + c), sh = *(const float4 *)(shift + c);
     float4 r;
 #define FIN(f) { const float y = __fadd_rn(__fmul_rn(sc.f, __fadd_rn(sc.f >= 0.f ? mx.f : mn.f, vi.f)), sh.f); r.f = y > 0.f ? y : __fmul_rn(0.2f, y); }
@@ -36,14 +37,21 @@ __global__ __launch_bounds__(256) void edge_gather_max_kernel(const float *__res
     *(float4 *)(out + pt * out_stride + c) = r;
 }
 
-extern "C" int scp_edge_gather_max(const float *u, const float *v, const int32_t *idx, const float *scale, const float *shift,
-                                   int32_t B, int32_t n, int32_t Cout, int32_t k, float *out, int32_t out_stride, void *stream) {
+// u, v with explicit row strides (e.g. the two halves of one [n][2 Cout] GEMM output, no copies)
+extern "C" SCP_API int scp_edge_gather_max_ld(const float *u, int64_t ldu, const float *v, int64_t ldv, const int32_t *idx, const float *scale,
+                                              const float *shift, int32_t B, int32_t n, int32_t Cout, int32_t k, float *out, int32_t out_stride,
+                                              void *stream) {
     if (!u || !v || !idx || !scale || !shift || !out || B <= 0 || n <= 0 || Cout <= 0 || (Cout & 3) || k <= 0 || out_stride < Cout ||
-        (out_stride & 3) || ((uintptr_t)out & 15))
+        (out_stride & 3) || ldu < Cout || ldv < Cout || (ldu & 3) || (ldv & 3) || (((uintptr_t)out | (uintptr_t)u | (uintptr_t)v) & 15))
         return SCP_EINVAL;
     const int64_t total = (int64_t)B * n * (Cout / 4);
     hipLaunchKernelGGL(edge_gather_max_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, u, v, idx, scale,
-                       shift, n, Cout, k, out, out_stride, total);
+                       shift, n, Cout, k, out, out_stride, total, ldu, ldv);
     LAUNCH_CHECK();
     return SCP_OK;
+}
+
+extern "C" int scp_edge_gather_max(const float *u, const float *v, const int32_t *idx, const float *scale, const float *shift,
+                                   int32_t B, int32_t n, int32_t Cout, int32_t k, float *out, int32_t out_stride, void *stream) {
+    return scp_edge_gather_max_ld(u, Cout, v, Cout, idx, scale, shift, B, n, Cout, k, out, out_stride, stream);
 }

@@ -161,9 +161,7 @@ def _edge_conv_packed(conv, feat, ktab):
     feat = feat.contiguous()
     idx = native.knn_topk_packed(feat, ktab)
     uv = linear(feat, Wuv, None, exact=True)
-    u = uv[:, :Cout].contiguous()
-    v = uv[:, Cout:].contiguous()
-    return native.edge_gather_max(u[None], v[None], idx[None], scale, shift)[0]
+    return native.edge_gather_max_rows(uv[:, :Cout], uv[:, Cout:], idx, scale, shift)
 
 
 def geo_feat_forward(g, ctx, pos):

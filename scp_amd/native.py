@@ -74,6 +74,7 @@ def lib():
         "scp_set_attention_mode": (C.c_int, [i32]),
         "scp_set_knn_mode": (C.c_int, [i32]),
         "scp_nn_sqdist_f64": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp]),
+        "scp_edge_gather_max_ld": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_embed_gather": (C.c_int, [_vp, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp]),
         "scp_packed_plan_sizes": (C.c_int, [_vp, i32, _vp]),
         "scp_packed_plan": (C.c_int, [_vp, i32, _vp, _vp, i32, _vp]),
@@ -338,6 +339,15 @@ def packed_plan(lengths, device):
              self_tab=[t[f"tab{l}"] for l in range(5)], cross_tab=[t[f"tab{l}"] for l in range(5, 9)], knn_tab=t["knn_tab"],
              self_valid=[t[f"valid{l}"] for l in range(5)], cross_valid=[t[f"valid{l}"] for l in range(5, 9)])
     return r, d
+
+
+def edge_gather_max_rows(u, v, idx, scale, shift):
+    """packed form: u, v f32 [n, C'] VIEWS with unit channel stride (any row stride), idx int32 [n, k] -> out f32 [n, C']."""
+    n, Co = u.shape
+    out = torch.empty((n, Co), dtype=torch.float32, device=u.device)
+    _check(lib().scp_edge_gather_max_ld(u.data_ptr(), u.stride(0), v.data_ptr(), v.stride(0), _dev(idx, torch.int32), _dev(scale), _dev(shift),
+                                        1, n, Co, idx.shape[1], out.data_ptr(), Co, _stream()), "scp_edge_gather_max_ld")
+    return out
 
 
 def set_knn_mode(f16x3):
