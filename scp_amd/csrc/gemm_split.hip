@@ -72,6 +72,8 @@ struct GemmSplitArgs {
     const __bf16 *Whi, *Wlo; int Kpad;           // weight planes [Npad][Kpad], zero padded, Npad % 256 == 0, Kpad % 32 == 0
     const float *bias;                           // [N] or null
     const float *res; int64_t ldr;               // fp32 residual [M][ldr] or null
+    const int64_t *res_map;                      // optional: row m adds residual row res_map[m] (gathered residual)
+    int res_first;                               // 1: activation AFTER the residual add, act(A.W^T + bias + residual)
     float *C; int64_t ldc;                       // fp32 output or null
     __bf16 *Ohi, *Olo; int64_t ldo;              // split output planes or null
     int M, N;
@@ -257,7 +259,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                 for (int it = 0; it < 8; ++it) {
                     const int m = mb + 4 * it;
                     const int mc = m < a.M ? m : a.M - 1;
-                    rr[it] = *(const f32x4 *)(a.res + (int64_t)mc * a.ldr + nb);
+                    const int64_t rrow = a.res_map ? a.res_map[mc] : (int64_t)mc;
+                    rr[it] = *(const f32x4 *)(a.res + rrow * a.ldr + nb);
                 }
             }
 #pragma unroll
@@ -265,7 +268,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ml = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    stg[ml * 64 + j * 32 + col] = apply_act_s<ACT>(acc[i][j][r] + bv[j]);
+                    const float t0 = acc[i][j][r] + bv[j];
+                    stg[ml * 64 + j * 32 + col] = a.res_first ? t0 : apply_act_s<ACT>(t0);
                 }
             if (full) {
 #pragma unroll
@@ -273,6 +277,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                     const int m = mb + 4 * it;
                     f32x4 y = *(const f32x4 *)(stg + (4 * it + rsub) * 64 + c4);
                     if (has_res) y += rr[it];
+                    if (a.res_first) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) y[u] = apply_act_s<ACT>(y[u]);
+                    }
                     if (has_c) { if (m < a.M) *(f32x4 *)(a.C + (int64_t)m * a.ldc + nb) = y; }
                     if (has_o) {
                         bf16x4 hi, lo;
@@ -295,7 +303,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                     if (m >= a.M) continue;
                     for (int u = 0; u < 4; ++u) {
                         if (nb + u < a.N) {
-                            if (has_res) y[u] += a.res[(int64_t)m * a.ldr + nb + u];
+                            if (has_res) y[u] += a.res[(a.res_map ? a.res_map[m] : (int64_t)m) * a.ldr + nb + u];
+                            if (a.res_first) y[u] = apply_act_s<ACT>(y[u]);
                             if (has_c) a.C[(int64_t)m * a.ldc + nb + u] = y[u];
                         } else y[u] = 0.f;
                     }
@@ -379,9 +388,9 @@ static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st) {
     return SCP_OK;
 }
 
-extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
-                                        const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, void *Ohi, void *Olo,
-                                        int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream) {
+static int linear_split_impl(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
+                             const float *bias, const float *residual, int64_t ldr, const int64_t *res_map, int32_t res_first, float *C, int64_t ldc,
+                             void *Ohi, void *Olo, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream) {
     if (!Ahi || !Alo || !Whi || !Wlo || (!C && !Ohi) || ((Ohi == nullptr) != (Olo == nullptr)) || M <= 0 || N <= 0 || K <= 0 || (lda & 7) ||
         Kpad < K || (Kpad & 31) || lda < Kpad || (Npad & 255) || Npad < N || act < 0 || act > 3 || (C && ldc < N) ||
         (residual && ldr < N) || (Ohi && ((ldo & 7) || ldo < N)) ||
@@ -399,6 +408,7 @@ extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_
     ga.Ahi = (const __bf16 *)Ahi; ga.Alo = (const __bf16 *)Alo; ga.lda = lda;
     ga.Whi = (const __bf16 *)Whi; ga.Wlo = (const __bf16 *)Wlo; ga.Kpad = Kpad;
     ga.bias = bias; ga.res = residual; ga.ldr = ldr; ga.C = C; ga.ldc = ldc;
+    ga.res_map = residual ? res_map : nullptr; ga.res_first = (residual && res_first) ? 1 : 0;
     ga.Ohi = (__bf16 *)Ohi; ga.Olo = (__bf16 *)Olo; ga.ldo = ldo; ga.M = M; ga.N = N;
     int nco = (N + 31) & ~31;
     if (nco > ldo) nco = (N + 3) & ~3;
@@ -420,4 +430,20 @@ extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_
     if (cfg == 2) return launch_cfg<4, 2, 2>(ga, act, st);
     if (cfg == 3) return launch_cfg<2, 2, 2>(ga, act, st);   // 128 x 128, 4 waves, two workgroups per CU
     return launch_cfg<2, 4, 4>(ga, act, st);
+}
+
+extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
+                                        const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, void *Ohi, void *Olo,
+                                        int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream) {
+    return linear_split_impl(Ahi, Alo, lda, Whi, Wlo, Npad, Kpad, bias, residual, ldr, nullptr, 0, C, ldc, Ohi, Olo, ldo, M, N, K, act, cfg, stream);
+}
+
+// the same with a GATHERED residual added BEFORE the activation: out[m] = act(A[m] . W^T + bias + residual[res_map[m]]).
+// Lets a layer whose input is a concatenation of per-stage features sampled at token >> s (concat_states, ehem.py:75-86) run as one
+// small product per stage at the stage's own resolution, each adding the coarser stages' partial sum through the parent-row map.
+extern "C" SCP_API int scp_linear_split_gather(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad,
+                                               int32_t Kpad, const float *bias, const float *residual, int64_t ldr, const int64_t *res_map, float *C,
+                                               int64_t ldc, void *Ohi, void *Olo, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act,
+                                               int32_t cfg, void *stream) {
+    return linear_split_impl(Ahi, Alo, lda, Whi, Wlo, Npad, Kpad, bias, residual, ldr, res_map, 1, C, ldc, Ohi, Olo, ldo, M, N, K, act, cfg, stream);
 }

@@ -175,6 +175,8 @@ extern "C" SCP_API int scp_packed_plan(const int64_t *lengths, int32_t W, int64_
     for (int l = 0; l < 9; ++l) add(PK_TAB, l, 0, 0, rows[l] / 512);
     add(PK_TAB_REAL, 0, 0, 0, rows[0] / 512);
     for (int l = 0; l < 9; ++l) add(PK_VALID, l, 0, 0, rows[l]);
+    for (int s = 0; s < 4; ++s) add(PK_CONCAT, s, s + 1, 1, rows[s]);        // parent rows: stage s token t -> stage s + 1 token t >> 1
+    for (int s = 5; s < 8; ++s) add(PK_CONCAT, s, s + 1, 1, rows[s]);
     if (nj != n_outs) return SCP_EINVAL;
     a.njobs = nj;
     // the host image must outlive the async copy: pageable-memory hipMemcpyAsync returns after staging, but be explicit

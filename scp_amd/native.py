@@ -85,6 +85,7 @@ def lib():
         "scp_linear_bf16x3": (C.c_int, [_vp, i64, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp]),
         "scp_linear_split": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_split_rows": (C.c_int, [_vp, i64, i64, _vp, i32, _vp, _vp, i64, i64, _vp]),
+        "scp_linear_split_gather": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_layernorm_rows": (C.c_int, [_vp, i64, i64, _vp, _vp, i32, _vp, _vp, _vp, C.c_float, _vp, i64, i64, _vp]),
         "scp_layernorm_rows_split": (C.c_int, [_vp, i64, i64, _vp, _vp, i32, _vp, _vp, _vp, C.c_float, _vp, _vp, i64, i64, _vp]),
         "scp_gather_rows": (C.c_int, [_vp, i64, _vp, i32, _vp, i64, i64, _vp]),
@@ -328,6 +329,7 @@ def packed_plan(lengths, device):
     spec += [(f"sc{s_}", i64, (r[0],)) for s_ in range(1, 5)] + [(f"cc{s_}", i64, (r[5],)) for s_ in range(1, 4)]
     spec += [(f"tab{l}", i32, (r[l] // 512, 2)) for l in range(9)] + [("knn_tab", i32, (r[0] // 512, 2))]
     spec += [(f"valid{l}", f32, (r[l], 1)) for l in range(9)]
+    spec += [(f"sp{s_}", i64, (r[s_],)) for s_ in range(4)] + [(f"cp{s_}", i64, (r[5 + s_],)) for s_ in range(3)]
     t = {name: torch.empty(shape, dtype=dt, device=device) for name, dt, shape in spec}
     ptrs = (C.c_void_p * len(spec))(*[t[name].data_ptr() for name, _, _ in spec])
     scratch = torch.empty((36 * W,), dtype=torch.int64, device=device)
@@ -337,7 +339,8 @@ def packed_plan(lengths, device):
              self_merge=[(t[f"sme{s_}"], t[f"smo{s_}"]) for s_ in range(4)], cross_merge=[(t[f"cme{s_}"], t[f"cmo{s_}"]) for s_ in range(3)],
              self_concat=[t[f"sc{s_}"] for s_ in range(1, 5)], cross_concat=[t[f"cc{s_}"] for s_ in range(1, 4)],
              self_tab=[t[f"tab{l}"] for l in range(5)], cross_tab=[t[f"tab{l}"] for l in range(5, 9)], knn_tab=t["knn_tab"],
-             self_valid=[t[f"valid{l}"] for l in range(5)], cross_valid=[t[f"valid{l}"] for l in range(5, 9)])
+             self_valid=[t[f"valid{l}"] for l in range(5)], cross_valid=[t[f"valid{l}"] for l in range(5, 9)],
+             self_parent=[t[f"sp{s_}"] for s_ in range(4)], cross_parent=[t[f"cp{s_}"] for s_ in range(3)])
     return r, d
 
 
@@ -471,7 +474,7 @@ def split_rows(x, idx=None, out=None):
     return out
 
 
-def linear_split(a, sw, bias=None, act=ACT_NONE, residual=None, out=None, out_split=None, want="f32", cfg=0):
+def linear_split(a, sw, bias=None, act=ACT_NONE, residual=None, out=None, out_split=None, want="f32", cfg=0, res_map=None, res_first=False):
     """a SplitAct [M, K] -> act(a @ W.T + bias) + residual as fp32 [M, N] (want "f32"), as SplitAct (want "split") or both
     (want "both": returns (fp32, SplitAct)).  out / out_split may be column slices of wider buffers."""
     M, N, K = a.M, sw.N, sw.K
@@ -484,6 +487,16 @@ def linear_split(a, sw, bias=None, act=ACT_NONE, residual=None, out=None, out_sp
     if want in ("split", "both"):
         o = out_split if out_split is not None else SplitAct.empty(M, N, t.device)
     r2 = residual
+    if res_map is not None or res_first:
+        # out[m] = act(a[m] . W^T + bias + residual[res_map[m]]): gathered residual, added before the activation
+        rc = lib().scp_linear_split_gather(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.Npad, sw.Kpad,
+                                           _opt(bias), None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0),
+                                           None if res_map is None else _dev(res_map, torch.int64),
+                                           None if c is None else c.data_ptr(), 0 if c is None else c.stride(0),
+                                           None if o is None else o.t[0].data_ptr(), None if o is None else o.t[1].data_ptr(),
+                                           0 if o is None else o.t.stride(1), M, N, K, act, cfg, _stream())
+        _check(rc, "scp_linear_split_gather")
+        return c if want == "f32" else (o if want == "split" else (c, o))
     rc = lib().scp_linear_split(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.Npad, sw.Kpad, _opt(bias),
                                 None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0),
                                 None if c is None else c.data_ptr(), 0 if c is None else c.stride(0),

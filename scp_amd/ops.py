@@ -59,15 +59,16 @@ def linear(x, w, b=None, act=None, residual=None, exact=False):
     return y if residual is None else y + residual
 
 
-def linear_s(a, w, b=None, act=None, residual=None, want="f32", out=None, out_split=None):
+def linear_s(a, w, b=None, act=None, residual=None, want="f32", out=None, out_split=None, res_map=None, res_first=False):
     """The same layer on a pre-split activation (native.SplitAct): operands go global -> LDS by LDS-DMA (csrc/gemm_split.hip).
     want: "f32" -> fp32 [M, N] (optionally into `out`, which may be a column slice), "split" -> SplitAct for the next layer."""
     N = w.shape[0]
     if want == "f32" and out is None and N % 4:
         # rows must be 16-byte aligned for the vector epilogue: pad the row stride, hand back the [M, N] view
         buf = torch.empty((a.M, -(-N // 4) * 4), dtype=torch.float32, device=a.t.device)
-        return native.linear_split(a, _split(w), b, _ACT[act], residual, out=buf, want="f32")[:, :N]
-    return native.linear_split(a, _split(w), b, _ACT[act], residual, out=out, out_split=out_split, want=want)
+        return native.linear_split(a, _split(w), b, _ACT[act], residual, out=buf, want="f32", res_map=res_map, res_first=res_first)[:, :N]
+    return native.linear_split(a, _split(w), b, _ACT[act], residual, out=out, out_split=out_split, want=want, res_map=res_map,
+                               res_first=res_first)
 
 
 def leaky_mlp3_s(seq, a, want="f32", out=None, out_split=None):
