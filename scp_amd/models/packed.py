@@ -117,6 +117,7 @@ class PackedPlan:
             even_dst=coded[we] + te, odd_dst=coded[wo] + ne[wo] + to,
             self_merge=[_merge_maps(self.self_layouts[s], self.self_layouts[s + 1]) for s in range(n_self - 1)],
             cross_merge=[_merge_maps(self.cross_layouts[s], self.cross_layouts[s + 1]) for s in range(n_cross - 1)],
+            # (stage-s row of stage-0 token t >> s: the direct form of concat_states; the forward now uses the parent maps below)
             self_concat=[_concat_map(P0, self.self_layouts[s], s) for s in range(1, n_self)],
             cross_concat=[_concat_map(Q0, self.cross_layouts[s], s) for s in range(1, n_cross)],
             self_tab=[l.table() for l in self.self_layouts], cross_tab=[l.table() for l in self.cross_layouts],
@@ -181,21 +182,6 @@ def _encoder(enc, x, valids, tabs, merges, query=None):
             if query is not None:
                 query = _merge(stage.downsample, query, merges[s])
     return hs
-
-
-def _concat(hs, cmaps, extra=None):
-    """concat_states (ehem.py:75-86): stage s is gathered at token >> s straight into its 256-column slot of a split (bf16 hi/lo)
-    buffer - the operand of the MLP that follows; `extra` = (src, map) appends one more gathered slot (the odd-token features of
-    the cross branch, ehem.py:124)."""
-    n = len(hs) - 1 + (1 if extra is not None else 0)
-    out = native.SplitAct.empty(hs[1].shape[0], 256 * n, hs[1].device)
-    native.split_rows(hs[1], out=out.cols(0, 256))
-    for s in range(1, len(hs) - 1):
-        native.split_rows(hs[s + 1], idx=cmaps[s - 1], out=out.cols(256 * s, 256 * (s + 1)))
-    if extra is not None:
-        k = len(hs) - 1
-        native.split_rows(extra[0], idx=extra[1], out=out.cols(256 * k, 256 * (k + 1)))
-    return out
 
 
 def _concat_layer(lin, hs, parents, extra=None):
