@@ -194,6 +194,10 @@ SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_t lda, cons
 SCP_API int scp_linear_split_gather(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
                             const float *bias, const float *residual, int64_t ldr, const int64_t *res_map, float *C, int64_t ldc, void *Ohi,
                             void *Olo, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream);
+/* scp_linear_split with SCATTERED fp32 output rows: row m goes to C row out_map[m] (negative: dropped). */
+SCP_API int scp_linear_split_scatter(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
+                             const float *bias, const int64_t *out_map, float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act,
+                             int32_t cfg, void *stream);
 SCP_API int scp_split_rows(const float *src, int64_t ld_src, int64_t n_src, const int64_t *idx, int32_t C, void *hi, void *lo, int64_t ldo,
                    int64_t rows, void *stream);
 /* producers that write the split format directly (same arithmetic as their fp32 forms, then hi = bf16(y), lo = bf16(y - hi)) */
@@ -291,12 +295,13 @@ SCP_API int scp_embed_gather(const uint8_t *ctx, const float *pos, const int64_t
 /* ---- index maps of the packed ("varlen") EHEM forward ------------------------------------------------------------------
  * lengths[W] (host): the window lengths of one packed chunk (encode.py:109-136 cuts every level into windows of <= 8192 nodes).
  * scp_packed_plan_sizes: rows of the 11 layouts (self stages 0..4, cross stages 0..3, even outputs, odd outputs; every window
- * padded to x512 rows per Swin stage).  scp_packed_plan: writes all 54 maps in one launch; outs[] = device buffers in this order:
+ * padded to x512 rows per Swin stage).  scp_packed_plan: writes all 56 maps in one launch; outs[] = device buffers in this order:
  *   inmap i64[rows0]; a1map, a2map i64[rowsX0]; even_rows i64[E]; odd_rows i64[O]; even_dst i64[E]; odd_dst i64[O];
  *   self merge (even, odd) i64[rows s+1] for s = 0..3; cross merge (even, odd) for s = 0..2; self concat i64[rows0] for s = 1..4;
  *   cross concat i64[rowsX0] for s = 1..3; window tables i32[rows/512][2] (base, padded length) of the 9 stage layouts;
  *   kNN table i32[rows0/512][2] (base, real length); valid f32[rows] of the 9 stage layouts; parent-row maps i64[rows s] (stage s
- *   token t -> stage s+1 token t >> 1) for self s = 0..3 and cross s = 0..2.
+ *   token t -> stage s+1 token t >> 1) for self s = 0..3 and cross s = 0..2; coded positions i64[rowsX0] of the even / odd token
+ *   of every cross-stage-0 row (-1 for padding rows).
  * Replaces the per-window Python bookkeeping of models/ehem.py:88-136 / swin_transformer.py:350-367,638-641 in the packed forward;
  * tables_dev: int64 scratch of 36 * W entries. */
 SCP_API int scp_packed_plan_sizes(const int64_t *lengths, int32_t W, int64_t *rows_out);

@@ -74,6 +74,7 @@ struct GemmSplitArgs {
     const float *res; int64_t ldr;               // fp32 residual [M][ldr] or null
     const int64_t *res_map;                      // optional: row m adds residual row res_map[m] (gathered residual)
     int res_first;                               // 1: activation AFTER the residual add, act(A.W^T + bias + residual)
+    const int64_t *out_map;                      // optional: fp32 row m is written to C row out_map[m] (< 0: dropped)
     float *C; int64_t ldc;                       // fp32 output or null
     __bf16 *Ohi, *Olo; int64_t ldo;              // split output planes or null
     int M, N;
@@ -281,7 +282,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
 #pragma unroll
                         for (int u = 0; u < 4; ++u) y[u] = apply_act_s<ACT>(y[u]);
                     }
-                    if (has_c) { if (m < a.M) *(f32x4 *)(a.C + (int64_t)m * a.ldc + nb) = y; }
+                    if (has_c && m < a.M) {
+                        const int64_t orow = a.out_map ? a.out_map[m] : (int64_t)m;
+                        if (orow >= 0) *(f32x4 *)(a.C + orow * a.ldc + nb) = y;
+                    }
                     if (has_o) {
                         bf16x4 hi, lo;
 #pragma unroll
@@ -305,7 +309,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                         if (nb + u < a.N) {
                             if (has_res) y[u] += a.res[(a.res_map ? a.res_map[m] : (int64_t)m) * a.ldr + nb + u];
                             if (a.res_first) y[u] = apply_act_s<ACT>(y[u]);
-                            if (has_c) a.C[(int64_t)m * a.ldc + nb + u] = y[u];
+                            if (has_c) {
+                                const int64_t orow = a.out_map ? a.out_map[m] : (int64_t)m;
+                                if (orow >= 0) a.C[orow * a.ldc + nb + u] = y[u];
+                            }
                         } else y[u] = 0.f;
                     }
                     if (has_o && nb < a.ncols_out) {
@@ -389,7 +396,7 @@ static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st) {
 }
 
 static int linear_split_impl(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
-                             const float *bias, const float *residual, int64_t ldr, const int64_t *res_map, int32_t res_first, float *C, int64_t ldc,
+                             const float *bias, const float *residual, int64_t ldr, const int64_t *res_map, int32_t res_first, const int64_t *out_map, float *C, int64_t ldc,
                              void *Ohi, void *Olo, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream) {
     if (!Ahi || !Alo || !Whi || !Wlo || (!C && !Ohi) || ((Ohi == nullptr) != (Olo == nullptr)) || M <= 0 || N <= 0 || K <= 0 || (lda & 7) ||
         Kpad < K || (Kpad & 31) || lda < Kpad || (Npad & 255) || Npad < N || act < 0 || act > 3 || (C && ldc < N) ||
@@ -409,6 +416,7 @@ static int linear_split_impl(const void *Ahi, const void *Alo, int64_t lda, cons
     ga.Whi = (const __bf16 *)Whi; ga.Wlo = (const __bf16 *)Wlo; ga.Kpad = Kpad;
     ga.bias = bias; ga.res = residual; ga.ldr = ldr; ga.C = C; ga.ldc = ldc;
     ga.res_map = residual ? res_map : nullptr; ga.res_first = (residual && res_first) ? 1 : 0;
+    ga.out_map = C ? out_map : nullptr;
     ga.Ohi = (__bf16 *)Ohi; ga.Olo = (__bf16 *)Olo; ga.ldo = ldo; ga.M = M; ga.N = N;
     int nco = (N + 31) & ~31;
     if (nco > ldo) nco = (N + 3) & ~3;
@@ -435,7 +443,7 @@ static int linear_split_impl(const void *Ahi, const void *Alo, int64_t lda, cons
 extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
                                         const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, void *Ohi, void *Olo,
                                         int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream) {
-    return linear_split_impl(Ahi, Alo, lda, Whi, Wlo, Npad, Kpad, bias, residual, ldr, nullptr, 0, C, ldc, Ohi, Olo, ldo, M, N, K, act, cfg, stream);
+    return linear_split_impl(Ahi, Alo, lda, Whi, Wlo, Npad, Kpad, bias, residual, ldr, nullptr, 0, nullptr, C, ldc, Ohi, Olo, ldo, M, N, K, act, cfg, stream);
 }
 
 // the same with a GATHERED residual added BEFORE the activation: out[m] = act(A[m] . W^T + bias + residual[res_map[m]]).
@@ -445,5 +453,15 @@ extern "C" SCP_API int scp_linear_split_gather(const void *Ahi, const void *Alo,
                                                int32_t Kpad, const float *bias, const float *residual, int64_t ldr, const int64_t *res_map, float *C,
                                                int64_t ldc, void *Ohi, void *Olo, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act,
                                                int32_t cfg, void *stream) {
-    return linear_split_impl(Ahi, Alo, lda, Whi, Wlo, Npad, Kpad, bias, residual, ldr, res_map, 1, C, ldc, Ohi, Olo, ldo, M, N, K, act, cfg, stream);
+    return linear_split_impl(Ahi, Alo, lda, Whi, Wlo, Npad, Kpad, bias, residual, ldr, res_map, 1, nullptr, C, ldc, Ohi, Olo, ldo, M, N, K, act, cfg, stream);
+}
+
+// the same as scp_linear_split with SCATTERED fp32 output rows: row m is written to C row out_map[m] (negative: dropped).  The last
+// layer of the probability heads writes its rows straight to their positions in the frame's coding-order table (encode.py:126-131).
+extern "C" SCP_API int scp_linear_split_scatter(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad,
+                                                int32_t Kpad, const float *bias, const int64_t *out_map, float *C, int64_t ldc, int32_t M, int32_t N,
+                                                int32_t K, int32_t act, int32_t cfg, void *stream) {
+    if (!out_map || !C) return SCP_EINVAL;
+    return linear_split_impl(Ahi, Alo, lda, Whi, Wlo, Npad, Kpad, bias, nullptr, 0, nullptr, 0, out_map, C, ldc, nullptr, nullptr, 0, M, N, K, act, cfg,
+                             stream);
 }

@@ -23,7 +23,9 @@ enum PlanKind : int32_t {
     PK_CONCAT = 9,     // [rows(stage 0)] i64: stage-s row of token t >> s
     PK_TAB = 10,       // [rows/512][2] i32: (base, padded length) of the window owning the chunk
     PK_TAB_REAL = 11,  // [rows/512][2] i32: (base, real length)
-    PK_VALID = 12      // [rows] f32: 1 for real tokens
+    PK_VALID = 12,     // [rows] f32: 1 for real tokens
+    PK_EVEN_OUT = 13,  // [rows(cross 0)] i64: coded position of the window's even token t (cstart + t), -1 beyond ceil(c/2)
+    PK_ODD_OUT = 14    // [rows(cross 0)] i64: coded position of the odd token t (cstart + ne + t), -1 beyond floor(c/2)
 };
 
 struct PlanJob {
@@ -90,6 +92,8 @@ __global__ __launch_bounds__(256) void plan_kernel(const PlanArgs a, int64_t tot
     case PK_MERGE_ODD: v = (real && 2 * t + 1 < a.len[jb.src][w]) ? a.base[jb.src][w] + 2 * t + 1 : a.rows[jb.src]; break;
     case PK_CONCAT: v = real ? a.base[jb.src][w] + (t >> jb.shift) : 0; break;
     case PK_VALID: ((float *)jb.out)[e] = real ? 1.f : 0.f; return;
+    case PK_EVEN_OUT: v = t < a.ne[w] ? a.cstart[w] + t : -1; break;
+    case PK_ODD_OUT: v = t < a.c[w] - a.ne[w] ? a.cstart[w] + a.ne[w] + t : -1; break;
     default: break;
     }
     ((int64_t *)jb.out)[e] = v;
@@ -177,6 +181,8 @@ extern "C" SCP_API int scp_packed_plan(const int64_t *lengths, int32_t W, int64_
     for (int l = 0; l < 9; ++l) add(PK_VALID, l, 0, 0, rows[l]);
     for (int s = 0; s < 4; ++s) add(PK_CONCAT, s, s + 1, 1, rows[s]);        // parent rows: stage s token t -> stage s + 1 token t >> 1
     for (int s = 5; s < 8; ++s) add(PK_CONCAT, s, s + 1, 1, rows[s]);
+    add(PK_EVEN_OUT, 5, 0, 0, rows[5]);
+    add(PK_ODD_OUT, 5, 0, 0, rows[5]);
     if (nj != n_outs) return SCP_EINVAL;
     a.njobs = nj;
     // the host image must outlive the async copy: pageable-memory hipMemcpyAsync returns after staging, but be explicit

@@ -199,16 +199,13 @@ class FrameEncoder:
         return table
 
     def logits_packed(self, pre, plan):
-        """All windows of the frame through ONE packed forward per chunk of <= max_tokens tokens (models/packed.py)."""
-        from .models.packed import PackedPlan
-        table = torch.empty((plan.n_rows, 255), dtype=torch.float32, device=self.device)
+        """All windows of the frame through ONE packed forward per chunk of <= max_tokens tokens (models/packed.py); the last layer
+        of both probability heads writes its rows straight into the coding-order table (row stride 256 floats: 16-byte rows)."""
+        full = torch.empty((plan.n_rows, 256), dtype=torch.float32, device=self.device)
         ctx, pos = pre["ctx"], pre["pos"]
         for r0, tok, pp in (pre.get("packed_plans") or self.packed_plans(plan)):
-            ev, od = self.model.forward_packed(ctx[r0:r0 + tok], pos[r0:r0 + tok], None, plan=pp)
-            table[pp.d["even_dst"] + r0] = ev
-            if od.shape[0]:
-                table[pp.d["odd_dst"] + r0] = od
-        return table
+            self.model.forward_packed(ctx[r0:r0 + tok], pos[r0:r0 + tok], None, plan=pp, table=full[r0:])
+        return full[:, :255]
 
     def packed_plans(self, plan):
         """The frame's windows cut into chunks of <= max_tokens tokens, each with its index maps: [(first row, tokens, PackedPlan)]."""

@@ -287,15 +287,16 @@ class EHEM(nn.Module):
         return self.forward_ctx(data.reshape(B, c, 12).long(), pos.transpose(1, 2).contiguous())
 
     @torch.no_grad()
-    def forward_packed(self, ctx, pos, lengths, plan=None):
+    def forward_packed(self, ctx, pos, lengths, plan=None, table=None):
         """All windows in one pass: ctx [T,12], pos [T,3] (windows back to back), lengths = window sizes.
-        Returns (even rows [sum ceil(c/2),255], odd rows [sum floor(c/2),255]); see models/packed.py."""
+        Returns (even rows [sum ceil(c/2),255], odd rows [sum floor(c/2),255]); see models/packed.py.  With `table` (fp32 view whose
+        row 0 is the chunk's first coded row, 16-byte aligned rows) the logits are written in coding order and (None, None) returns."""
         from .packed import PackedPlan, ehem_forward_packed
         if not ctx.is_cuda:
             raise native.ScpError("EHEM runs on the MI355X only (no CPU fallback)")
         if plan is None:
             plan = PackedPlan(lengths, device=ctx.device)
-        return ehem_forward_packed(self, ctx, pos, plan)
+        return ehem_forward_packed(self, ctx, pos, plan, table=table)
 
     @torch.no_grad()
     def forward_ctx(self, ctx, pos):

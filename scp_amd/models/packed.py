@@ -68,6 +68,14 @@ def _merge_maps(cur, nxt):
     return even, odd
 
 
+def _out_map(q0, counts, first):
+    """coded position of token t of every cross-stage-0 row (first[w] + t for t < counts[w], else -1)."""
+    m = torch.full((q0.rows,), -1, dtype=torch.int64, device=q0.L.device)
+    wid, t = _tokens(counts)
+    m[q0.base[wid] + t] = first[wid] + t
+    return m
+
+
 def _concat_map(l0, ls, s):
     """rows of stage-s layout `ls` that stage-0 token t of each window gathers (t >> s)."""
     m = torch.zeros(l0.rows, dtype=torch.int64, device=l0.L.device)
@@ -125,7 +133,8 @@ class PackedPlan:
             self_valid=[l.valid().contiguous() for l in self.self_layouts], cross_valid=[l.valid().contiguous() for l in self.cross_layouts],
             # parent rows: stage s token t -> stage s + 1 token t >> 1 (the hierarchical evaluation of a layer over concat_states)
             self_parent=[_concat_map(self.self_layouts[s], self.self_layouts[s + 1], 1) for s in range(n_self - 1)],
-            cross_parent=[_concat_map(self.cross_layouts[s], self.cross_layouts[s + 1], 1) for s in range(n_cross - 1)])
+            cross_parent=[_concat_map(self.cross_layouts[s], self.cross_layouts[s + 1], 1) for s in range(n_cross - 1)],
+            even_out=_out_map(Q0, ne, coded), odd_out=_out_map(Q0, no, coded + ne))
 
 
 def _swin_layer(layer, x, valid, wtab, shift, query=None):
@@ -215,10 +224,19 @@ def _mlp_over_concat(seq, hs, parents, extra=None):
     return linear_s(a, seq[4].weight, seq[4].bias)
 
 
+def _head_to_table(seq, a, out_map, table):
+    """leaky_mlp3 whose last layer writes its rows straight to their coding-order positions in `table` (rows out_map[m] >= 0)."""
+    from ..ops import _split
+    a = linear_s(a, seq[0].weight, seq[0].bias, act="leaky", want="split")
+    a = linear_s(a, seq[2].weight, seq[2].bias, act="leaky", want="split")
+    native.linear_split_scatter(a, _split(seq[4].weight), seq[4].bias, out_map, table)
+
+
 @torch.no_grad()
-def ehem_phase1_packed(model, ctx, pos, plan):
+def ehem_phase1_packed(model, ctx, pos, plan, table=None):
     """Everything that does not depend on the windows' own occupancies (ehem.py:92-115).
-    Returns (even-node logits in window order [sum ceil(c/2), 255], state for phase 2)."""
+    Returns (even-node logits in window order [sum ceil(c/2), 255], state for phase 2); with `table` (fp32 [>= n_tokens, ld] view
+    starting at the chunk's first coded row) the logits go straight to their coding-order rows and None is returned for them."""
     d = plan.d
     g = model.geo_feat_generator
     dev = ctx.device
@@ -255,12 +273,16 @@ def ehem_phase1_packed(model, ctx, pos, plan):
     Q0 = d["a1map"].shape[0]
     a1 = native.split_rows(feat_a, idx=d["a1map"])
     a2 = native.gather_rows(feat_a, d["a2map"], torch.empty((Q0, 256), dtype=torch.float32, device=dev))
+    st = dict(a1=a1, a2=a2, pre_occ=occ_self[d["a1map"]])
+    if table is not None:
+        _head_to_table(model.prob_pred_mlp1, a1, d["even_out"], table)
+        return None, st
     prob1 = leaky_mlp3_s(model.prob_pred_mlp1, a1)
-    return prob1[d["even_rows"]], dict(a1=a1, a2=a2, pre_occ=occ_self[d["a1map"]])
+    return prob1[d["even_rows"]], st
 
 
 @torch.no_grad()
-def ehem_phase2_packed(model, st, plan, pre_occ=None):
+def ehem_phase2_packed(model, st, plan, pre_occ=None, table=None):
     """Odd-node logits given the occupancies of the even nodes (ehem.py:117-127).  pre_occ: int64 [Q0 rows] in the cross
     layout (None = the true occupancies taken from ctx, as the encoder does)."""
     d = plan.d
@@ -273,13 +295,19 @@ def ehem_phase2_packed(model, st, plan, pre_occ=None):
     pre[:, :no] = occ_feat
     leaky_mlp3_s(model.pre_attn_mlp, a1, out=pre[:, no:])
     hc = _encoder(model.swin_cross_transformer, pre, d["cross_valid"], d["cross_tab"], d["cross_merge"], query=a2)
+    if table is not None:
+        a = _concat_layer(model.prob_pred_mlp2[0], hc, d["cross_parent"], a2)
+        from ..ops import _split
+        a = linear_s(a, model.prob_pred_mlp2[2].weight, model.prob_pred_mlp2[2].bias, act="leaky", want="split")
+        native.linear_split_scatter(a, _split(model.prob_pred_mlp2[4].weight), model.prob_pred_mlp2[4].bias, d["odd_out"], table)
+        return None
     prob2 = _mlp_over_concat(model.prob_pred_mlp2, hc, d["cross_parent"], extra=a2)
     return prob2[d["odd_rows"]]
 
 
 @torch.no_grad()
-def ehem_forward_packed(model, ctx, pos, plan):
+def ehem_forward_packed(model, ctx, pos, plan, table=None):
     """ctx uint8/int64 [T,12], pos float32 [T,3]: the frame's tokens, windows back to back (lengths = plan.c).
     Returns (logits_even_rows [sum ceil(c/2), 255], logits_odd_rows [sum floor(c/2), 255]) in window order."""
-    ev, st = ehem_phase1_packed(model, ctx, pos, plan)
-    return ev, ehem_phase2_packed(model, st, plan)
+    ev, st = ehem_phase1_packed(model, ctx, pos, plan, table=table)
+    return ev, ehem_phase2_packed(model, st, plan, table=table)

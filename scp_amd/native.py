@@ -85,6 +85,7 @@ def lib():
         "scp_linear_bf16x3": (C.c_int, [_vp, i64, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp]),
         "scp_linear_split": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_split_rows": (C.c_int, [_vp, i64, i64, _vp, i32, _vp, _vp, i64, i64, _vp]),
+        "scp_linear_split_scatter": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_linear_split_gather": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_layernorm_rows": (C.c_int, [_vp, i64, i64, _vp, _vp, i32, _vp, _vp, _vp, C.c_float, _vp, i64, i64, _vp]),
         "scp_layernorm_rows_split": (C.c_int, [_vp, i64, i64, _vp, _vp, i32, _vp, _vp, _vp, C.c_float, _vp, _vp, i64, i64, _vp]),
@@ -330,6 +331,7 @@ def packed_plan(lengths, device):
     spec += [(f"tab{l}", i32, (r[l] // 512, 2)) for l in range(9)] + [("knn_tab", i32, (r[0] // 512, 2))]
     spec += [(f"valid{l}", f32, (r[l], 1)) for l in range(9)]
     spec += [(f"sp{s_}", i64, (r[s_],)) for s_ in range(4)] + [(f"cp{s_}", i64, (r[5 + s_],)) for s_ in range(3)]
+    spec += [("even_out", i64, (r[5],)), ("odd_out", i64, (r[5],))]
     t = {name: torch.empty(shape, dtype=dt, device=device) for name, dt, shape in spec}
     ptrs = (C.c_void_p * len(spec))(*[t[name].data_ptr() for name, _, _ in spec])
     scratch = torch.empty((36 * W,), dtype=torch.int64, device=device)
@@ -340,7 +342,8 @@ def packed_plan(lengths, device):
              self_concat=[t[f"sc{s_}"] for s_ in range(1, 5)], cross_concat=[t[f"cc{s_}"] for s_ in range(1, 4)],
              self_tab=[t[f"tab{l}"] for l in range(5)], cross_tab=[t[f"tab{l}"] for l in range(5, 9)], knn_tab=t["knn_tab"],
              self_valid=[t[f"valid{l}"] for l in range(5)], cross_valid=[t[f"valid{l}"] for l in range(5, 9)],
-             self_parent=[t[f"sp{s_}"] for s_ in range(4)], cross_parent=[t[f"cp{s_}"] for s_ in range(3)])
+             self_parent=[t[f"sp{s_}"] for s_ in range(4)], cross_parent=[t[f"cp{s_}"] for s_ in range(3)],
+             even_out=t["even_out"], odd_out=t["odd_out"])
     return r, d
 
 
@@ -458,6 +461,15 @@ class SplitAct:
 
     def float(self):
         return self.t[0, :, :self.K].float() + self.t[1, :, :self.K].float()
+
+
+def linear_split_scatter(a, sw, bias, out_map, table, act=ACT_NONE, cfg=0):
+    """table[out_map[m], :N] = act(a[m] . W^T + bias) for out_map[m] >= 0: fp32 rows written straight to their final positions.
+    table: fp32 [rows, ld >= N] with unit column stride (a row-offset view selects the chunk)."""
+    t = a.t
+    _check(lib().scp_linear_split_scatter(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.Npad, sw.Kpad,
+                                          _opt(bias), _dev(out_map, torch.int64), table.data_ptr(), table.stride(0), a.M, sw.N, sw.K, act, cfg,
+                                          _stream()), "scp_linear_split_scatter")
 
 
 def split_rows(x, idx=None, out=None):
