@@ -82,7 +82,9 @@ struct GemmSplitArgs {
     int ncols_out;                               // split output: columns written (N rounded up to 32, <= ldo): zero filled beyond N
 };
 
-template <int WM, int WN, int TM, int ACT>
+// EXT: the epilogue extensions (gathered residual before the activation, scattered output rows) are compiled only into the
+// variant that needs them - as run-time options they cost every dense layer ~12 % (measured)
+template <int WM, int WN, int TM, int ACT, bool EXT>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmSplitArgs a) {
     constexpr int NW = WM * WN;                            // waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU)
     constexpr int TN = 2;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                 for (int it = 0; it < 8; ++it) {
                     const int m = mb + 4 * it;
                     const int mc = m < a.M ? m : a.M - 1;
-                    const int64_t rrow = a.res_map ? a.res_map[mc] : (int64_t)mc;
+                    const int64_t rrow = (EXT && a.res_map) ? a.res_map[mc] : (int64_t)mc;
                     rr[it] = *(const f32x4 *)(a.res + rrow * a.ldr + nb);
                 }
             }
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                 for (int r = 0; r < 16; ++r) {
                     const int ml = (r & 3) + 8 * (r >> 2) + 4 * h;
                     const float t0 = acc[i][j][r] + bv[j];
-                    stg[ml * 64 + j * 32 + col] = a.res_first ? t0 : apply_act_s<ACT>(t0);
+                    stg[ml * 64 + j * 32 + col] = (EXT && a.res_first) ? t0 : apply_act_s<ACT>(t0);
                 }
             if (full) {
 #pragma unroll
@@ -278,12 +280,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                     const int m = mb + 4 * it;
                     f32x4 y = *(const f32x4 *)(stg + (4 * it + rsub) * 64 + c4);
                     if (has_res) y += rr[it];
-                    if (a.res_first) {
+                    if (EXT && a.res_first) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) y[u] = apply_act_s<ACT>(y[u]);
                     }
                     if (has_c && m < a.M) {
-                        const int64_t orow = a.out_map ? a.out_map[m] : (int64_t)m;
+                        const int64_t orow = (EXT && a.out_map) ? a.out_map[m] : (int64_t)m;
                         if (orow >= 0) *(f32x4 *)(a.C + orow * a.ldc + nb) = y;
                     }
                     if (has_o) {
@@ -307,10 +309,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                     if (m >= a.M) continue;
                     for (int u = 0; u < 4; ++u) {
                         if (nb + u < a.N) {
-                            if (has_res) y[u] += a.res[(a.res_map ? a.res_map[m] : (int64_t)m) * a.ldr + nb + u];
-                            if (a.res_first) y[u] = apply_act_s<ACT>(y[u]);
+                            if (has_res) y[u] += a.res[((EXT && a.res_map) ? a.res_map[m] : (int64_t)m) * a.ldr + nb + u];
+                            if (EXT && a.res_first) y[u] = apply_act_s<ACT>(y[u]);
                             if (has_c) {
-                                const int64_t orow = a.out_map ? a.out_map[m] : (int64_t)m;
+                                const int64_t orow = (EXT && a.out_map) ? a.out_map[m] : (int64_t)m;
                                 if (orow >= 0) a.C[orow * a.ldc + nb + u] = y[u];
                             }
                         } else y[u] = 0.f;
@@ -371,7 +373,7 @@ extern "C" SCP_API int scp_split_rows(const float *src, int64_t ld_src, int64_t 
 
 static int g_num_cu = 0;
 
-template <int WM, int WN, int TM>
+template <int WM, int WN, int TM, bool EXT>
 static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * 64;
     constexpr int STAGE = (BM + BN) * 128;
@@ -379,16 +381,16 @@ static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st) {
     constexpr int LDS = STAGE + (STAGE > BOUNCE ? STAGE : BOUNCE);   // stage 0 + max(stage 1, the epilogue's 8 KiB bounce slice per wave)
     static bool configured = false;
     if (!configured) {
-        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_NONE, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_LEAKY, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_GELU, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_RELU, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         configured = true;
     }
     const int64_t ntiles = cdiv64(ga.M, BM) * cdiv64(ga.N, BN);
     const int64_t slots = (int64_t)g_num_cu * (WM * WN == 4 ? 2 : 1);
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
-#define GOS(ACT) hipLaunchKernelGGL((gemm_split_kernel<WM, WN, TM, ACT>), dim3(grid), dim3(WM * WN * 64), LDS, st, ga)
+#define GOS(ACT) hipLaunchKernelGGL((gemm_split_kernel<WM, WN, TM, ACT, EXT>), dim3(grid), dim3(WM * WN * 64), LDS, st, ga)
     switch (act) { case ACT_LEAKY: GOS(ACT_LEAKY); break; case ACT_GELU: GOS(ACT_GELU); break; case ACT_RELU: GOS(ACT_RELU); break; default: GOS(ACT_NONE); }
 #undef GOS
     LAUNCH_CHECK();
@@ -435,9 +437,10 @@ static int linear_split_impl(const void *Ahi, const void *Alo, int64_t lda, cons
     hipStream_t st = (hipStream_t)stream;
     // cfg 0 = automatic: the 256 x 128 tile where a 256-wide one would leave the chip's last round mostly empty or N <= 128
     if (cfg == 0) cfg = (N <= 128) ? 2 : 1;
-    if (cfg == 2) return launch_cfg<4, 2, 2>(ga, act, st);
-    if (cfg == 3) return launch_cfg<2, 2, 2>(ga, act, st);   // 128 x 128, 4 waves, two workgroups per CU
-    return launch_cfg<2, 4, 4>(ga, act, st);
+    const bool ext = ga.res_map || ga.res_first || ga.out_map;
+    if (cfg == 2) return ext ? launch_cfg<4, 2, 2, true>(ga, act, st) : launch_cfg<4, 2, 2, false>(ga, act, st);
+    if (cfg == 3) return ext ? SCP_EINVAL : launch_cfg<2, 2, 2, false>(ga, act, st);   // 128 x 128, 4 waves, two workgroups per CU
+    return ext ? launch_cfg<2, 4, 4, true>(ga, act, st) : launch_cfg<2, 4, 4, false>(ga, act, st);
 }
 
 extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,

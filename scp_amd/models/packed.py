@@ -193,6 +193,25 @@ def _encoder(enc, x, valids, tabs, merges, query=None):
     return hs
 
 
+def _concat(hs, cmaps, extra=None):
+    """concat_states (ehem.py:75-86): stage s is gathered at token >> s straight into its 256-column slot of a split (bf16 hi/lo)
+    buffer - the operand of the MLP that follows; `extra` = (src, map) appends one more gathered slot (the odd-token features of
+    the cross branch, ehem.py:124)."""
+    n = len(hs) - 1 + (1 if extra is not None else 0)
+    out = native.SplitAct.empty(hs[1].shape[0], 256 * n, hs[1].device)
+    native.split_rows(hs[1], out=out.cols(0, 256))
+    for s in range(1, len(hs) - 1):
+        native.split_rows(hs[s + 1], idx=cmaps[s - 1], out=out.cols(256 * s, 256 * (s + 1)))
+    if extra is not None:
+        k = len(hs) - 1
+        native.split_rows(extra[0], idx=extra[1], out=out.cols(256 * k, 256 * (k + 1)))
+    return out
+
+
+# SCP_CONCAT=direct builds the 1280-wide concatenation and runs one product (the literal form of ehem.py:75-86); default: per stage
+HIER = __import__('os').environ.get('SCP_CONCAT', 'hier') != 'direct'
+
+
 def _concat_layer(lin, hs, parents, extra=None):
     """LeakyReLU(Linear(concat_states(hs))) (ehem.py:75-86 + the first layer of the MLP that consumes it) WITHOUT building the
     concatenation: the layer's weight is cut into one 256-column slab per Swin stage, stage s contributes h_s . W_s^T at its OWN
@@ -269,7 +288,7 @@ def ehem_phase1_packed(model, ctx, pos, plan, table=None):
     leaky_mlp3_s(g.edge_mlp1, split_cat((pos1, pos2, pos3)), want="split", out_split=e_in.cols(pos3.shape[1], e_in.K))
     leaky_mlp3_s(g.edge_mlp2, e_in, out=feat[:, nx:])
     hs = _encoder(model.swin_self_transformer, feat, d["self_valid"], d["self_tab"], d["self_merge"])
-    feat_a = _mlp_over_concat(model.ancient_mlp, hs, d["self_parent"])
+    feat_a = _mlp_over_concat(model.ancient_mlp, hs, d["self_parent"]) if HIER else leaky_mlp3_s(model.ancient_mlp, _concat(hs, d["self_concat"]))
     Q0 = d["a1map"].shape[0]
     a1 = native.split_rows(feat_a, idx=d["a1map"])
     a2 = native.gather_rows(feat_a, d["a2map"], torch.empty((Q0, 256), dtype=torch.float32, device=dev))
@@ -296,12 +315,13 @@ def ehem_phase2_packed(model, st, plan, pre_occ=None, table=None):
     leaky_mlp3_s(model.pre_attn_mlp, a1, out=pre[:, no:])
     hc = _encoder(model.swin_cross_transformer, pre, d["cross_valid"], d["cross_tab"], d["cross_merge"], query=a2)
     if table is not None:
-        a = _concat_layer(model.prob_pred_mlp2[0], hc, d["cross_parent"], a2)
+        a = _concat_layer(model.prob_pred_mlp2[0], hc, d["cross_parent"], a2) if HIER else linear_s(_concat(hc, d["cross_concat"], extra=(a2, None)), model.prob_pred_mlp2[0].weight, model.prob_pred_mlp2[0].bias, act="leaky", want="split")
         from ..ops import _split
         a = linear_s(a, model.prob_pred_mlp2[2].weight, model.prob_pred_mlp2[2].bias, act="leaky", want="split")
         native.linear_split_scatter(a, _split(model.prob_pred_mlp2[4].weight), model.prob_pred_mlp2[4].bias, d["odd_out"], table)
         return None
-    prob2 = _mlp_over_concat(model.prob_pred_mlp2, hc, d["cross_parent"], extra=a2)
+    prob2 = (_mlp_over_concat(model.prob_pred_mlp2, hc, d["cross_parent"], extra=a2) if HIER
+             else leaky_mlp3_s(model.prob_pred_mlp2, _concat(hc, d["cross_concat"], extra=(a2, None))))
     return prob2[d["odd_rows"]]
 
 

@@ -451,3 +451,25 @@ def test_packed_plan_kernel_equals_torch_construction(dev, lengths):
                     assert xa.dtype == xb.dtype and xa.shape == xb.shape and torch.equal(xa, xb), k
         else:
             assert va.dtype == vb.dtype and va.shape == vb.shape and torch.equal(va, vb), k
+
+
+@pytest.mark.gpu
+def test_hierarchical_concat_layers_equal_direct_form(dev, ehem):
+    """The layers that consume concat_states (ehem.py:75-86) are evaluated per Swin stage with gathered partial sums
+    (models/packed.py: _concat_layer); against the direct form (build the 1280-wide concatenation, one product) the logits differ
+    only by fp32 summation order."""
+    from scp_amd.models import packed
+    z = golden("logits_ehem_c1024")
+    ctx = torch.from_numpy(z["data"].astype(np.int64)).to(dev).reshape(1024, 12).to(torch.uint8)
+    p = torch.from_numpy(z["pos"]).to(dev).T.contiguous()
+    lengths = [1, 7, 2, 300, 513, 1, 200]
+    try:
+        packed.HIER = True
+        a = ehem.forward_packed(ctx, p, lengths)
+        packed.HIER = False
+        b = ehem.forward_packed(ctx, p, lengths)
+    finally:
+        packed.HIER = True
+    worst = max((a[0] - b[0]).abs().max().item(), (a[1] - b[1]).abs().max().item())
+    print(f"hierarchical vs direct concat layers: max|dlogit| = {worst:.3e}")
+    assert worst < 5e-5
