@@ -23,6 +23,17 @@ __global__ __launch_bounds__(64) void cdf_kernel(const float *__restrict__ in, i
     if (ld == nsym) {
         const float *src = in + row0 * ld;
         for (int i = lane; i < total; i += 64) tile[i] = src[i];
+    } else if (ld == 256 && nsym <= 256 && (((uintptr_t)in) & 15) == 0) {
+        // 16-byte aligned rows of 256 floats (the coding-order table the probability heads write into): one 16-byte load per lane and row
+        for (int r = 0; r < nrow; ++r) {
+            const float4 v = *(const float4 *)(in + (row0 + r) * 256 + 4 * lane);
+            const int c = 4 * lane;
+            float *d = tile + r * nsym + c;
+            if (c < nsym) d[0] = v.x;
+            if (c + 1 < nsym) d[1] = v.y;
+            if (c + 2 < nsym) d[2] = v.z;
+            if (c + 3 < nsym) d[3] = v.w;
+        }
     } else {
         for (int i = lane; i < total; i += 64) { const int r = i / nsym, c = i - r * nsym; tile[i] = in[(row0 + r) * ld + c]; }
     }
