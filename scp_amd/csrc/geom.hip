@@ -152,8 +152,10 @@ extern "C" int scp_quantize(const float *xyz, int64_t n, int32_t mode, double qs
     hipStream_t st = (hipStream_t)stream;
     int rc = g_qtmp.reserve((size_t)n * 12 + 64);
     if (rc) return rc;
-    float *tr = tr_out ? tr_out : g_qtmp.as<float>();
-    uint32_t *red = (uint32_t *)((char *)g_qtmp.p + g_qtmp.cap - 32);
+    // scratch layout: [4 reduction words, padded to 64 B][transformed coordinates].  (The reduction words used to sit at
+    // `cap - 32`; the capacity is not a multiple of 4 for odd n, and a misaligned atomic faults.)
+    uint32_t *red = g_qtmp.as<uint32_t>();
+    float *tr = tr_out ? tr_out : (float *)((char *)g_qtmp.p + 64);
     uint32_t init[4] = {0u, 0xffffffffu, (uint32_t)INT32_MIN, (uint32_t)INT32_MAX};
     HIP_TRY(hipMemcpyAsync(red, init, sizeof(init), hipMemcpyHostToDevice, st));
     const int nb = (int)cdiv64(n, WG);

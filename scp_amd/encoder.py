@@ -84,6 +84,9 @@ class FrameEncoder:
         self.mode = native.CYLIN if cylin else (native.SPHER if spher else native.CART)
         self.spher, self.cylin = spher and not cylin, cylin
         self.mullevel = mullevel
+        if mullevel and self.mode == native.CART:
+            # encode_dataset_ehem_mullevel.py:97-186 has a cylindrical and a spherical branch only
+            raise native.ScpError("--mullevel needs --spher or --cylin (the reference has no Cartesian multi-level path)")
         self.max_batch = max_batch
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.context_size = model.cfg.model.context_size

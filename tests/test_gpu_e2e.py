@@ -464,3 +464,35 @@ def test_full_size_encode_decode_roundtrip(enc_parts):
         want = occ[info.node_base:info.node_base + info.n_nodes].cpu().numpy()
         got = torch.cat(codes).cpu().numpy()
         assert len(got) == len(want) and got[-1] == 0 and np.array_equal(got[:-1], want[:-1]), s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["one", "dup2", "five", "line"])
+@pytest.mark.parametrize("spher", [True, False])
+def test_degenerate_frames_roundtrip(enc_parts, case, spher):
+    """Frames of one point, two identical points, five points, 300 collinear points: encode -> decode regenerates the octree."""
+    from scp_amd.decoder import FrameDecoder
+    from scp_amd.encoder import FrameEncoder
+    model, dev = enc_parts
+    xyz = {"one": np.array([[10.0, 3.0, -1.0]], np.float32), "dup2": np.array([[10.0, 3.0, -1.0]] * 2, np.float32),
+           "five": np.array([[10, 3, -1], [12, -4, 0.5], [30, 1, 2], [5, 5, -1.5], [60, -20, 1]], np.float32),
+           "line": np.stack([np.linspace(2, 80, 300), np.zeros(300), np.zeros(300)], 1).astype(np.float32)}[case]
+    enc = FrameEncoder(model, "kitti", 12, spher=spher, device=dev)
+    res = enc.encode(xyz)
+    occ = enc.geom.nodes(("occ",))["occ"].cpu().numpy()
+    (codes, leaves), = FrameDecoder(model, 12, mullevel=False, polar=spher, device=dev).decode(res["bytes"], res["n_levels"], res["pos_mm"])
+    assert np.array_equal(torch.cat(codes).cpu().numpy(), occ)
+    assert np.array_equal(leaves.cpu().numpy(), enc.geom.leaves(0).cpu().numpy())
+    assert res["n_points"] == len(xyz) and res["bits"] == 8 * len(res["bytes"])
+
+
+@pytest.mark.gpu
+def test_unsupported_configurations_fail_loudly(enc_parts):
+    from scp_amd import native
+    from scp_amd.encoder import FrameEncoder
+    model, dev = enc_parts
+    with pytest.raises(native.ScpError):
+        FrameEncoder(model, "kitti", 12, spher=False, cylin=False, mullevel=True, device=dev)     # no Cartesian multi-level path
+    enc = FrameEncoder(model, "kitti", 12, spher=True, mullevel=True, device=dev)
+    with pytest.raises(native.ScpError):
+        enc.encode(np.array([[10.0, 3.0, -1.0]], np.float32))                                       # two of the three shells are empty

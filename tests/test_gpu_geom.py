@@ -373,3 +373,23 @@ def test_legacy_octree_abi_matches_reference_so(dev):
         assert n == len(z["occ"])
         lib.delete_vector(vec)
     assert lib.genOctreeInterface(lib.new_vector(), np.zeros(3).ctypes.data_as(C.POINTER(C.c_double)), 1) is None   # depth 0: NULL, no abort
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 255, 257, 4001, 119999])
+def test_quantizer_any_point_count(dev, orc, n):
+    """Point counts of every parity and size (a scratch pointer derived from an odd-sized allocation once made every odd-n frame
+    fault on a misaligned atomic): same integers as the oracle up to the float -> int boundary points, all three modes."""
+    import torch
+    from scp_amd import native
+    from scp_amd.synth import synth_frame
+    xyz = synth_frame(7)[:n].copy()
+    for mode, name in ((native.SPHER, "spher"), (native.CYLIN, "cylin"), (native.CART, "cart")):
+        q, info, _ = native.quantize(torch.from_numpy(xyz).to(dev), mode, 400 / (2 ** 12 - 1), -200.0)
+        _, bin_num, _, _, pt = orc.quantise(xyz, 400 / (2 ** 12 - 1), name)
+        got = q.cpu().numpy()
+        assert got.shape == (n, 3) and info.bin_num == bin_num
+        # (synthetic rings can sit on a rounding boundary of theta / qs as a whole: DESIGN.md 2.1)
+        assert (got != pt.astype(np.int64)).any(1).sum() <= max(2, n // 40)
+        g = native.Geom()
+        g.build(q, [(0, n, None, False)])
+        assert g.info[0].n_leaves == len(np.unique(got, axis=0))
