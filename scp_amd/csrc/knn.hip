@@ -114,23 +114,40 @@ __device__ __forceinline__ void knn_merge_write(const u64 (&key)[TK], float *mva
 }
 
 // ---- selection step shared by both kernels: this lane holds candidates row = (r&3) + 8(r>>2) + 4h of a 32-tile for its query ---
-// `acc[r]` = x_i . x_j (SCALED: multiplied by `usc` and the candidate's entry of `sis` when SCALED).
-// Pass 1 (branch-free, ~6 VALU per candidate): d = (2 x.y - xx_j) - xx_i and a bit mask of the candidates that beat the pruning
-// bound thr = the tighter 20th best of the two lanes of the query: d > thr passes; d == thr (rare: collected as one wave-wide
-// scalar flag, resolved in a slow path) passes if it beats this lane's own 20th best under the (value desc, index asc) order.
-// Pass 2: lanes pop their survivors one at a time (the wavefront pays for max-over-lanes survivors, not for all 16 slots);
-// the 20-step insertion skips the leading 5-step segments that no lane's survivor reaches - late in the sweep a survivor
-// almost always lands near the end of the list.
+// `acc[r]` = x_i . x_j (SCALED: times the two row scales; `usc2` = 2 / scale of the query, `sis` = 1 / scale of the candidates).
+// With a = 2 x_i.x_j - |x_j|^2 the (negated squared) distance is d = fl(a - |x_i|^2).
+// Pass 1 (branch-free, 4-5 VALU per candidate) never forms d: fl() is monotone, so "d < bound" is implied by "a < cut" for a
+// cut placed a few ulps below bound + |x_i|^2 (derivation at `cut`); the pass builds a bit mask of the candidates at or above
+// the cut and keeps the a of the last one.  Candidates the cut lets through although they do not qualify (a few ulps, or exact
+// ties with the bound) are harmless: the insertion compares full (value, index) keys and they fall off the end of the list.
+// Pass 2: lanes pop their survivors one at a time (the wavefront pays for max-over-lanes survivors, not for all 16 slots).
 template <bool SCALED>
-__device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, const float *sis, float usc, float xxi, int c0, int n, int h,
+__device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, const float *sis, float usc2, float xxi, int c0, int n, int h,
                                            u64 (&key)[TK], float thr0) {
-    // both lanes of a query prune with the tighter of their bounds, and with the caller's a-priori bound thr0 (a distance that at
-    // least 20 candidates are known to beat: nothing below it can be among the 20 best; -inf when there is none)
-    const float v19 = knn_key_val(key[TK - 1]);
-    const float thr = fmaxf(fmaxf(v19, __shfl_xor(v19, 32)), thr0);
+    // Pruning bound.  The two lanes of a query (h = 0 / 1) keep separate sorted lists a, b over disjoint candidates.  a[i] and
+    // b[18 - i] bound the 20th best of their union from below (i + 1 entries of a and 19 - i entries of b are at least
+    // min(a[i], b[18 - i])), as do a[19] and b[19] alone; each lane evaluates four such pairs (values only: the sortable high
+    // words) and the pair of lanes takes the maximum - about the 21st best seen so far instead of the ~38th that
+    // max(a[19], b[19]) gives.  thr0 is the caller's a-priori bound (a distance that at least 20 candidates are known to beat;
+    // -inf when there is none).
+    static_assert(TK == 20, "pair table");
+    unsigned sb = (unsigned)(key[TK - 1] >> 32);
+    {
+        const unsigned p3 = __shfl_xor((unsigned)(key[3] >> 32), 32), p6 = __shfl_xor((unsigned)(key[6] >> 32), 32),
+                       p9 = __shfl_xor((unsigned)(key[9] >> 32), 32);
+        sb = max(sb, min((unsigned)(key[15] >> 32), p3));
+        sb = max(sb, min((unsigned)(key[12] >> 32), p6));
+        sb = max(sb, min((unsigned)(key[9] >> 32), p9));
+        sb = max(sb, (unsigned)__shfl_xor(sb, 32));
+    }
+    const float thr = fmaxf(knn_unsortable(sb), thr0);
+    // cut: with m = max(|thr|, |xxi|), s = fl(thr + xxi) and cut = fl(s - 2^-21 m) satisfy cut <= thr + xxi - 2^-22 m (both
+    // roundings are at most 2^-23 m).  a < cut then gives a - xxi < thr - 2^-22 |thr|, which lies below the float preceding thr,
+    // so fl(a - xxi) < thr: the candidate cannot be among the 20 best.  thr = -inf (list not full yet): cut = -inf, all pass.
+    const float cut = (thr + xxi) - 0x1p-21f * fmaxf(fabsf(thr), fabsf(xxi));
     const bool full = c0 + 32 <= n;                                   // wave-uniform: every candidate of the tile exists
-    unsigned pend = 0, eqm = 0;
-    unsigned long long anyeq = 0;
+    unsigned pend = 0;                                                // candidate r -> bit 15 - r
+    float asel = 0.f;                                                 // a of the survivor with the lowest bit
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 xj = *(const f32x4 *)(sxx + 8 * g + 4 * h);      // candidates (r & 3) + 8 g + 4 h, r & 3 = 0..3
@@ -139,41 +156,32 @@ __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = 4 * g + u;
-            float t = acc[r];
-            if (SCALED) t = (t * usc) * sj[u];                        // powers of two: exact
-            float d = (2.f * t - xj[u]) - xxi;
-            if (!full) d = (c0 + u + 8 * g + 4 * h < n) ? d : -INFINITY;
-            pend |= (d > thr) ? (1u << r) : 0u;
-            anyeq |= __ballot(d == thr);
+            // scales are powers of two: (acc * usc2) * sj is exact, one rounding in the fma
+            const float a = SCALED ? fmaf(acc[r] * usc2, sj[u], -xj[u]) : fmaf(2.f, acc[r], -xj[u]);
+            bool pass = a >= cut;
+            if (!full) pass = pass && (c0 + u + 8 * g + 4 * h < n);
+            pend = (pend << 1) | (pass ? 1u : 0u);
+            asel = pass ? a : asel;
         }
     }
-    // the distance of slot r again (pass 2 and the tie path; same arithmetic, so the same value)
-    auto dist = [&](int r) {
-        float a = acc[0];
-#pragma unroll
-        for (int rr = 1; rr < 16; ++rr) a = (rr == r) ? acc[rr] : a;
-        const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (SCALED) a = (a * usc) * sis[cl];
-        const float d = (2.f * a - sxx[cl]) - xxi;
-        return (full || c0 + cl < n) ? d : -INFINITY;
-    };
-    if (anyeq) {   // some lane has a candidate exactly on the bound (rare): admit it if it beats the lane's own 20th best
-        for (int r = 0; r < 16; ++r) {
-            const float d = dist(r);
-            const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool pass = d == thr && d > -INFINITY && knn_key(d, j) > key[TK - 1];
-            eqm |= pass ? (1u << r) : 0u;
-        }
-        pend |= eqm;
-    }
-    while (__any(pend != 0u)) {   // wave-uniform loop; lanes without a survivor insert a harmless (-inf, INT_MAX)
+    if (!__any(pend != 0u)) return;
+    {   // first survivor of every lane: its a is at hand
         const bool act = pend != 0u;
-        const int r = act ? (__ffs(pend) - 1) : 0;
+        const int r = act ? 16 - __ffs(pend) : 0;
         pend &= pend - 1u;
-        const float d = dist(r);
         const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        // a survivor that no longer qualifies simply falls off the end; 0 is below every key, KEY_EMPTY included
-        key_insert(key, act ? knn_key(d, j) : 0ull);
+        key_insert(key, act ? knn_key(asel - xxi, j) : 0ull);        // 0 is below every key, KEY_EMPTY included
+    }
+    while (__any(pend != 0u)) {   // further survivors (wave-uniform loop): recompute a of slot r, same arithmetic -> same value
+        const bool act = pend != 0u;
+        const int r = act ? 16 - __ffs(pend) : 0;
+        pend &= pend - 1u;
+        float t = acc[0];
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr) t = (rr == r) ? acc[rr] : t;
+        const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float a = SCALED ? fmaf(t * usc2, sis[cl], -sxx[cl]) : fmaf(2.f, t, -sxx[cl]);
+        key_insert(key, act ? knn_key(a - xxi, c0 + cl) : 0ull);
     }
 }
 
@@ -339,11 +347,12 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
     constexpr int NDMA = STAGE_B / 1024;            // 1 KiB DMA instructions per stage (24 / 18)
     constexpr int NDMA_W = (NDMA + 3) / 4;
     constexpr int MERGE_B = 2 * 128 * 2 * TK * 4;
-    constexpr int TILES_B = 2 * STAGE_B + 2 * 64 * 4;
+    constexpr int NST = 3;                          // LDS stages: candidate tiles are requested two sweep steps ahead
+    constexpr int TILES_B = NST * STAGE_B + NST * 64 * 4;
     constexpr int POOL_B = TILES_B > MERGE_B ? TILES_B : MERGE_B;
     static_assert(STAGE_B % 1024 == 0, "layout");
     __shared__ __attribute__((aligned(1024))) char pool[POOL_B];
-    float *txx = (float *)(pool + 2 * STAGE_B);     // [2][64]: |x|^2 of the 32 candidates, then their inverse scales
+    float *txx = (float *)(pool + NST * STAGE_B);   // [NST][64]: |x|^2 of the 32 candidates, then their inverse scales
 
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -407,21 +416,33 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
     };
 
     const int swz = (R % 16 == 0) ? (col & 15) : ((col >> 2) & 3);
+    // sweep order: own tile first, then alternately outwards (the pruning bound tightens fastest on nearby rows)
     const int own = q0 >> 5;
     int lo = own - 1, hi = own + 1, cur = own < nt ? own : nt - 1;
     if (own >= nt) { lo = nt - 2; hi = nt; }
+    int step = 0;
+    auto next_tile = [&]() {
+        int t;
+        if ((step & 1) == 0) { if (hi < nt) t = hi++; else t = lo--; }
+        else { if (lo >= 0) t = lo--; else t = hi++; }
+        ++step;
+        return t;
+    };
+    // DMA instructions this wave issues per stage: a stage has landed when at most that many (the next stage's) are in flight
+    const int per_stage = (NDMA - w + 3) / 4 + (w == 0 ? 1 : 0);
     issue(cur, 0);
+    int cur1 = -1;
+    if (nt > 1) { cur1 = next_tile(); issue(cur1, 1); }
 
     for (int s = 0; s < nt; ++s) {
-        const int buf = s & 1;
-        SCP_WAIT_DMA(0);
-        __syncthreads();   // stage s has landed and every wave is done with the other stage
-        int nxt = -1;
+        const int buf = s % NST;
         if (s + 1 < nt) {
-            if ((s & 1) == 0) { if (hi < nt) nxt = hi++; else nxt = lo--; }
-            else { if (lo >= 0) nxt = lo--; else nxt = hi++; }
-            issue(nxt, buf ^ 1);
-        }
+            if (per_stage >= 7) SCP_WAIT_DMA(7); else if (per_stage == 6) SCP_WAIT_DMA(6);
+            else if (per_stage == 5) SCP_WAIT_DMA(5); else SCP_WAIT_DMA(4);
+        } else SCP_WAIT_DMA(0);
+        __syncthreads();   // stage s has landed and every wave is done with stage s - 1, whose buffer is refilled now
+        int nxt = -1;
+        if (s + 2 < nt) { nxt = next_tile(); issue(nxt, (s + 2) % NST); }
         const char *arow = pool + buf * STAGE_B + col * RB;
         f32x16 acc;
 #pragma unroll
@@ -437,8 +458,9 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
         }
         // un-scaling (acc / s_query / s_candidate, powers of two: exact) happens inside the selection
         const float *sxx = txx + buf * 64;
-        knn_select<true>(acc, sxx, sxx + 32, isq, xxi, cur * 32, n, h, key, thr0v);
-        cur = nxt;
+        knn_select<true>(acc, sxx, sxx + 32, 2.f * isq, xxi, cur * 32, n, h, key, thr0v);
+        cur = cur1;
+        cur1 = nxt;
     }
     __syncthreads();
     knn_merge_write(key, (float *)pool, (int *)(pool + 128 * 2 * TK * 4), tid, w, col, h, q0, n, k, row0, ctab, idx);
