@@ -180,6 +180,19 @@ SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void *Whi, cons
                       const float *residual, int64_t ldr, float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act,
                       void *stream);
 
+/* "f16x3" form of scp_linear_bf16x3: IEEE-half planes (22 significant bits per operand instead of 16) with one power-of-two scale
+ * per row of A and per row of W (largest magnitude -> [2^13, 2^14)), undone exactly in the epilogue: the accuracy class of an
+ * fp32 FMA chain at the MFMA rate of the bf16 form.  Replaces the nn.Linear calls of models/oct_attention.py:48-83 and
+ * models/attention_model.py:58-125 (embeddings scaled by sqrt(600): bf16x3 misses the 1e-3 logit tolerance there).
+ *   scp_split_weight_f16: W fp32 [N][K] -> scaled f16 planes hi/lo [Npad][Kpad] (Npad % 128 == 0, Kpad % 32 == 0) and
+ *                         inv_scale[Npad] (1 / row scale; 1 on padding rows)
+ *   scp_linear_f16x3    : as scp_linear_bf16x3; row_scale_ws = device workspace of 2 M floats (row scales of A, written here) */
+SCP_API int scp_split_weight_f16(const float *W, int32_t N, int32_t K, int32_t Npad, int32_t Kpad, void *hi, void *lo,
+                                 float *inv_scale, void *stream);
+SCP_API int scp_linear_f16x3(const float *A, int64_t lda, const void *Whi, const void *Wlo, const float *w_inv_scale, int32_t Kpad,
+                             const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, int32_t M, int32_t N,
+                             int32_t K, int32_t act, float *row_scale_ws, void *stream);
+
 /* The same dense layer with the ACTIVATION pre-split too: A arrives as bf16 planes hi/lo [M][lda] (lda % 8 == 0, lda >= Kpad,
  * columns K..Kpad zero) written by the producing kernel (scp_split_rows, scp_layernorm_rows_split, the attention kernels, or this
  * function's own split output), so operand tiles go global -> LDS by LDS-DMA with no conversion.  Outputs: C fp32 [M][ldc]
@@ -234,6 +247,15 @@ SCP_API int scp_linear_f32(const float *A, int64_t lda, const float *W, const fl
  * q_u,k,k_u,v,v_u [B][c][H*hd] -> out, out_u [B][c][H*hd] */
 SCP_API int scp_octattn_attention(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
                           int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *stream);
+
+/* The same attention for head width 150 on f16 MFMA with fp32-class accuracy ("f16x3": every operand as two IEEE-half planes
+ * with power-of-two scales - per (token, head) for q and k, one per launch for v - three MFMA products per product, fp32
+ * accumulate; csrc/octattn_f16.hip).  A preparation kernel lays the planes out as LDS-DMA-ready key tiles in `workspace`
+ * (device memory, 1 KiB aligned, scp_octattn_f16x3_ws_bytes(B, c, H) bytes).  q_u, k, v must be 16-byte aligned. */
+SCP_API int64_t scp_octattn_f16x3_ws_bytes(int32_t B, int32_t c, int32_t H);
+SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
+                                        int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *workspace,
+                                        int64_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stage C - softmax -> integer CDF, on device

@@ -16,6 +16,8 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -58,12 +60,20 @@ __device__ __forceinline__ float apply_act(float y) {
     return y;
 }
 
-template <int ACT>
+// F16 = true is the "f16x3" form of the same kernel: planes are IEEE half (11 significant bits each, 22 together, against 16 for
+// bf16) and every row of A and of W is first multiplied by a power of two that puts its largest magnitude into [2^13, 2^14)
+// (row_scale_kernel / split_weight_f16_kernel), so that neither plane overflows and the low plane of the elements that matter
+// stays normal; the accumulator is multiplied back by the two inverse scales in the epilogue (powers of two: exact).  The
+// dropped lo.lo term and the plane rounding are ~2^-22 relative - the error class of an fp32 FMA chain over K = 600 - at the
+// MFMA rate of the bf16 form.  Used by OctAttention, whose sqrt(600)-scaled embeddings leave bf16x3 short of the 1e-3 logit
+// tolerance.  asc / iasc: scale and inverse scale per row of A; iwsc: inverse scale per row of W.
+template <int ACT, bool F16>
 __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__restrict__ A, int64_t lda, const __bf16 *__restrict__ Whi,
                                                             const __bf16 *__restrict__ Wlo, int Kpad, const float *__restrict__ bias,
                                                             const float *__restrict__ res, int64_t ldr, float *__restrict__ C, int64_t ldc,
-                                                            int M, int N, int K) {
-    // two LDS stages x four bf16 planes (A hi, A lo, B hi, B lo) = 2 x 40 KiB: exactly two workgroups per CU
+                                                            int M, int N, int K, const float *__restrict__ asc,
+                                                            const float *__restrict__ iasc, const float *__restrict__ iwsc) {
+    // two LDS stages x four 16-bit planes (A hi, A lo, B hi, B lo) = 2 x 40 KiB: exactly two workgroups per CU
     __shared__ __attribute__((aligned(16))) __bf16 lds[2][4][BM * LDP];
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, col = lane & 31, h = lane >> 5;
@@ -85,6 +95,11 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__rest
     // with only two workgroups per CU)
     f32x4 pa2[2][2];
     bf16x8 pbh2[2][1], pbl2[2][1];
+    float rsc[2] = {1.f, 1.f};                           // F16: scale of this thread's two staged rows
+    if (F16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int m = m0 + a_r + 64 * i; rsc[i] = asc[m < M ? m : M - 1]; }
+    }
     auto issue = [&](int kt, auto &pa, auto &pbh, auto &pbl) {
         const int k0 = kt * BK;
 #pragma unroll
@@ -108,16 +123,29 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__rest
         __bf16 *sAh = lds[st][0], *sAl = lds[st][1], *sBh = lds[st][2], *sBl = lds[st][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            bf16x4 hi, lo;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const __bf16 hh = (__bf16)pa[i][u];
-                hi[u] = hh;
-                lo[u] = (__bf16)(pa[i][u] - (float)hh);
-            }
             const int o = (a_r + 64 * i) * LDP + 4 * a_c;
-            *(bf16x4 *)(sAh + o) = hi;
-            *(bf16x4 *)(sAl + o) = lo;
+            if (F16) {
+                f16x4 hi, lo;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float x = pa[i][u] * rsc[i];
+                    const _Float16 hh = (_Float16)x;
+                    hi[u] = hh;
+                    lo[u] = (_Float16)(x - (float)hh);
+                }
+                *(f16x4 *)(sAh + o) = hi;
+                *(f16x4 *)(sAl + o) = lo;
+            } else {
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const __bf16 hh = (__bf16)pa[i][u];
+                    hi[u] = hh;
+                    lo[u] = (__bf16)(pa[i][u] - (float)hh);
+                }
+                *(bf16x4 *)(sAh + o) = hi;
+                *(bf16x4 *)(sAl + o) = lo;
+            }
         }
         {
             const int o = b_r * LDP + 8 * b_c;
@@ -158,9 +186,15 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__rest
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 1; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    if (F16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16((f16x8)al[i], (f16x8)bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16((f16x8)ah[i], (f16x8)bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16((f16x8)ah[i], (f16x8)bh[j], acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
                 }
         }
         // tile kt + 1 (issued one iteration ago) -> the other LDS stage: nobody reads it during this iteration
@@ -176,12 +210,15 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__rest
     {
         const int n = n0 + wn * 32 + col;
         const float bv = (bias && n < N) ? bias[n] : 0.f;
+        const float wsc = F16 ? iwsc[n] : 1.f;               // planes are padded to Npad rows: always in range
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                stg[ml * LDE + col] = apply_act<ACT>(acc[i][0][r] + bv);
+                float t = acc[i][0][r];
+                if (F16) { const int m = m0 + wm * 64 + ml; t = (t * iasc[m < M ? m : M - 1]) * wsc; }
+                stg[ml * LDE + col] = apply_act<ACT>(t + bv);
             }
     }
     __syncthreads();
@@ -234,8 +271,83 @@ extern "C" SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void
         ((uintptr_t)A & 15) || lda < K || ldc < N || (residual && ldr < N))
         return SCP_EINVAL;
     const dim3 grid((unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM)));
-#define GO(ACT) hipLaunchKernelGGL(gemm_bf16x3_kernel<ACT>, grid, dim3(512), 0, (hipStream_t)stream, A, lda, (const __bf16 *)Whi, \
-                              (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K)
+#define GO(ACT) hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT, false>), grid, dim3(512), 0, (hipStream_t)stream, A, lda, (const __bf16 *)Whi, \
+                              (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K, nullptr, nullptr, nullptr)
+    switch (act) { case ACT_LEAKY: GO(ACT_LEAKY); break; case ACT_GELU: GO(ACT_GELU); break; case ACT_RELU: GO(ACT_RELU); break; default: GO(ACT_NONE); }
+#undef GO
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+// ---- f16x3: row scales, weight planes, launch ------------------------------------------------------------------------------------
+// power of two that maps a row maximum mx into [2^13, 2^14) (1 for an all-zero or non-finite row; exponent clamped to +-100)
+__device__ __forceinline__ void pow2_scale(float mx, float &sc, float &isc) {
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) {
+        e = 140 - (int)((__float_as_uint(mx) >> 23) & 0xffu);
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    }
+    sc = __uint_as_float((unsigned)(127 + e) << 23);
+    isc = __uint_as_float((unsigned)(127 - e) << 23);
+}
+
+// one wavefront per row of A [M][lda] (K % 4 == 0): scale and inverse scale
+__global__ __launch_bounds__(256) void row_scale_kernel(const float *__restrict__ A, int64_t lda, int M, int K, float *__restrict__ sc,
+                                                       float *__restrict__ isc) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float *a = A + (int64_t)row * lda;
+    float mx = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+        const f32x4 v = *(const f32x4 *)(a + k);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) { float s, is; pow2_scale(mx, s, is); sc[row] = s; isc[row] = is; }
+}
+
+// one wavefront per row of W [N][K] -> scaled f16 planes [Npad][Kpad] (zero padded) + inverse row scale [Npad] (1 on padding)
+__global__ __launch_bounds__(256) void split_weight_f16_kernel(const float *__restrict__ W, int N, int K, int Npad, int Kpad,
+                                                              _Float16 *__restrict__ hi, _Float16 *__restrict__ lo, float *__restrict__ isc) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= Npad) return;
+    float mx = 0.f;
+    if (row < N)
+        for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(W[(int64_t)row * K + k]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float s, is;
+    pow2_scale(mx, s, is);
+    if (lane == 0) isc[row] = is;
+    for (int k = lane; k < Kpad; k += 64) {
+        const float x = (row < N && k < K) ? W[(int64_t)row * K + k] * s : 0.f;
+        const _Float16 hh = (_Float16)x;
+        hi[(int64_t)row * Kpad + k] = hh;
+        lo[(int64_t)row * Kpad + k] = (_Float16)(x - (float)hh);
+    }
+}
+
+extern "C" SCP_API int scp_split_weight_f16(const float *W, int32_t N, int32_t K, int32_t Npad, int32_t Kpad, void *hi, void *lo,
+                                            float *inv_scale, void *stream) {
+    if (!W || !hi || !lo || !inv_scale || N <= 0 || K <= 0 || Npad < N || Kpad < K || (Npad % BN) || (Kpad % BK)) return SCP_EINVAL;
+    hipLaunchKernelGGL(split_weight_f16_kernel, dim3((unsigned)((Npad + 3) / 4)), dim3(256), 0, (hipStream_t)stream, W, N, K, Npad, Kpad,
+                       (_Float16 *)hi, (_Float16 *)lo, inv_scale);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+extern "C" SCP_API int scp_linear_f16x3(const float *A, int64_t lda, const void *Whi, const void *Wlo, const float *w_inv_scale,
+                                        int32_t Kpad, const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc,
+                                        int32_t M, int32_t N, int32_t K, int32_t act, float *row_scale_ws, void *stream) {
+    if (!A || !Whi || !Wlo || !w_inv_scale || !C || !row_scale_ws || M <= 0 || N <= 0 || K <= 0 || (K & 3) || (lda & 3) || Kpad < K ||
+        (Kpad % BK) || act < 0 || act > 3 || ((uintptr_t)A & 15) || lda < K || ldc < N || (residual && ldr < N))
+        return SCP_EINVAL;
+    float *sc = row_scale_ws, *isc = row_scale_ws + M;      // workspace: 2 M floats
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, A, lda, M, K, sc, isc);
+    const dim3 grid((unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM)));
+#define GO(ACT) hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT, true>), grid, dim3(512), 0, (hipStream_t)stream, A, lda, (const __bf16 *)Whi, \
+                              (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K, sc, isc, w_inv_scale)
     switch (act) { case ACT_LEAKY: GO(ACT_LEAKY); break; case ACT_GELU: GO(ACT_GELU); break; case ACT_RELU: GO(ACT_RELU); break; default: GO(ACT_NONE); }
 #undef GO
     LAUNCH_CHECK();

@@ -1,0 +1,357 @@
+// OctAttention dual-stream causal attention on f16 MFMA with fp32-class accuracy ("f16x3", gfx950 / CDNA4), head width 150.
+//
+// Same mathematics as octattn_mfma_kernel (octattn.hip; replaces models/attention_model.py:58-95): one flash pass over the strictly
+// lower triangle gives (M, L, A) per query, the two streams differ in their diagonal term only.  The difference is the arithmetic
+// of the two big products: every operand is a pair of IEEE-half planes hi = f16(x s), lo = f16(x s - hi) (22 significant bits)
+// and a product is three v_mfma_f32_32x32x16_f16 (lo.hi + hi.lo + hi.hi, fp32 accumulate) - 60 MFMAs of 32 cycles per 32-key
+// tile instead of 156 fp32 MFMAs of 64 cycles.  Scales s are powers of two, undone exactly:
+//   q, k : one per (token, head), largest magnitude -> [2^13, 2^14)   (score = acc / (s_q s_k))
+//   v    : one for the whole launch (scp_octattn_attention_f16x3 reduces max |v| first): o = acc / s_v
+//   p    : none (p <= 1)
+// A preparation kernel writes the planes in the layouts the attention kernel consumes, so that a key tile goes global -> LDS by
+// LDS-DMA as a linear copy:
+//   Q planes  [b][token][head][2][160]                                  (read once per query block, straight into registers)
+//   K image   [b][tile][head] : planes [2][32 keys][168] (336-byte rows: conflict-free ds_read_b128) + 32 inverse scales
+//   V image   [b][tile][head] : planes [2][160 dims][40] = V^T, key order permuted (bits 2 and 3 of the key index swapped: the
+//             order in which the S^T accumulator registers hold the keys), 80-byte rows
+// The preparation kernel also evaluates the two diagonal terms q_i.k_i and q_i.ku_i (plain fp32) - the attention kernel reads
+// neither k nor k_u.
+// Workgroup = 4 waves = 128 queries of one (batch, head); a wave owns 32 queries.  Per key tile: wait K -> barrier -> start the
+// V DMA -> S^T = K . Q^T, softmax -> wait V -> barrier -> start the next K DMA -> O^T += V^T . P^T.  The epilogue goes through a
+// wave-private LDS tile so that v / v_u loads and the stores of out / out_u move 128 contiguous bytes per row.
+#include "scp_internal.h"
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16h __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void *oa_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *oa_glb_ptr_t;
+
+#define FHD 150
+#define FHP 160                     // head dims padded to ten k-chunks of 16
+#define FKLD 168                    // f16 per K row in the tile image
+#define FVLD 40                     // f16 per V^T row in the tile image
+#define FK_PLANE (32 * FKLD)        // f16 per K plane
+#define FV_PLANE (FHP * FVLD)       // f16 per V plane
+#define FK_ISK (2 * FK_PLANE * 2)   // byte offset of the 32 inverse key scales inside the K image
+#define FK_IMG 22528                // bytes: 2 planes + 128 B of scales, rounded up to 1 KiB
+#define FV_IMG 25600                // bytes: 2 planes (25 KiB)
+static_assert(FK_ISK + 128 <= FK_IMG && 2 * FV_PLANE * 2 == FV_IMG, "image sizes");
+
+__device__ __forceinline__ void oa_pow2_scale(float mx, float &sc, float &isc) {
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) {
+        e = 140 - (int)((__float_as_uint(mx) >> 23) & 0xffu);   // mx 2^e in [2^13, 2^14)
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    }
+    sc = __uint_as_float((unsigned)(127 + e) << 23);
+    isc = __uint_as_float((unsigned)(127 - e) << 23);
+}
+
+// max |v| over the launch (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void oa_absmax_kernel(const float *__restrict__ v, int64_t n4, unsigned *__restrict__ out) {
+    float mx = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 x = ((const float4 *)v)[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx == mx) atomicMax(out, __float_as_uint(fminf(mx, 3.0e38f)));
+}
+
+// workgroup = one 32-token tile of one (batch, head): thread (t = tid >> 3, s = tid & 7) walks float2 pieces s, s + 8, ... of row t
+__global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ q_u, const float *__restrict__ k, const float *__restrict__ k_u,
+                                                     const float *__restrict__ v, int c, int H, int nt, const unsigned *__restrict__ vmax_bits,
+                                                     _Float16 *__restrict__ qp, float *__restrict__ isq, float2 *__restrict__ diag,
+                                                     char *__restrict__ kimg, char *__restrict__ vimg) {
+    __shared__ float vt[32][FHD + 1];
+    const int tid = threadIdx.x, t = tid >> 3, s = tid & 7;
+    const int tile = blockIdx.x % nt, b = blockIdx.x / nt, head = blockIdx.y;
+    const int D = H * FHD, cpad = nt * 32;
+    const int tok = tile * 32 + t;
+    const bool real = tok < c;
+    const size_t row = ((size_t)b * c + (real ? tok : c - 1)) * D + (size_t)head * FHD;
+    float vs, ivs;
+    oa_pow2_scale(__uint_as_float(*vmax_bits), vs, ivs);
+
+    float2 qv[10], kv[10];
+    float qm = 0.f, km = 0.f, sii = 0.f, dz = 0.f;                   // the two diagonal terms q_i.k_i, q_i.ku_i: plain fp32
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int p = s + 8 * i;
+        const bool ok = real && p < 75;
+        const int pc = p < 75 ? p : 74;
+        const float2 a = *(const float2 *)(q_u + row + 2 * pc), bb = *(const float2 *)(k + row + 2 * pc), cc = *(const float2 *)(v + row + 2 * pc),
+                     uu = *(const float2 *)(k_u + row + 2 * pc);
+        qv[i] = ok ? a : make_float2(0.f, 0.f);
+        kv[i] = ok ? bb : make_float2(0.f, 0.f);
+        qm = fmaxf(qm, fmaxf(fabsf(qv[i].x), fabsf(qv[i].y)));
+        km = fmaxf(km, fmaxf(fabsf(kv[i].x), fabsf(kv[i].y)));
+        sii = fmaf(qv[i].x, kv[i].x, fmaf(qv[i].y, kv[i].y, sii));
+        dz = fmaf(qv[i].x, uu.x, fmaf(qv[i].y, uu.y, dz));
+        if (p < 75) { vt[t][2 * p] = ok ? cc.x * vs : 0.f; vt[t][2 * p + 1] = ok ? cc.y * vs : 0.f; }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        qm = fmaxf(qm, __shfl_xor(qm, o)); km = fmaxf(km, __shfl_xor(km, o));
+        sii += __shfl_xor(sii, o); dz += __shfl_xor(dz, o);
+    }
+    float qs, iqs, ks, iks;
+    oa_pow2_scale(qm, qs, iqs);
+    oa_pow2_scale(km, ks, iks);
+
+    const size_t th = ((size_t)b * cpad + tok) * H + head;
+    _Float16 *qrow = qp + th * (2 * FHP);
+    char *kbase = kimg + (((size_t)b * nt + tile) * H + head) * FK_IMG;
+    _Float16 *krow = (_Float16 *)kbase + t * FKLD;
+    if (s == 0) { isq[th] = iqs; diag[th] = make_float2(sii, dz); ((float *)(kbase + FK_ISK))[t] = iks; }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int p = s + 8 * i;                      // float2 piece; pieces 75..79 are the zero padding (dims 150..159)
+        h16x2 qh, ql, kh, kl;
+        const float x[4] = {qv[i].x * qs, qv[i].y * qs, kv[i].x * ks, kv[i].y * ks};
+        qh[0] = (_Float16)x[0]; ql[0] = (_Float16)(x[0] - (float)qh[0]);
+        qh[1] = (_Float16)x[1]; ql[1] = (_Float16)(x[1] - (float)qh[1]);
+        kh[0] = (_Float16)x[2]; kl[0] = (_Float16)(x[2] - (float)kh[0]);
+        kh[1] = (_Float16)x[3]; kl[1] = (_Float16)(x[3] - (float)kh[1]);
+        *(h16x2 *)(qrow + 2 * p) = qh;
+        *(h16x2 *)(qrow + FHP + 2 * p) = ql;
+        *(h16x2 *)(krow + 2 * p) = kh;
+        *(h16x2 *)(krow + FK_PLANE + 2 * p) = kl;
+    }
+    __syncthreads();
+    // V^T: thread = (dim d, group g of 8 permuted key positions): position 8 g + j holds key 16 (g >> 1) + 4 (g & 1) + (j & 3) + 8 (j >> 2)
+    _Float16 *vbase = (_Float16 *)(vimg + (((size_t)b * nt + tile) * H + head) * FV_IMG);
+    for (int e = tid; e < FHP * 4; e += 256) {
+        const int d = e >> 2, g = e & 3;
+        h16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = 16 * (g >> 1) + 4 * (g & 1) + (j & 3) + 8 * (j >> 2);
+            const float x = d < FHD ? vt[key][d] : 0.f;
+            hi[j] = (_Float16)x;
+            lo[j] = (_Float16)(x - (float)hi[j]);
+        }
+        *(h16x8 *)(vbase + d * FVLD + 8 * g) = hi;
+        *(h16x8 *)(vbase + FV_PLANE + d * FVLD + 8 * g) = lo;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void oa_attn_f16x3_kernel(const float *__restrict__ v,
+                                                              const float *__restrict__ v_u, int c, int H, int nt,
+                                                              const unsigned *__restrict__ vmax_bits, const _Float16 *__restrict__ qp,
+                                                              const float *__restrict__ isq, const float2 *__restrict__ diag,
+                                                              const char *__restrict__ kimg,
+                                                              const char *__restrict__ vimg, float *__restrict__ out,
+                                                              float *__restrict__ out_u) {
+    __shared__ __attribute__((aligned(1024))) char Ks[FK_IMG];
+    __shared__ __attribute__((aligned(1024))) char Vs[FV_IMG];
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qblocks = (c + 127) / 128;
+    int bid = blockIdx.x;
+    // workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous run, so that the query blocks of one
+    // (batch, head) - which stream the same key tiles - share one L2
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+    const int qb = qblocks - 1 - bid % qblocks; bid /= qblocks;      // heavy query blocks (late rows see more keys) first
+    const int head = bid % H, b = bid / H;
+    const int D = H * FHD, cpad = nt * 32;
+    const size_t base = (size_t)b * c * D + (size_t)head * FHD;
+    const int q0 = qb * 128, qi = q0 + w * 32 + col;
+    const int qc = qi < c ? qi : c - 1;
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    // Q fragments (B operand): query qc, dims 16 ch + 8 h .. + 7, both planes
+    h16x8 qh[10], ql[10];
+    float qmul;                                                       // 1 / s_q, 1 / sqrt(150) and log2(e) in one factor
+    {
+        const size_t th = ((size_t)b * cpad + qc) * H + head;
+        const _Float16 *src = qp + th * (2 * FHP) + 8 * h;
+#pragma unroll
+        for (int ch = 0; ch < 10; ++ch) { qh[ch] = *(const h16x8 *)(src + 16 * ch); ql[ch] = *(const h16x8 *)(src + FHP + 16 * ch); }
+        qmul = isq[th] * (LOG2E / sqrtf((float)FHD));
+    }
+    float sii, dz;                                                    // diagonal terms (oa_prep_kernel), log2 domain
+    {
+        const float2 dd = diag[((size_t)b * cpad + qc) * H + head];
+        const float sc2 = LOG2E / sqrtf((float)FHD);
+        sii = dd.x * sc2;
+        dz = dd.y * sc2;
+    }
+    f32x16h o[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                             // log2 domain
+
+    const int last_q = (q0 + 127 < c ? q0 + 127 : c - 1);
+    const int nkt = (last_q + 31) / 32;                               // tiles holding keys j < last_q
+    const int wave_last = q0 + w * 32 + 31;                           // this wave needs keys j < wave_last
+    const char *kt_base = kimg + ((size_t)b * nt * H + head) * FK_IMG, *vt_base = vimg + ((size_t)b * nt * H + head) * FV_IMG;
+    auto issue_k = [&](int kt) {
+        int ln;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));     // keep the address arithmetic next to the DMA (no hoisting, no spills)
+        const char *src = kt_base + (size_t)kt * H * FK_IMG + 16 * ln;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int i = w + 4 * j;
+            if (i < FK_IMG / 1024) __builtin_amdgcn_global_load_lds((oa_glb_ptr_t)(src + i * 1024), (oa_lds_ptr_t)(Ks + i * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_v = [&](int kt) {
+        int ln;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));
+        const char *src = vt_base + (size_t)kt * H * FV_IMG + 16 * ln;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int i = w + 4 * j;
+            if (i < FV_IMG / 1024) __builtin_amdgcn_global_load_lds((oa_glb_ptr_t)(src + i * 1024), (oa_lds_ptr_t)(Vs + i * 1024), 16, 0, 0);
+        }
+    };
+
+    if (nkt > 0) issue_k(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        SCP_WAIT_DMA(0);
+        __syncthreads();                                              // K tile kt has landed; every wave is done with V tile kt - 1
+        issue_v(kt);
+        const bool active = kt * 32 < wave_last;                      // wave-uniform: otherwise the tile is above this wave's diagonal
+        f32x16h sc;
+        if (active) {
+            // ---- S^T = K . Q^T ------------------------------------------------------------------------------------------
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+            const _Float16 *krow = (const _Float16 *)Ks + col * FKLD + 8 * h;
+#pragma unroll
+            for (int ch = 0; ch < 10; ++ch) {
+                const h16x8 kh = *(const h16x8 *)(krow + 16 * ch), kl = *(const h16x8 *)(krow + FK_PLANE + 16 * ch);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ch], sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ch], sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ch], sc, 0, 0, 0);
+            }
+            // ---- un-scale, strict causal mask (j < i), online softmax (log2 domain) ---------------------------------------
+            const float *isk = (const float *)(Ks + FK_ISK);
+            const int j0 = kt * 32 + 4 * h;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jl = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float sv = (sc[r] * isk[jl]) * qmul;
+                sc[r] = (j0 - 4 * h + jl < qi) ? sv : -INFINITY;
+                mx = fmaxf(mx, sc[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            // a query with no admissible key so far keeps (m, l, o) = (-inf, 0, 0): exp(-inf - (-inf)) must not produce NaN
+            const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[r] = (sc[r] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(sc[r] - m_new); ps += sc[r]; }
+            ps += __shfl_xor(ps, 32);
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+            if (__any(alpha != 1.f)) {
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+            }
+        }
+        SCP_WAIT_DMA(0);
+        __syncthreads();                                              // V tile kt has landed; every wave is done with K tile kt
+        if (kt + 1 < nkt) issue_k(kt + 1);
+        if (active) {
+            // ---- O^T += V^T . P^T: chunk cc pairs accumulator registers 8 cc .. 8 cc + 7 with V^T columns 16 cc + 8 h + j ----
+            const _Float16 *vrow = (const _Float16 *)Vs + col * FVLD + 8 * h;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                h16x8 ph, pl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = sc[8 * cc + j];
+                    const _Float16 hh = (_Float16)x;
+                    ph[j] = hh;
+                    pl[j] = (_Float16)(x - (float)hh);
+                }
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    const h16x8 vh = *(const h16x8 *)(vrow + 32 * t * FVLD + 16 * cc), vl = *(const h16x8 *)(vrow + FV_PLANE + 32 * t * FVLD + 16 * cc);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue: out_i = (A e^{M-m} + e^{s_ii-m} v_i) / (L e^{M-m} + e^{s_ii-m}), out_u likewise with dz_i, vu_i.  The accumulators
+    //      hold one query per lane (rows 2400 B apart): each 32-dim slab goes through a wave-private LDS tile so that loads of
+    //      v / v_u and the stores move 128 contiguous bytes per row (16 lanes x float2, four rows per instruction)
+    __syncthreads();                                                  // every wave is done with the operand tiles
+    float vs, ivs;
+    oa_pow2_scale(__uint_as_float(*vmax_bits), vs, ivs);
+    const float m1 = fmaxf(m_run, sii), m2 = fmaxf(m_run, dz);
+    const float eo1 = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m1), ed1 = __builtin_amdgcn_exp2f(sii - m1);
+    const float eo2 = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m2), ed2 = __builtin_amdgcn_exp2f(dz - m2);
+    const float inv1 = 1.f / (l_run * eo1 + ed1), inv2 = 1.f / (l_run * eo2 + ed2);
+    constexpr int SLD = 34;                                           // floats per staged row (even: float2 reads stay aligned)
+    float *stg = (float *)Ks + w * (32 * SLD);
+    float *coef = (float *)Vs + w * 128;
+    if (h == 0) *(float4 *)(coef + 4 * col) = make_float4(eo1 * inv1 * ivs, ed1 * inv1, eo2 * inv2 * ivs, ed2 * inv2);
+    const int rsub = lane >> 4, pp = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[col * SLD + (r & 3) + 8 * (r >> 2) + 4 * h] = o[t][r];
+        __builtin_amdgcn_wave_barrier();
+        const int d = 32 * t + 2 * pp;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int ql_ = pass * 4 + rsub, qr_ = q0 + w * 32 + ql_;
+            if (qr_ < c && d < FHD) {
+                const float2 ov = *(const float2 *)(stg + ql_ * SLD + 2 * pp);
+                const float4 cf = *(const float4 *)(coef + 4 * ql_);
+                const size_t ro = base + (size_t)qr_ * D + d;
+                const float2 vv = *(const float2 *)(v + ro), vu = *(const float2 *)(v_u + ro);
+                *(float2 *)(out + ro) = make_float2(fmaf(cf.y, vv.x, cf.x * ov.x), fmaf(cf.y, vv.y, cf.x * ov.y));
+                *(float2 *)(out_u + ro) = make_float2(fmaf(cf.w, vu.x, cf.z * ov.x), fmaf(cf.w, vu.y, cf.z * ov.y));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+static inline size_t oa_align(size_t x) { return (x + 1023) & ~(size_t)1023; }
+
+extern "C" SCP_API int64_t scp_octattn_f16x3_ws_bytes(int32_t B, int32_t c, int32_t H) {
+    if (B <= 0 || c <= 0 || H <= 0) return SCP_EINVAL;
+    const size_t nt = (size_t)(c + 31) / 32, rows = (size_t)B * nt * 32 * H;
+    return (int64_t)(1024 + oa_align(rows * 4) + oa_align(rows * 8) + oa_align(rows * 2 * FHP * 2) + (size_t)B * nt * H * (FK_IMG + FV_IMG));
+}
+
+extern "C" SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
+                                                   int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *workspace,
+                                                   int64_t ws_bytes, void *stream) {
+    if (!q_u || !k || !k_u || !v || !v_u || !out || !out_u || !workspace || B <= 0 || c <= 0 || c > 1024 || H <= 0 || hd != FHD || ((H * FHD) & 3) ||
+        ((((uintptr_t)q_u | (uintptr_t)k | (uintptr_t)v) & 15) != 0) || ((uintptr_t)workspace & 1023) ||
+        ws_bytes < scp_octattn_f16x3_ws_bytes(B, c, H))
+        return SCP_EINVAL;
+    const int nt = (c + 31) / 32;
+    const size_t rows = (size_t)B * nt * 32 * H;
+    char *ws = (char *)workspace;
+    unsigned *vmax = (unsigned *)ws;
+    float *isq = (float *)(ws + 1024);
+    float2 *diag = (float2 *)(ws + 1024 + oa_align(rows * 4));
+    _Float16 *qp = (_Float16 *)((char *)diag + oa_align(rows * 8));
+    char *kimg = (char *)qp + oa_align(rows * 2 * FHP * 2);
+    char *vimg = kimg + (size_t)B * nt * H * FK_IMG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(vmax, 0, 4, st) != hipSuccess) return SCP_EHIP;
+    const int64_t n4 = (int64_t)B * c * H * FHD / 4;                 // 600 floats per token: a multiple of 4
+    hipLaunchKernelGGL(oa_absmax_kernel, dim3((unsigned)(n4 < 256 * 1024 ? (n4 + 255) / 256 : 1024)), dim3(256), 0, st, v, n4, vmax);
+    hipLaunchKernelGGL(oa_prep_kernel, dim3(B * nt, H), dim3(256), 0, st, q_u, k, k_u, v, c, H, nt, vmax, qp, isq, diag, kimg, vimg);
+    hipLaunchKernelGGL(oa_attn_f16x3_kernel, dim3(B * H * ((c + 127) / 128)), dim3(256), 0, st, v, v_u, c, H, nt, vmax, qp, isq, diag,
+                       kimg, vimg, out, out_u);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}

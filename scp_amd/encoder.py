@@ -330,7 +330,7 @@ class OctAttnFrameEncoder:
     with context_size-1 rows (occ 255), cut into consecutive 1024-windows; node r is predicted at position (r+1023) % 1024
     of window (r+1023) // 1024.  Plain BFS coding order.  `--cylin` is wired here (the reference forgot to, SURVEY B-7)."""
 
-    def __init__(self, model, data_type=KITTI, lidar_level=12, spher=True, cylin=False, max_batch=16, device=None):
+    def __init__(self, model, data_type=KITTI, lidar_level=12, spher=True, cylin=False, max_batch=128, device=None):
         self.model = model
         self.data_type = data_type
         self.lidar_level = lidar_level

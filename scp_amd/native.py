@@ -81,8 +81,12 @@ def lib():
         "scp_edge_gather_max": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_swin_attention": (C.c_int, [_vp, _vp, _vp, _vp, i32, i32, i32, i32, i32, _vp, _vp]),
         "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
+        "scp_octattn_f16x3_ws_bytes": (C.c_int64, [i32, i32, i32]),
+        "scp_octattn_attention_f16x3": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp, i64, _vp]),
         "scp_split_weight_bf16": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp, _vp]),
         "scp_linear_bf16x3": (C.c_int, [_vp, i64, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp]),
+        "scp_split_weight_f16": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp, _vp, _vp]),
+        "scp_linear_f16x3": (C.c_int, [_vp, i64, _vp, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp, _vp]),
         "scp_linear_split": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_split_rows": (C.c_int, [_vp, i64, i64, _vp, i32, _vp, _vp, i64, i64, _vp]),
         "scp_linear_split_scatter": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
@@ -438,6 +442,43 @@ def linear_bf16x3(x, sw, bias=None, act=ACT_NONE, residual=None, out=None):
     return out.reshape(*lead, N) if out.dim() == 2 and len(lead) != 1 else out
 
 
+class SplitWeightF16:
+    """Row-scaled f16 hi/lo planes of a Linear weight [N,K] (scp_split_weight_f16), zero-padded to [Npad,Kpad]."""
+
+    def __init__(self, w):
+        N, K = w.shape
+        self.N, self.K = N, K
+        self.Npad, self.Kpad = -(-N // 128) * 128, -(-K // 32) * 32
+        self.hi = torch.empty((self.Npad, self.Kpad), dtype=torch.float16, device=w.device)
+        self.lo = torch.empty_like(self.hi)
+        self.inv_scale = torch.empty((self.Npad,), dtype=torch.float32, device=w.device)
+        wc = w.detach().contiguous().float()
+        _check(lib().scp_split_weight_f16(_dev(wc), N, K, self.Npad, self.Kpad, _dev(self.hi), _dev(self.lo), _dev(self.inv_scale),
+                                          _stream()), "scp_split_weight_f16")
+
+
+def linear_f16x3(x, sw, bias=None, act=ACT_NONE, residual=None):
+    """x [..., K] fp32 -> act(x @ W.T + bias) + residual, [..., N] fp32, on the f16x3 kernel (22-bit operands, row scaled)."""
+    K, N = sw.K, sw.N
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or (x2.stride(0) & 3) or (x2.data_ptr() & 15):
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    ws = torch.empty((2 * M,), dtype=torch.float32, device=x.device)
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, N)
+        if r2.stride(1) != 1:
+            r2 = r2.contiguous()
+    rc = lib().scp_linear_f16x3(x2.data_ptr(), x2.stride(0), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.inv_scale.data_ptr(), sw.Kpad,
+                                _opt(bias), None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0), out.data_ptr(),
+                                out.stride(0), M, N, K, act, ws.data_ptr(), _stream())
+    _check(rc, "scp_linear_f16x3")
+    return out.reshape(*lead, N)
+
+
 class SplitAct:
     """An activation [M, K] as bf16 planes hi = bf16(x), lo = bf16(x - hi): t is bfloat16 [2, M, ld] (ld = K rounded up to 32,
     padding columns zero) or a column slice of such a buffer.  This is the operand format of scp_linear_split."""
@@ -565,10 +606,24 @@ def linear_f32(x, w, bias=None, act=ACT_NONE):
     return out.reshape(*lead, N)
 
 
+OCTATTN_MODE = os.environ.get("SCP_OCTATTN", "f16x3")   # "f32": the fp32 MFMA kernel for head width 150 as well
+
+
 def octattn_attention(q_u, k, k_u, v, v_u, heads):
+    """Dual-stream causal attention (models/attention_model.py:58-95).  Head width 150 (the reference configuration) runs on the
+    f16x3 kernel (22-bit operands on f16 MFMA, csrc/octattn_f16.hip); SCP_OCTATTN=f32 or any other width: the fp32 kernels."""
     B, c, D = q_u.shape
     out, out_u = torch.empty_like(q_u), torch.empty_like(q_u)
-    rc = lib().scp_octattn_attention(_dev(q_u), _dev(k), _dev(k_u), _dev(v), _dev(v_u), B, c, heads, D // heads,
+    hd = D // heads
+    if OCTATTN_MODE == "f16x3" and hd == 150 and (D & 3) == 0:
+        nb = lib().scp_octattn_f16x3_ws_bytes(B, c, heads)
+        ws = torch.empty((nb + 1024,), dtype=torch.uint8, device=q_u.device)
+        off = (-ws.data_ptr()) % 1024
+        rc = lib().scp_octattn_attention_f16x3(_dev(q_u), _dev(k), _dev(k_u), _dev(v), _dev(v_u), B, c, heads, hd, _dev(out),
+                                               _dev(out_u), ws.data_ptr() + off, nb, _stream())
+        _check(rc, "scp_octattn_attention_f16x3")
+        return out, out_u
+    rc = lib().scp_octattn_attention(_dev(q_u), _dev(k), _dev(k_u), _dev(v), _dev(v_u), B, c, heads, hd,
                                      _dev(out), _dev(out_u), _stream())
     _check(rc, "scp_octattn_attention")
     return out, out_u

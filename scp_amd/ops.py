@@ -36,15 +36,33 @@ def _split(w):
     return ent[0]
 
 
+_cache16 = {}
+
+
+def _split16(w):
+    """row-scaled f16 hi/lo planes of a weight (native.SplitWeightF16), cached like _split."""
+    key = id(w)
+    ent = _cache16.get(key)
+    if ent is None or ent[1] != w._version or ent[2]() is not w:
+        sw = native.SplitWeightF16(w)
+        _cache16[key] = (sw, w._version, weakref.ref(w, lambda _r, k=key: _cache16.pop(k, None)))
+        return sw
+    return ent[0]
+
+
 def clear_cache():
     _cache.clear()
+    _cache16.clear()
 
 
-def linear(x, w, b=None, act=None, residual=None, exact=False):
-    """act(x @ w.T + b) + residual.  exact=True keeps plain fp32 (used where the result feeds a kNN search)."""
+def linear(x, w, b=None, act=None, residual=None, exact=False, precise=False):
+    """act(x @ w.T + b) + residual.  exact=True keeps plain fp32 (used where the result feeds a kNN search); precise=True uses
+    the f16x3 kernel (22-bit operands: fp32-chain accuracy at the MFMA rate; OctAttention)."""
     K = w.shape[1]
     if MODE == "bf16x3" and x.is_cuda:
-        if not exact and K % 4 == 0 and K >= 32:
+        if precise and not exact and K % 4 == 0 and K >= 32:
+            return native.linear_f16x3(x, _split16(w), b, _ACT[act], residual)
+        if not exact and not precise and K % 4 == 0 and K >= 32:
             return native.linear_bf16x3(x, _split(w), b, _ACT[act], residual)
         # exact fp32 MFMA kernel: k-ordered FMA chains, results independent of how many rows share the launch
         y = native.linear_f32(x, w, b, _ACT[act])

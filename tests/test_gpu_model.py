@@ -297,6 +297,43 @@ def test_packed_forward_equals_per_window_forward(dev, ehem):
     assert worst < 2e-4, worst
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 255, 600), (7, 16, 32), (300, 600, 300), (1000, 300, 600), (4100, 255, 512), (513, 240, 80)])
+@pytest.mark.parametrize("act", [None, "relu"])
+def test_linear_f16x3_vs_float64(dev, M, N, K, act):
+    """f16x3 (22-bit operands, one power-of-two scale per row of A and of W): the error of an fp32 FMA chain, for rows whose
+    magnitudes differ by many orders (each row has its own scale), zero rows included; one row alone gives the same bits as the
+    row inside the batch."""
+    from scp_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn((M, K), generator=g) * 25.0
+    rowmag = torch.pow(10.0, torch.randint(-6, 7, (M, 1), generator=g).float())
+    x = x * rowmag
+    if M > 4:
+        x[3] = 0.0
+    w = torch.randn((N, K), generator=g) / K ** 0.5
+    w = w * torch.pow(10.0, torch.randint(-3, 4, (N, 1), generator=g).float())
+    b = torch.randn(N, generator=g)
+    r = torch.randn((M, N), generator=g)
+    ops.set_mode("bf16x3")
+    xd, wd, bd, rd = x.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    # the bare product, against the magnitude its rounding errors are relative to
+    scale = (x.double().abs() @ w.double().abs().T) + 1e-300
+    ref0 = x.double() @ w.double().T
+    err = ((ops.linear(xd, wd, precise=True).cpu().double() - ref0).abs() / scale).max().item()
+    err32 = ((ops.linear(xd, wd, exact=True).cpu().double() - ref0).abs() / scale).max().item()
+    print(f"M={M} N={N} K={K}: f16x3 rel err {err:.2e} (exact fp32 MFMA chain {err32:.2e})")
+    assert err < 1.5e-6, err
+    # epilogue: bias, activation, residual
+    y = ops.linear(xd, wd, bd, act=act, residual=rd, precise=True)
+    ref = ref0 + b.double()
+    if act == "relu":
+        ref = torch.relu(ref)
+    ref = ref + r.double()
+    assert ((y.cpu().double() - ref).abs() / (scale + 1.0)).max().item() < 2e-6
+    one = ops.linear(xd[M // 2:M // 2 + 1], wd, bd, act=act, residual=rd[M // 2:M // 2 + 1], precise=True)
+    assert torch.equal(one[0], y[M // 2])
+
+
 # ----------------------------------------------------------------------------------------------- OctAttention
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_octattn_*.npz"))))
 def test_octattn_logits_vs_reference(dev, octattn, name):
@@ -309,6 +346,52 @@ def test_octattn_logits_vs_reference(dev, octattn, name):
     e = np.abs(o - z["out"]).max()
     print(f"{name}: max|dlogit| = {e:.3e}")
     assert e <= LOGIT_TOL
+
+
+@pytest.mark.parametrize("B,c", [(1, 1), (2, 37), (3, 300), (2, 1024), (1, 129)])
+def test_octattn_attention_f16x3_vs_fp32_mfma(dev, B, c):
+    """Dual-stream causal attention on f16 MFMA (22-bit operands, power-of-two scales) against the fp32 MFMA kernel and a float64
+    evaluation of attention_model.py:58-95; rows of very different magnitude (each (token, head) has its own q / k scale)."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(B * 1000 + c)
+    H, hd = 4, 150
+    D = H * hd
+    # per-token magnitudes 2^-6 .. 2 on both sides: scores up to ~N(0, 4^2), a softmax from flat to sharp
+    mq = torch.pow(2.0, torch.randint(-6, 2, (B, c, 1), generator=g).float())
+    mk = torch.pow(2.0, torch.randint(-6, 2, (B, c, 1), generator=g).float())
+    q_u = (torch.randn((B, c, D), generator=g) * mq).to(dev)
+    k = (torch.randn((B, c, D), generator=g) * mk).to(dev)
+    k_u = (torch.randn((B, c, D), generator=g) * mk).to(dev)
+    v = (torch.randn((B, c, D), generator=g) * 7.0).to(dev)
+    v_u = (torch.randn((B, c, D), generator=g) * 7.0).to(dev)
+    keep = native.OCTATTN_MODE
+    try:
+        native.OCTATTN_MODE = "f16x3"
+        o16, ou16 = native.octattn_attention(q_u, k, k_u, v, v_u, H)
+        native.OCTATTN_MODE = "f32"
+        o32, ou32 = native.octattn_attention(q_u, k, k_u, v, v_u, H)
+    finally:
+        native.OCTATTN_MODE = keep
+
+    def ref(qq, kk, kku, vv, vvu):
+        qq, kk, kku, vv, vvu = [t.double().cpu().reshape(B, c, H, hd).transpose(1, 2) for t in (qq, kk, kku, vv, vvu)]
+        s = qq @ kk.transpose(-1, -2) / hd ** 0.5
+        du = (qq * kku).sum(-1) / hd ** 0.5
+        eye = torch.eye(c, dtype=torch.bool)
+        causal = torch.tril(torch.ones(c, c, dtype=torch.bool))
+        s1 = s.masked_fill(~causal, -float("inf"))
+        o = torch.softmax(s1, -1) @ vv
+        s2 = torch.where(eye, du.unsqueeze(-1).expand_as(s), s).masked_fill(~causal, -float("inf"))
+        p2 = torch.softmax(s2, -1)
+        ou = (p2.masked_fill(eye, 0.0)) @ vv + torch.diagonal(p2, dim1=-2, dim2=-1).unsqueeze(-1) * vvu
+        return [t.transpose(1, 2).reshape(B, c, D) for t in (o, ou)]
+
+    r, ru = ref(q_u, k, k_u, v, v_u)
+    e16 = max((o16.cpu().double() - r).abs().max().item(), (ou16.cpu().double() - ru).abs().max().item())
+    e32 = max((o32.cpu().double() - r).abs().max().item(), (ou32.cpu().double() - ru).abs().max().item())
+    print(f"B={B} c={c}: f16x3 max err {e16:.2e}, fp32 MFMA max err {e32:.2e} (|out| max {r.abs().max().item():.1f})")
+    assert e16 < 1e-4 and e32 < 1e-4
+    assert e16 < 4 * e32 + 2e-6
 
 
 @pytest.mark.gpu
