@@ -368,18 +368,25 @@ class OctAttnFrameEncoder:
             table[N - 1] = self.model(seq_ctx[-1:].reshape(1, 1, 4, 3), seq_pos[-1:].reshape(1, 1, 4, 3))[0, -1]
         return table
 
-    def encode_ints(self, q, bin_num, n_points, t0=None, sequential=False):
-        t0 = t0 or time.perf_counter()
-        if isinstance(q, np.ndarray):
-            q = torch.from_numpy(np.ascontiguousarray(q, np.int32))
-        q = q.to(self.device)
+    def _front(self, q):
+        """stage G + the front-padded context sequence (encode_dataset.py:32-55) on the current stream"""
         self.geom.build(q.contiguous(), [(0, q.shape[0], None, False)])
         ctx, pos, sym = self.geom.context_octattn(0)
-        N, cs = ctx.shape[0], self.context_size
+        cs = self.context_size
         pad_ctx = torch.zeros((cs - 1, 12), dtype=torch.uint8, device=self.device)
         pad_ctx[:, 0::3] = 255
         seq_ctx = torch.cat((pad_ctx, ctx))
         seq_pos = torch.cat((torch.zeros((cs - 1, 4, 3), dtype=torch.float32, device=self.device), pos))
+        return seq_ctx, seq_pos, sym, ctx.shape[0]
+
+    def encode_ints(self, q, bin_num, n_points, t0=None, sequential=False, defer=False, front=None):
+        t0 = t0 or time.perf_counter()
+        if isinstance(q, np.ndarray):
+            q = torch.from_numpy(np.ascontiguousarray(q, np.int32))
+        q = q.to(self.device)
+        front = self._front(q) if front is None else front
+        seq_ctx, seq_pos, sym, N = front
+        cs = self.context_size
         total = N + cs - 1
         table = torch.empty((N, 255), dtype=torch.float32, device=self.device)
         n_full = total // cs
@@ -400,12 +407,57 @@ class OctAttnFrameEncoder:
             out = self.model(d, p)[0]
             lo = n_full * cs - (cs - 1)
             table[max(lo, 0):] = out[max(-lo, 0):]
-        lohi = native.softmax_cdf(table, sym)["lohi"].cpu().numpy()
-        stream = native.ac_encode_lohi(lohi)
+        lohi = native.softmax_cdf(table, sym)["lohi"]
+        meta = dict(n_nodes=N, n_points=n_points, bin_num=bin_num, z_offset=0.0, n_levels=1, pos_mm=np.zeros((0, 2)), level_sizes=[N])
+        if defer:
+            return lohi, meta, (table, sym, seq_ctx, seq_pos)
+        stream = native.ac_encode_lohi(lohi.cpu().numpy())
         bits = 8 * len(stream)
-        return dict(bytes=stream, bits=bits, bpp=bits / n_points, n_nodes=N, n_points=n_points, bin_num=bin_num, z_offset=0.0,
-                    n_levels=1, pos_mm=np.zeros((0, 2)), level_sizes=[N], times=dict(total=time.perf_counter() - t0),
-                    _debug=dict(table=table, sym_coded=sym))
+        return dict(bytes=stream, bits=bits, bpp=bits / n_points, times=dict(total=time.perf_counter() - t0),
+                    _debug=dict(table=table, sym_coded=sym), **meta)
+
+    def encode_async(self, xyz):
+        """Like encode(), but the D2H copy of the (c_low, c_high) pairs and the serial host range coder run on a worker thread
+        behind an event on a side stream (the same scheme as FrameEncoder.encode_async): the caller can enqueue the next frame
+        while this one is being coded.  `finish(handle)` blocks and returns the usual result dict."""
+        t0 = time.perf_counter()
+        if isinstance(xyz, np.ndarray):
+            xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
+        if not hasattr(self, "_pool"):
+            self._pool = ThreadPoolExecutor(max_workers=2)
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._front_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        # stage G has small D2H syncs: on a high-priority side stream they wait for stage G only, not for the previous frame's
+        # model kernels still queued on the main stream
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._front_stream):
+            xyz_dev = xyz.to(self.device, non_blocking=True)
+            q, qi, _ = native.quantize(xyz_dev, self.mode, level_qs(self.data_type, self.lidar_level), self.cart_offset)
+            front = self._front(q)
+            ready = torch.cuda.Event()
+            ready.record()
+        main.wait_event(ready)
+        lohi, meta, keep = self.encode_ints(q, qi.bin_num, xyz_dev.shape[0], t0, defer=True, front=front)
+        done = torch.cuda.Event()
+        done.record()
+        host = torch.empty(lohi.shape, dtype=lohi.dtype, pin_memory=True)
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(done)
+            host.copy_(lohi, non_blocking=True)
+            lohi.record_stream(self._copy_stream)
+            copied = torch.cuda.Event()
+            copied.record()
+
+        def work():
+            copied.synchronize()
+            return native.ac_encode_lohi(host.numpy())
+
+        return dict(future=self._pool.submit(work), meta=meta, t0=t0, keep=(keep, lohi, q, xyz_dev))
+
+    def finish(self, h):
+        stream = h["future"].result()
+        bits = 8 * len(stream)
+        return dict(bytes=stream, bits=bits, bpp=bits / h["meta"]["n_points"], times=dict(total=time.perf_counter() - h["t0"]), **h["meta"])
 
     def outfile(self, base, res):
         return base + ".bin"

@@ -106,21 +106,18 @@ class OctAttention(nn.Module):
             parts.append(pe)
             parts_u.append(pe)
         D = self.embed_dimension
-        emb = torch.cat(parts, 3).reshape(B, c, D) * math.sqrt(D)
-        emu = torch.cat(parts_u, 3).reshape(B, c, D) * math.sqrt(D)
-        tab = self.transformer_encoder.position_enc.pe[:c]
-        emb, emu = emb + tab, emu + tab
+        # both streams travel as one [2, B, c, D] tensor (0: known, 1: unknown): every layer they share runs as one launch
+        E = torch.stack((torch.cat(parts, 3).reshape(B, c, D), torch.cat(parts_u, 3).reshape(B, c, D))) * math.sqrt(D)
+        E = E + self.transformer_encoder.position_enc.pe[:c]
         for lyr in self.transformer_encoder.layers:
             a = lyr.attn
-            key, key_u = linear(emb, a.mlp_key.weight, a.mlp_key.bias), linear(emu, a.mlp_key.weight, a.mlp_key.bias)
-            q_u = linear(emu, a.mlp_query.weight, a.mlp_query.bias)
-            val, val_u = linear(emb, a.mlp_value.weight, a.mlp_value.bias), linear(emu, a.mlp_value.weight, a.mlp_value.bias)
-            out, out_u = native.octattn_attention(q_u.contiguous(), key.contiguous(), key_u.contiguous(), val.contiguous(),
-                                                  val_u.contiguous(), self.heads)
-            emb = F.layer_norm(out + emb, (D,), lyr.norm1.weight, lyr.norm1.bias, 1e-5)
-            emu = F.layer_norm(out_u + emu, (D,), lyr.norm1.weight, lyr.norm1.bias, 1e-5)
-            emb = F.layer_norm(linear(linear(emb, lyr.linear1.weight, lyr.linear1.bias, act="relu"), lyr.linear2.weight,
-                                      lyr.linear2.bias, residual=emb), (D,), lyr.norm2.weight, lyr.norm2.bias, 1e-5)
-            emu = F.layer_norm(linear(linear(emu, lyr.linear1.weight, lyr.linear1.bias, act="relu"), lyr.linear2.weight,
-                                      lyr.linear2.bias, residual=emu), (D,), lyr.norm2.weight, lyr.norm2.bias, 1e-5)
+            key = linear(E, a.mlp_key.weight, a.mlp_key.bias)
+            val = linear(E, a.mlp_value.weight, a.mlp_value.bias)
+            q_u = linear(E[1], a.mlp_query.weight, a.mlp_query.bias)
+            att = torch.empty_like(E)
+            native.octattn_attention(q_u, key[0], key[1], val[0], val[1], self.heads, out=att[0], out_u=att[1])
+            E = F.layer_norm(att + E, (D,), lyr.norm1.weight, lyr.norm1.bias, 1e-5)
+            E = F.layer_norm(linear(linear(E, lyr.linear1.weight, lyr.linear1.bias, act="relu"), lyr.linear2.weight,
+                                    lyr.linear2.bias, residual=E), (D,), lyr.norm2.weight, lyr.norm2.bias, 1e-5)
+        emu = E[1]
         return linear(linear(emu, self.decoder0.weight, self.decoder0.bias, act="relu"), self.decoder1.weight, self.decoder1.bias)

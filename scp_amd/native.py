@@ -609,11 +609,14 @@ def linear_f32(x, w, bias=None, act=ACT_NONE):
 OCTATTN_MODE = os.environ.get("SCP_OCTATTN", "f16x3")   # "f32": the fp32 MFMA kernel for head width 150 as well
 
 
-def octattn_attention(q_u, k, k_u, v, v_u, heads):
+def octattn_attention(q_u, k, k_u, v, v_u, heads, out=None, out_u=None):
     """Dual-stream causal attention (models/attention_model.py:58-95).  Head width 150 (the reference configuration) runs on the
     f16x3 kernel (22-bit operands on f16 MFMA, csrc/octattn_f16.hip); SCP_OCTATTN=f32 or any other width: the fp32 kernels."""
     B, c, D = q_u.shape
-    out, out_u = torch.empty_like(q_u), torch.empty_like(q_u)
+    if out is None:
+        out, out_u = torch.empty_like(q_u), torch.empty_like(q_u)
+    elif not (out.is_contiguous() and out_u.is_contiguous() and out.shape == q_u.shape and out_u.shape == q_u.shape):
+        raise ScpError("octattn_attention: out / out_u must be contiguous [B, c, D] float32")
     hd = D // heads
     if OCTATTN_MODE == "f16x3" and hd == 150 and (D & 3) == 0:
         nb = lib().scp_octattn_f16x3_ws_bytes(B, c, heads)

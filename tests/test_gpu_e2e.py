@@ -139,6 +139,24 @@ def test_octattn_frame_vs_reference_driver(orc):
     assert orc.ac_encode(cdf, sym.astype(np.int16)) == res["bytes"]
 
 
+def test_octattn_async_pipeline_equals_sync():
+    """OctAttnFrameEncoder.encode_async / finish (range coder on a worker thread) give the bytes of encode(), frames in flight."""
+    from cfgs import octattn_cfg
+    from scp_amd.encoder import OctAttnFrameEncoder
+    from scp_amd.models import OctAttention
+    from scp_amd.synth import synth_frame
+    from scp_amd.weights import fill_weights
+    dev = torch.device("cuda:0")
+    model = fill_weights(OctAttention(octattn_cfg()), 0).to(dev)
+    enc = OctAttnFrameEncoder(model, "kitti", 12, cylin=True, device=dev)
+    frames = [synth_frame(s)[::9].copy() for s in (4, 5, 6)]
+    want = [enc.encode(f) for f in frames]
+    hs = [enc.encode_async(f) for f in frames]
+    got = [enc.finish(h) for h in hs]
+    assert [g["bytes"] for g in got] == [w["bytes"] for w in want]
+    assert [g["n_nodes"] for g in got] == [w["n_nodes"] for w in want] and got[0]["bpp"] == want[0]["bpp"]
+
+
 def test_numpyac_api_roundtrip():
     """B3: arithmeticCoding / arithmeticDeCoding keep the reference's names and argument order."""
     from scp_amd import numpyAc

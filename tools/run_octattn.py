@@ -17,3 +17,16 @@ for i in range(3):
     res = enc.encode(xyz)
     torch.cuda.synchronize(); dt = time.perf_counter() - t
     print(f"frame {i}: {dt*1e3:.1f} ms nodes {res['n_nodes']} bpp {res['bpp']:.3f}", flush=True)
+# pipelined throughput: the host range coder of frame k runs under the GPU work of frame k + 1
+frames = [synth_frame(i) for i in range(12)]
+for f in frames[:2]: enc.finish(enc.encode_async(f))
+torch.cuda.synchronize(); t = time.perf_counter()
+prev = None
+outs = []
+for f in frames:
+    h = enc.encode_async(f)
+    if prev is not None: outs.append(enc.finish(prev))
+    prev = h
+outs.append(enc.finish(prev))
+torch.cuda.synchronize(); dt = time.perf_counter() - t
+print(f"pipelined: {dt / len(frames) * 1e3:.1f} ms per frame ({len(frames) / dt:.2f} frames/s), bpp {outs[1]['bpp']:.3f}", flush=True)
