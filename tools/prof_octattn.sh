@@ -8,7 +8,8 @@ import csv, glob
 f = glob.glob("$R/gpurun_out/prof_$1/*/*kernel_stats.csv")[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"total kernel time {tot/3e6:.1f} ms per frame")
+nf = 17   # run_octattn.py: 3 single frames + 2 warm-up + 12 pipelined
+print(f"total kernel time {tot/nf/1e6:.1f} ms per frame ({nf} frames)")
 for r in rows[:16]:
-    print(f"{r['Name'][:70]:70s} {int(r['Calls'])//3:5d} {float(r['TotalDurationNs'])/3e6:8.2f} ms")
+    print(f"{r['Name'][:70]:70s} {int(r['Calls'])/nf:6.1f} {float(r['TotalDurationNs'])/nf/1e6:8.2f} ms")
 PY
