@@ -72,6 +72,27 @@ def test_knn_topk_is_a_valid_topk(dev, B, n, C):
     assert (got.diff(dim=2) <= tol).all()
 
 
+@pytest.mark.parametrize("n,C,span", [(20, 3, 2), (33, 3, 3), (1000, 3, 6), (8192, 3, 12), (2500, 144, 2), (4096, 192, 2), (300, 192, 1)])
+def test_knn_exact_order_under_heavy_ties(dev, n, C, span):
+    """Small-integer features: every product and sum is exact in fp32 (and in the f16x3 split), so the distances are exact and
+    massively tied (duplicates included).  The result must be THE top-20 under (distance ascending, index ascending) - this
+    pins the pruning bound (union of the two half-lists), the cut of pass 1 (ties must pass) and the final merge."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(n + C)
+    x = torch.randint(0, span + 1, (1, n, C), generator=g).float()
+    k = min(20, n)
+    got = native.knn_topk(x.to(dev), k).cpu().long()[0]
+    xi = x[0].long()
+    d = ((xi[:, None, :] - xi[None, :, :]) ** 2).sum(-1) if n <= 2500 else None
+    if d is None:   # blockwise exact integer distances
+        d = torch.empty((n, n), dtype=torch.int64)
+        for i0 in range(0, n, 512):
+            d[i0:i0 + 512] = ((xi[i0:i0 + 512, None, :] - xi[None, :, :]) ** 2).sum(-1)
+    key = d * n + torch.arange(n)[None, :]                            # distance major, index minor: unique keys
+    want = torch.topk(key, k, dim=1, largest=False)[1]
+    assert torch.equal(got, want), (got[:2], want[:2])
+
+
 def test_knn_matches_cpu_reference_topk_on_real_window(dev):
     from scp_amd import native
     from oracle import models_ref
