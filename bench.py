@@ -44,12 +44,12 @@ def measure_dominant_kernel(enc, xyz_dev):
     the C ABI launches them): the dominant kernel (gemm_split_kernel, all tile / epilogue variants) and, for the secondary
     roofline entries, the window attention and the feature-space kNN searches.  ALGORITHMIC flops only."""
     from scp_amd import native
-    recs = {"gemm": [], "attn": [], "knn": []}
+    recs = {"gemm": [], "attn": [], "knn": [], "mlp": []}
 
     def ev():
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    o_lin, o_att, o_knn = native.linear_split, native.swin_attention_packed, native.knn_topk_packed
+    o_lin, o_att, o_knn, o_mlp = native.linear_split, native.swin_attention_packed, native.knn_topk_packed, native.mlp_split_fused
 
     def lin(a, sw, *args, **kw):
         s, e = ev(); s.record(); y = o_lin(a, sw, *args, **kw); e.record()
@@ -67,12 +67,17 @@ def measure_dominant_kernel(enc, xyz_dev):
         recs["knn"].append((s, e, float((n * 512).sum().item()) * 2.0 * max(4, x.shape[1]), x.shape[1]))   # sum over 512-row chunks of n * 512 pairs
         return y
 
-    native.linear_split, native.swin_attention_packed, native.knn_topk_packed = lin, att, knn
+    def mlp(a, *args, **kw):
+        s, e = ev(); s.record(); y = o_mlp(a, *args, **kw); e.record()
+        recs["mlp"].append((s, e, 2.0 * a.M * 256 * 1024 * 2))              # fc1 + fc2
+        return y
+
+    native.linear_split, native.swin_attention_packed, native.knn_topk_packed, native.mlp_split_fused = lin, att, knn, mlp
     try:
         enc.encode(xyz_dev)
         torch.cuda.synchronize()
     finally:
-        native.linear_split, native.swin_attention_packed, native.knn_topk_packed = o_lin, o_att, o_knn
+        native.linear_split, native.swin_attention_packed, native.knn_topk_packed, native.mlp_split_fused = o_lin, o_att, o_knn, o_mlp
 
     def summ(rs):
         ms = sum(r[0].elapsed_time(r[1]) for r in rs)
@@ -81,6 +86,7 @@ def measure_dominant_kernel(enc, xyz_dev):
                     tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, total_ms=ms)
     out = summ(recs["gemm"])
     out["attn"] = summ(recs["attn"])
+    out["mlp"] = summ(recs["mlp"])
     out["knn_feat"] = summ([r for r in recs["knn"] if r[3] > 4])
     out["knn_pos"] = summ([r for r in recs["knn"] if r[3] <= 4])
     return out
@@ -214,13 +220,18 @@ def main():
             # secondary kernels, same convention (algorithmic flops of the fp32 product / measured time; ceiling = dense 16-bit MFMA
             # peak / 3 products); the position search (3 features) is selection-bound, its MFMA share is negligible
             "roofline_kernels": {
+                "mlp_fused_kernel": {"bound": "mfma", "achieved": dom["mlp"]["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
+                                     "frac": dom["mlp"]["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 3.0), "launches_per_frame": dom["mlp"]["launches"],
+                                     "avg_launch_us": dom["mlp"]["avg_launch_us"],
+                                     "note": "fc1 + GELU + fc2 + residual of a Swin block in one launch, hidden activation in LDS; bound by the "
+                                             "LDS fill from L2 / Infinity Cache (3 MB per 128-row tile), see DESIGN.md"},
                 "swin_attn_bf16x3_kernel": {"bound": "mfma", "achieved": dom["attn"]["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
                                             "frac": dom["attn"]["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 3.0), "launches_per_frame": dom["attn"]["launches"],
                                             "avg_launch_us": dom["attn"]["avg_launch_us"]},
                 "knn_f16x3_kernel": {"bound": "mfma", "achieved": dom["knn_feat"]["tflops"], "peak": BF16_MFMA_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
                                      "frac": dom["knn_feat"]["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 3.0), "launches_per_frame": dom["knn_feat"]["launches"],
                                      "avg_launch_us": dom["knn_feat"]["avg_launch_us"],
-                                     "note": "fused distance + top-20 selection; the selection (VALU) is about half of the time"},
+                                     "note": "fused distance + top-20 selection; 84 % of the time is the three MFMA products per distance and their operand pipeline"},
                 "knn_mfma_kernel<2,16> (positions)": {"bound": "valu", "launches_per_frame": dom["knn_pos"]["launches"],
                                                       "avg_launch_us": dom["knn_pos"]["avg_launch_us"]}},
             "roofline_stages": {

@@ -202,6 +202,14 @@ SCP_API int scp_linear_f16x3(const float *A, int64_t lda, const void *Whi, const
 SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
                      const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, void *Ohi, void *Olo, int64_t ldo,
                      int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream);
+
+/* The MLP of a Swin block in one launch: C = GELU(X . W1^T + b1) . W2^T + b2 + residual with X as bf16 hi/lo planes [M][ldx]
+ * (256 columns), W1 planes [1024][256], W2 planes [256][1024] (scp_split_weight_bf16), fp32 C [M][ldc].  The 1024-wide hidden
+ * activation stays in LDS (intermediate.dense + GELU + output.dense + residual, swin_transformer.py:559-571); bit-identical to
+ * scp_linear_split (act 2, split output) followed by scp_linear_split (residual). */
+SCP_API int scp_mlp_split_fused(const void *Xhi, const void *Xlo, int64_t ldx, const void *W1hi, const void *W1lo, const void *W2hi,
+                                const void *W2lo, const float *b1, const float *b2, const float *residual, int64_t ldr, float *C,
+                                int64_t ldc, int32_t M, void *stream);
 /* scp_linear_split with a GATHERED residual added BEFORE the activation: out[m] = act(A[m].W^T + bias + residual[res_map[m]])
  * (res_map may be NULL = identity).  Used to evaluate a layer over concat_states (ehem.py:75-86) as one product per Swin stage. */
 SCP_API int scp_linear_split_gather(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,

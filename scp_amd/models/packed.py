@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import native
-from ..ops import linear_s, leaky_mlp3_s, split_cat, linear, layer_norm, leaky_mlp3
+from ..ops import linear_s, leaky_mlp3_s, split_cat, linear, layer_norm, leaky_mlp3, _split
 from .ehem import SHIFT, WINDOW, _edge_conv_packed
 
 
@@ -137,6 +137,9 @@ class PackedPlan:
             even_out=_out_map(Q0, ne, coded), odd_out=_out_map(Q0, no, coded + ne))
 
 
+FUSED_MLP = __import__('os').environ.get('SCP_MLP', 'fused') != 'split'   # SCP_MLP=split: fc1 and fc2 as two launches
+
+
 def _swin_layer(layer, x, valid, wtab, shift, query=None):
     """swin_transformer.py:654-706 on a packed layout (rows beyond a window's length are don't-care, except that the
     LayerNorm output is zeroed there - the reference zero-pads AFTER LayerNorm)."""
@@ -168,9 +171,14 @@ def _swin_layer(layer, x, valid, wtab, shift, query=None):
     o = native.swin_attention_packed(q, k, v, att.relative_position_bias_table, wtab, shift, split=True)
     x = linear_s(o, layer.attention.output.dense.weight, layer.attention.output.dense.bias, residual=x)
     lna = layer.layernorm_after
-    y = linear_s(native.layernorm_rows(x, lna.weight, lna.bias, lna.eps, split=True), layer.intermediate.dense.weight,
-                 layer.intermediate.dense.bias, act="gelu", want="split")
-    return linear_s(y, layer.output.dense.weight, layer.output.dense.bias, residual=x)
+    h2 = native.layernorm_rows(x, lna.weight, lna.bias, lna.eps, split=True)
+    fc1, fc2 = layer.intermediate.dense, layer.output.dense
+    if FUSED_MLP and fc1.weight.shape == (1024, 256) and fc2.weight.shape == (256, 1024):
+        # intermediate.dense + GELU + output.dense + residual in one kernel: the 1024-wide hidden activation stays in LDS
+        # (csrc/mlp_fused.hip; bit-identical to the two launches below)
+        return native.mlp_split_fused(h2, _split(fc1.weight), fc1.bias, _split(fc2.weight), fc2.bias, residual=x)
+    y = linear_s(h2, fc1.weight, fc1.bias, act="gelu", want="split")
+    return linear_s(y, fc2.weight, fc2.bias, residual=x)
 
 
 def _merge(m, x, maps):

@@ -88,6 +88,7 @@ def lib():
         "scp_split_weight_f16": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp, _vp, _vp]),
         "scp_linear_f16x3": (C.c_int, [_vp, i64, _vp, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp, _vp]),
         "scp_linear_split": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
+        "scp_mlp_split_fused": (C.c_int, [_vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp, i64, i32, _vp]),
         "scp_split_rows": (C.c_int, [_vp, i64, i64, _vp, i32, _vp, _vp, i64, i64, _vp]),
         "scp_linear_split_scatter": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_linear_split_gather": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
@@ -557,6 +558,19 @@ def linear_split(a, sw, bias=None, act=ACT_NONE, residual=None, out=None, out_sp
                                 0 if o is None else o.t.stride(1), M, N, K, act, cfg, _stream())
     _check(rc, "scp_linear_split")
     return c if want == "f32" else (o if want == "split" else (c, o))
+
+
+def mlp_split_fused(a, sw1, b1, sw2, b2, residual=None):
+    """GELU(a @ W1.T + b1) @ W2.T + b2 + residual in one launch (256 -> 1024 -> 256; csrc/mlp_fused.hip): fp32 [M, 256]."""
+    if a.K != 256 or (sw1.N, sw1.K, sw2.N, sw2.K) != (1024, 256, 256, 1024):
+        raise ScpError("mlp_split_fused: 256 -> 1024 -> 256 only")
+    t = a.t
+    c = torch.empty((a.M, 256), dtype=torch.float32, device=t.device)
+    rc = lib().scp_mlp_split_fused(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw1.hi.data_ptr(), sw1.lo.data_ptr(), sw2.hi.data_ptr(),
+                                   sw2.lo.data_ptr(), _dev(b1), _dev(b2), None if residual is None else residual.data_ptr(),
+                                   0 if residual is None else residual.stride(0), c.data_ptr(), c.stride(0), a.M, _stream())
+    _check(rc, "scp_mlp_split_fused")
+    return c
 
 
 def layernorm_rows(x, gamma, beta, eps=1e-5, valid=None, ia=None, ib=None, out=None, split=False):

@@ -415,6 +415,28 @@ def test_octattn_attention_f16x3_vs_fp32_mfma(dev, B, c):
     assert e16 < 4 * e32 + 2e-6
 
 
+@pytest.mark.parametrize("M,res", [(1, True), (127, False), (128, True), (129, True), (1000, True), (70001, True), (33000, False)])
+def test_fused_mlp_is_bit_identical_to_two_launches(dev, M, res):
+    """scp_mlp_split_fused (fc1 + GELU + fc2 + residual, hidden activation in LDS) against scp_linear_split twice: the same products
+    in the same order - identical bits, for ragged row counts and several tiles per workgroup."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn((M, 256), generator=g) * 2).to(dev)
+    w1 = (torch.randn((1024, 256), generator=g) / 16).to(dev); b1 = torch.randn(1024, generator=g).to(dev)
+    w2 = (torch.randn((256, 1024), generator=g) / 32).to(dev); b2 = torch.randn(256, generator=g).to(dev)
+    r = torch.randn((M, 256), generator=g).to(dev) if res else None
+    a = native.split_rows(x)
+    s1, s2 = native.SplitWeight(w1), native.SplitWeight(w2)
+    hid = native.linear_split(a, s1, b1, act=native.ACT_GELU, want="split")
+    want = native.linear_split(hid, s2, b2, residual=r)
+    got = native.mlp_split_fused(a, s1, b1, s2, b2, residual=r)
+    assert torch.equal(got, want)
+    ref = torch.nn.functional.gelu(x.double() @ w1.double().T + b1.double()) @ w2.double().T + b2.double()
+    if res:
+        ref = ref + r.double()
+    assert (got.double() - ref).abs().max().item() < 2e-4
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K,act,res", [(1000, 256, 256, 0, True), (257, 300, 64, 3, False), (700, 255, 512, 1, False),
                                            (513, 240, 240, 0, False), (2049, 1024, 256, 2, False), (300, 128, 448, 1, True),
