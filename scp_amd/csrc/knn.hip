@@ -436,11 +436,12 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
 
     for (int s = 0; s < nt; ++s) {
         const int buf = s % NST;
+        // stage s has landed and every wave is done with stage s - 1, whose buffer is refilled now (raw barrier: __syncthreads()
+        // would drain the younger stage's DMAs too, scp_internal.h)
         if (s + 1 < nt) {
-            if (per_stage >= 7) SCP_WAIT_DMA(7); else if (per_stage == 6) SCP_WAIT_DMA(6);
-            else if (per_stage == 5) SCP_WAIT_DMA(5); else SCP_WAIT_DMA(4);
-        } else SCP_WAIT_DMA(0);
-        __syncthreads();   // stage s has landed and every wave is done with stage s - 1, whose buffer is refilled now
+            if (per_stage >= 7) SCP_BARRIER_DMA(7); else if (per_stage == 6) SCP_BARRIER_DMA(6);
+            else if (per_stage == 5) SCP_BARRIER_DMA(5); else SCP_BARRIER_DMA(4);
+        } else SCP_BARRIER_DMA(0);
         int nxt = -1;
         if (s + 2 < nt) { nxt = next_tile(); issue(nxt, (s + 2) % NST); }
         const char *arow = pool + buf * STAGE_B + col * RB;

@@ -110,9 +110,9 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
         if (tile + (int)gridDim.x < ntiles) { issue((tile + (int)gridDim.x) * MBM, s + 2 - 96, gs0 + s + 2); return true; }
         return false;
     };
-    auto landed = [&](int s) {                                        // wait for step s given what has been requested after it
+    auto landed = [&](int s) {   // barrier: step s has landed in every wave's view (given what has been requested after it)
         const bool younger = (s + 1 < 96) || (tile + (int)gridDim.x < ntiles);
-        if (younger) SCP_WAIT_DMA(4); else SCP_WAIT_DMA(0);
+        if (younger) SCP_BARRIER_DMA(4); else SCP_BARRIER_DMA(0);
     };
 
     for (; tile < ntiles; tile += gridDim.x, gs0 += 96) {
@@ -135,7 +135,6 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
             for (int t = 0; t < 8; ++t) {
                 const int s = c * 12 + t;
                 landed(s);
-                __syncthreads();
                 ahead(m0, s);
                 const char *st = smem + ((gs0 + s) % MNST) * MSTAGE;
                 const int ow = 16384 + (wn * 32 + col) * 64, ox = (wm * 64 + col) * 64;
@@ -160,10 +159,18 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
             // ---------------- bias + GELU + split -> H image (k-slab wn) ----------------
             {
                 char *hb = smem + MHOFF + wn * 16384;
-                const float *b1p = a.b1 + c * 128 + wn * 32 + 4 * h;
+                // the 32 biases of this wave's hidden tile through the scalar path (wave-uniform address -> s_load: a vector load
+                // here would make the compiler wait vmcnt(0) for it, which also drains the operand DMAs in flight)
+                typedef const __attribute__((address_space(4))) float *m_const_ptr_t;   // constant address space: scalar loads
+                m_const_ptr_t b1p = (m_const_ptr_t)(uintptr_t)(a.b1 + c * 128 + wn * 32);
+                float sb[32];
+#pragma unroll
+                for (int e = 0; e < 32; ++e) sb[e] = b1p[e];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const mf32x4 bv = *(const mf32x4 *)(b1p + 8 * g);          // hidden units 8 g + 4 h + 0..3 of this wave's 32
+                    mf32x4 bv;                                                 // hidden units 8 g + 4 h + 0..3 of this wave's 32
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bv[u] = h ? sb[8 * g + 4 + u] : sb[8 * g + u];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int xr = wm * 64 + 32 * j + col;
@@ -184,8 +191,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
             // ---------------- phase 2: Y += H . W2c^T ----------------
             for (int t = 8; t < 12; ++t) {
                 const int s = c * 12 + t;
-                landed(s);
-                __syncthreads();                                    // at t = 8 this also publishes the H image
+                landed(s);                                          // at t = 8 this also publishes the H image
                 ahead(m0, s);
                 const char *st = smem + ((gs0 + s) % MNST) * MSTAGE;
                 const char *hs = smem + MHOFF + (t - 8) * 16384;

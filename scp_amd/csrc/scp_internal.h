@@ -26,6 +26,11 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // does depends on the surrounding code (observed: adding an unrelated, never-executed DMA to a loop removed the wait) - so every
 // barrier that publishes DMA data is preceded by an explicit wait.  N = DMA instructions of THIS wave that may stay in flight.
 #define SCP_WAIT_DMA(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+// Workgroup barrier that lets N LDS-DMA instructions of this wave stay in flight.  __syncthreads() cannot do that: its release
+// fence makes hipcc emit s_waitcnt vmcnt(0) in front of s_barrier, which drains every prefetch deeper than one step (seen in the
+// ISA of the first three-stage pipelines: the counted wait was there, followed by the compiler's vmcnt(0)).  LDS traffic of this
+// wave (ds_read / ds_write) is drained by lgkmcnt(0); global stores that other waves must see still need __syncthreads().
+#define SCP_BARRIER_DMA(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // growable device buffer owned by a handle
 struct DevBuf {
