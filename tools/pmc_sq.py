@@ -2,7 +2,7 @@
 import csv, glob, sys, collections, os
 tag = sys.argv[1]
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-f = glob.glob(f"{root}/gpurun_out/pmc_{tag}_sq/*/*counter_collection.csv")[0]
+f = max(glob.glob(f"{root}/gpurun_out/pmc_{tag}_sq/*/*counter_collection.csv"), key=os.path.getmtime)   # newest run
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0][:44]

@@ -1,10 +1,10 @@
 """Summarise the two PMC passes of tools/pmc_traffic.sh into profiles/<tag>_pmc_traffic.json (HBM bytes per launch per kernel).
 FETCH_SIZE is doubled (gfx950 reports half of the bytes of wide coalesced reads, MI355X_MICROARCH.md); both counters are in KB."""
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
 tag = sys.argv[1]
 tot = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"/root/repo/gpurun_out/pmc_{tag}_{c}/*/*counter_collection.csv")[0]
+    f = max(glob.glob(f"/root/repo/gpurun_out/pmc_{tag}_{c}/*/*counter_collection.csv"), key=os.path.getmtime)   # newest run
     acc = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != c:
