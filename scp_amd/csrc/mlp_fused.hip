@@ -1,15 +1,22 @@
 // Swin MLP in one kernel: C = GELU(X . W1^T + b1) . W2^T + b2 + R   (256 -> 1024 -> 256, swin_transformer.py:559-571), bf16x3 on
 // split operands like gemm_split.hip, the 1024-wide hidden activation never leaves the CU (gfx950 / CDNA4).
 //
-// Workgroup = 8 waves (2 x 4) = 128 rows of X, persistent over row tiles.  The hidden dimension is processed in 8 chunks of 128:
-//   phase 1 (8 k-steps of 32):  H^T[128 hidden x 128 rows] = W1c . X^T      wave: 32 hidden x 64 rows (A = W1 rows, B = X rows:
-//                               the accumulator then holds four consecutive hidden units per register group = one 8-byte
-//                               store into the A-operand image of phase 2)
-//   GELU + bias + hi/lo split -> LDS image H[4 k-slabs][2 planes][128 rows][32] (same 64-byte rows and XOR swizzle as an A stage)
-//   phase 2 (4 k-steps of 32):  Y[128 x 256] += H . W2c^T                   wave: 64 rows x 64 columns
-// All global operands arrive by LDS-DMA into two 32 KiB stages (phase 1: X slab + W1 slab, phase 2: W2 slab), one step ahead.
+// Workgroup = 8 waves (2 x 4) = 128 rows of X, persistent over row tiles.  The hidden dimension is processed in 4 super-chunks of
+// 256 = two chunks of 128:
+//   phase 1 (8 k-steps of 32):  H^T[256 hidden x 128 rows] = W1c . X^T      wave: (32 + 32) hidden x 64 rows (A = W1 rows, B = X
+//                               rows: the accumulator then holds four consecutive hidden units per register group = one 8-byte
+//                               store into the A-operand image of phase 2).  One pass over the activation tile feeds both chunks:
+//                               the tile is streamed four times per row tile, not eight.
+//   per chunk: bias + GELU + hi/lo split -> LDS image H[4 k-slabs][2 planes][128 rows][32] (64-byte rows, XOR swizzle of an A
+//              stage), then phase 2 (4 k-steps of 32): Y[128 x 256] += H . W2c^T, wave: 64 rows x 64 columns; the second chunk's
+//              accumulators wait in registers meanwhile.
+// All global operands arrive by LDS-DMA into two 48 KiB stages (phase 1: X slab 16 KiB + W1 slab 32 KiB, phase 2: W2 slab 32 KiB),
+// one step ahead, behind raw barriers (SCP_BARRIER_DMA); biases come through the scalar path (a vector load would drain the DMAs).
 // Products, their order and the k order are those of two scp_linear_split calls (fc1 with GELU and split output, fc2 with
-// residual): results are bit-identical.  LDS: 3 x 32 KiB stages + 64 KiB H image (reused as the epilogue bounce) = 160 KiB.
+// residual): results are bit-identical.  LDS: 2 x 48 KiB stages + 64 KiB H image (reused as the epilogue bounce) = 160 KiB.
+// Measured and dropped: 128-hidden chunks with three 32 KiB stages two steps ahead (8 passes over the activation tile: 6 - 9 %
+// slower), GELU of the second chunk in the MFMA shadow of the first chunk's phase 2 (58 spilled registers, no gain), packed-fp32
+// GELU (no gain), nt cache policy on either stream (13 - 20 % slower).
 #include <stdlib.h>
 #include "scp_internal.h"
 
@@ -57,10 +64,8 @@ struct MlpArgs {
 };
 
 #define MBM 128
-#define MSTAGE 32768
-#define MNST 3                                   // LDS stages: operands are requested two steps ahead (64 KiB in flight per CU)
-#define MHOFF (MNST * MSTAGE)                    // H image: 4 slabs x (hi 8 KiB + lo 8 KiB)
-
+#define M2STAGE 49152
+#define M2HOFF (2 * M2STAGE)
 __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
@@ -71,10 +76,10 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
     const int d_q = (lane & 3) ^ ((lane >> 4) & 3);
     const int f_pos0 = (h ^ ((lane >> 2) & 3)) << 4;
 
-    // step s of a tile: chunk c = s / 12, t = s % 12; t < 8: phase 1 k-step t, else phase 2 k-step t - 8
-    auto issue = [&](int m0, int s, int gs) {
-        char *base = smem + (gs % MNST) * MSTAGE;
-        const int c = s / 12, t = s - 12 * c;
+    // step s of a tile: super-chunk sc = s / 16, t = s % 16; t < 8: phase 1 k-step t; 8..11: phase 2 of chunk 2 sc; 12..15: of chunk 2 sc + 1
+    auto issue = [&](int m0, int s) {
+        char *base = smem + (s & 1) * M2STAGE;
+        const int sc = s >> 4, t = s & 15;
         if (t < 8) {
             const int k0 = t * 32 + 8 * d_q;
             int m = m0 + 16 * w + d_row;
@@ -82,11 +87,16 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
             const int64_t xo = (int64_t)m * a.ldx + k0;
             mlp_dma16(a.Xhi + xo, base + w * 1024);
             mlp_dma16(a.Xlo + xo, base + 8192 + w * 1024);
-            const int64_t wo = (int64_t)(c * 128 + 16 * w + d_row) * 256 + k0;
-            mlp_dma16(a.W1hi + wo, base + 16384 + w * 1024);
-            mlp_dma16(a.W1lo + wo, base + 24576 + w * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cr = w + 8 * j;                          // 16-row chunk of the 256 hidden rows
+                const int64_t wo = (int64_t)(sc * 256 + 16 * cr + d_row) * 256 + k0;
+                mlp_dma16(a.W1hi + wo, base + 16384 + cr * 1024);
+                mlp_dma16(a.W1lo + wo, base + 32768 + cr * 1024);
+            }
         } else {
-            const int k0 = c * 128 + (t - 8) * 32 + 8 * d_q;
+            const int c = 2 * sc + ((t - 8) >> 2);
+            const int k0 = c * 128 + ((t - 8) & 3) * 32 + 8 * d_q;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int cr = w + 8 * j;
@@ -99,23 +109,9 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
-    // one continuous stream of steps across this workgroup's tiles: global step gs = 96 * (tile ordinal) + s uses stage gs % 3 and
-    // is requested two steps ahead; every wave issues exactly four DMA instructions per step, so "step gs has landed" is
-    // vmcnt <= 4 while a younger step is in flight (the counter retires in order: older epilogue loads / stores are covered)
-    int gs0 = 0;
-    issue(tile * MBM, 0, 0);
-    issue(tile * MBM, 1, 1);
-    auto ahead = [&](int m0, int s) {                                 // request step s + 2 of the stream; false if there is none
-        if (s + 2 < 96) { issue(m0, s + 2, gs0 + s + 2); return true; }
-        if (tile + (int)gridDim.x < ntiles) { issue((tile + (int)gridDim.x) * MBM, s + 2 - 96, gs0 + s + 2); return true; }
-        return false;
-    };
-    auto landed = [&](int s) {   // barrier: step s has landed in every wave's view (given what has been requested after it)
-        const bool younger = (s + 1 < 96) || (tile + (int)gridDim.x < ntiles);
-        if (younger) SCP_BARRIER_DMA(4); else SCP_BARRIER_DMA(0);
-    };
+    issue(tile * MBM, 0);
 
-    for (; tile < ntiles; tile += gridDim.x, gs0 += 96) {
+    for (; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * MBM;
         mf32x16 acc2[2][2];
 #pragma unroll
@@ -124,24 +120,25 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
-        mf32x16 acc1[2];
+        mf32x16 acc1[2][2];                                         // [chunk of the pair][row tile]
 
-        for (int c = 0; c < 8; ++c) {
-            // ---------------- phase 1: H^T chunk = W1c . X^T ----------------
+        for (int sc = 0; sc < 4; ++sc) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc1[q][j][r] = 0.f;
+            // ---------------- phase 1: both chunks of the pair ----------------
             for (int t = 0; t < 8; ++t) {
-                const int s = c * 12 + t;
-                landed(s);
-                ahead(m0, s);
-                const char *st = smem + ((gs0 + s) % MNST) * MSTAGE;
+                const int s = sc * 16 + t;
+                SCP_BARRIER_DMA(0);
+                issue(m0, s + 1);
+                const char *st = smem + (s & 1) * M2STAGE;
                 const int ow = 16384 + (wn * 32 + col) * 64, ox = (wm * 64 + col) * 64;
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
                     const int po = f_pos0 ^ (kc * 32);
-                    const mbf16x8 wh = *(const mbf16x8 *)(st + ow + po), wl = *(const mbf16x8 *)(st + ow + 8192 + po);
                     mbf16x8 xh[2], xl[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -149,84 +146,92 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
                         xl[j] = *(const mbf16x8 *)(st + ox + 8192 + j * 2048 + po);
                     }
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[j], acc1[j], 0, 0, 0);   // x_lo . w_hi
+                    for (int q = 0; q < 2; ++q) {
+                        const mbf16x8 wh = *(const mbf16x8 *)(st + ow + q * 8192 + po), wl = *(const mbf16x8 *)(st + ow + 16384 + q * 8192 + po);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[j], acc1[j], 0, 0, 0);   // x_hi . w_lo
+                        for (int j = 0; j < 2; ++j) acc1[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[j], acc1[q][j], 0, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[j], acc1[j], 0, 0, 0);   // x_hi . w_hi
+                        for (int j = 0; j < 2; ++j) acc1[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[j], acc1[q][j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc1[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[j], acc1[q][j], 0, 0, 0);
+                    }
                 }
             }
-            // ---------------- bias + GELU + split -> H image (k-slab wn) ----------------
-            {
-                char *hb = smem + MHOFF + wn * 16384;
-                // the 32 biases of this wave's hidden tile through the scalar path (wave-uniform address -> s_load: a vector load
-                // here would make the compiler wait vmcnt(0) for it, which also drains the operand DMAs in flight)
-                typedef const __attribute__((address_space(4))) float *m_const_ptr_t;   // constant address space: scalar loads
-                m_const_ptr_t b1p = (m_const_ptr_t)(uintptr_t)(a.b1 + c * 128 + wn * 32);
-                float sb[32];
 #pragma unroll
-                for (int e = 0; e < 32; ++e) sb[e] = b1p[e];
+            for (int q = 0; q < 2; ++q) {
+                const int c = 2 * sc + q;
+                // ---------------- bias + GELU + split of chunk c -> H image (k-slab wn) ----------------
+                if (q == 1) SCP_BARRIER_DMA(0);                    // every wave is done reading chunk A's H image (the DMA in flight
+                                                                    // is re-waited at the next step; one step of prefetch is lost here)
+                {
+                    char *hb = smem + M2HOFF + wn * 16384;
+                    typedef const __attribute__((address_space(4))) float *m_const_ptr_t;
+                    m_const_ptr_t b1p = (m_const_ptr_t)(uintptr_t)(a.b1 + c * 128 + wn * 32);
+                    float sb[32];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    mf32x4 bv;                                                 // hidden units 8 g + 4 h + 0..3 of this wave's 32
+                    for (int e = 0; e < 32; ++e) sb[e] = b1p[e];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) bv[u] = h ? sb[8 * g + 4 + u] : sb[8 * g + u];
+                    for (int g = 0; g < 4; ++g) {
+                        mf32x4 bv;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int xr = wm * 64 + 32 * j + col;
-                        mbf16x4 hi, lo;
+                        for (int u = 0; u < 4; ++u) bv[u] = h ? sb[8 * g + 4 + u] : sb[8 * g + u];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const float y = mlp_gelu(acc1[j][4 * g + u] + bv[u]);
-                            const __bf16 hh = (__bf16)y;
-                            hi[u] = hh;
-                            lo[u] = (__bf16)(y - (float)hh);
+                        for (int j = 0; j < 2; ++j) {
+                            const int xr = wm * 64 + 32 * j + col;
+                            mbf16x4 hi, lo;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float y = mlp_gelu(acc1[q][j][4 * g + u] + bv[u]);
+                                const __bf16 hh = (__bf16)y;
+                                hi[u] = hh;
+                                lo[u] = (__bf16)(y - (float)hh);
+                            }
+                            const int off = xr * 64 + ((g ^ ((xr >> 2) & 3)) << 4) + 8 * h;
+                            *(mbf16x4 *)(hb + off) = hi;
+                            *(mbf16x4 *)(hb + 8192 + off) = lo;
                         }
-                        const int off = xr * 64 + ((g ^ ((xr >> 2) & 3)) << 4) + 8 * h;
-                        *(mbf16x4 *)(hb + off) = hi;
-                        *(mbf16x4 *)(hb + 8192 + off) = lo;
                     }
                 }
-            }
-            // ---------------- phase 2: Y += H . W2c^T ----------------
-            for (int t = 8; t < 12; ++t) {
-                const int s = c * 12 + t;
-                landed(s);                                          // at t = 8 this also publishes the H image
-                ahead(m0, s);
-                const char *st = smem + ((gs0 + s) % MNST) * MSTAGE;
-                const char *hs = smem + MHOFF + (t - 8) * 16384;
-                const int oa = (wm * 64 + col) * 64, ob = (wn * 64 + col) * 64;
+                // ---------------- phase 2 of chunk c ----------------
+                for (int t = 0; t < 4; ++t) {
+                    const int s = sc * 16 + 8 + 4 * q + t;
+                    SCP_BARRIER_DMA(0);                             // at t = 0 this also publishes the H image
+                    if (s + 1 < 64) issue(m0, s + 1);
+                    const char *st = smem + (s & 1) * M2STAGE;
+                    const char *hs = smem + M2HOFF + t * 16384;
+                    const int oa = (wm * 64 + col) * 64, ob = (wn * 64 + col) * 64;
 #pragma unroll
-                for (int kc = 0; kc < 2; ++kc) {
-                    const int po = f_pos0 ^ (kc * 32);
-                    mbf16x8 ah[2], al[2], bh[2], bl[2];
+                    for (int kc = 0; kc < 2; ++kc) {
+                        const int po = f_pos0 ^ (kc * 32);
+                        mbf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        ah[i] = *(const mbf16x8 *)(hs + oa + i * 2048 + po);
-                        al[i] = *(const mbf16x8 *)(hs + 8192 + oa + i * 2048 + po);
-                        bh[i] = *(const mbf16x8 *)(st + ob + i * 2048 + po);
-                        bl[i] = *(const mbf16x8 *)(st + 16384 + ob + i * 2048 + po);
+                        for (int i = 0; i < 2; ++i) {
+                            ah[i] = *(const mbf16x8 *)(hs + oa + i * 2048 + po);
+                            al[i] = *(const mbf16x8 *)(hs + 8192 + oa + i * 2048 + po);
+                            bh[i] = *(const mbf16x8 *)(st + ob + i * 2048 + po);
+                            bl[i] = *(const mbf16x8 *)(st + 16384 + ob + i * 2048 + po);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc2[i][j], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc2[i][j], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc2[i][j], 0, 0, 0);
                     }
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc2[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc2[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc2[i][j], 0, 0, 0);
                 }
             }
         }
-        __syncthreads();                                            // every wave is done with the H image (the next tile's first two
-                                                                    // steps are already streaming into their stages)
+        SCP_WAIT_DMA(0);
+        __syncthreads();                                            // every wave is done with the stages and the H image
+        if (tile + (int)gridDim.x < ntiles) issue((tile + gridDim.x) * MBM, 0);
 
-        // ---------------- epilogue: + b2, + residual, fp32 rows (bounce through this wave's 8 KiB of the H region) ----------------
-        float *stg = (float *)(smem + MHOFF + w * 8192);
+        float *stg = (float *)(smem + M2HOFF + w * 8192);
         float bv[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) bv[j] = a.b2[wn * 64 + j * 32 + col];
@@ -255,7 +260,6 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
                 if (m < a.M) *(mf32x4 *)(a.C + (int64_t)m * a.ldc + nb) = y;
             }
         }
-        // the first barrier of the next tile orders these LDS reads before that tile's H writes (eight steps later anyway)
     }
 }
 
@@ -279,7 +283,7 @@ extern "C" SCP_API int scp_mlp_split_fused(const void *Xhi, const void *Xlo, int
         HIP_TRY(hipGetDeviceProperties(&p, dev));
         g_mlp_num_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     }
-    constexpr int LDS = MNST * MSTAGE + 65536;
+    constexpr int LDS = 2 * M2STAGE + 65536;
     static bool configured = false;
     if (!configured) {
         HIP_TRY(hipFuncSetAttribute((const void *)mlp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
