@@ -108,10 +108,8 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__rest
             // outstanding loads and wait vmcnt(0) every iteration (no prefetch at all)
             const int m = m0 + a_r + 64 * i, k = k0 + 4 * a_c;
             const int mc = m < M ? m : M - 1, kc = k < K ? k : K - 4;             // K % 4 == 0
-            f32x4 v = *(const f32x4 *)(A + (int64_t)mc * lda + kc);
-            const bool ok = (m < M) && (k < K);
-            v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; v[2] = ok ? v[2] : 0.f; v[3] = ok ? v[3] : 0.f;
-            pa[i] = v;
+            pa[i] = *(const f32x4 *)(A + (int64_t)mc * lda + kc);                 // masked when it is consumed (commit): a select
+                                                                                  // here would make the wave wait for the load at once
         }
         {
             const int64_t off = (int64_t)(n0 + b_r) * Kpad + k0 + 8 * b_c;   // planes are padded: always in range
@@ -119,10 +117,14 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__rest
             pbl[0] = *(const bf16x8 *)(Wlo + off);
         }
     };
-    auto commit = [&](int st, auto &pa, auto &pbh, auto &pbl) {
+    auto commit = [&](int st, int kt, auto &pa, auto &pbh, auto &pbl) {
         __bf16 *sAh = lds[st][0], *sAl = lds[st][1], *sBh = lds[st][2], *sBl = lds[st][3];
+        // the prefetched registers become visible HERE: without this the scheduler hoists the conversions of the next step's
+        // commit above the barrier, and with them the wait for loads that should stay in flight across it
+        asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pbh[0]), "+v"(pbl[0]));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if (!((m0 + a_r + 64 * i < M) && (kt * BK + 4 * a_c < K))) pa[i] = (f32x4){0.f, 0.f, 0.f, 0.f};   // rows / columns beyond the matrix
             const int o = (a_r + 64 * i) * LDP + 4 * a_c;
             if (F16) {
                 f16x4 hi, lo;
@@ -161,12 +163,18 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__rest
         for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
 
     issue(0, pa2[0], pbh2[0], pbl2[0]);
-    if (nk > 1) issue(1, pa2[1], pbh2[1], pbl2[1]);
-    commit(0, pa2[0], pbh2[0], pbl2[0]);
+    issue(nk > 1 ? 1 : 0, pa2[1], pbh2[1], pbl2[1]);
+    commit(0, 0, pa2[0], pbh2[0], pbl2[0]);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        // register set (kt & 1) is free again (tile kt went to LDS one iteration ago): refill it with tile kt + 2
-        if (kt + 2 < nk) { if (kt & 1) issue(kt + 2, pa2[1], pbh2[1], pbl2[1]); else issue(kt + 2, pa2[0], pbh2[0], pbl2[0]); }
+    // one k-step; `rf*` = the register set that held tile kt (in LDS since the previous step): refilled with tile kt + 2;
+    // `cm*` = the set holding tile kt + 1 (loaded during the previous step): written to the other LDS stage after the MFMAs.
+    // The loop is unrolled by two so that both sets are compile-time registers: the wait in front of the commit is then a
+    // counted one (the four younger loads of tile kt + 2 stay in flight), and the raw barrier keeps them in flight too
+    // (__syncthreads() would drain them: vmcnt(0) in front of s_barrier, scp_internal.h).
+    auto step = [&](int kt, auto &rfa, auto &rfh, auto &rfl, auto &cma, auto &cmh, auto &cml) {
+        issue(kt + 2 < nk ? kt + 2 : nk - 1, rfa, rfh, rfl);   // unconditional (the last two steps re-read the last tile): a branch
+                                                                // around the loads would make the compiler copy - and so wait for -
+                                                                // the loaded registers at the join
         const __bf16 *sAh = lds[kt & 1][0], *sAl = lds[kt & 1][1], *sBh = lds[kt & 1][2], *sBl = lds[kt & 1][3];
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
@@ -197,9 +205,12 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__rest
                     }
                 }
         }
-        // tile kt + 1 (issued one iteration ago) -> the other LDS stage: nobody reads it during this iteration
-        if (kt + 1 < nk) { if (kt & 1) commit(0, pa2[0], pbh2[0], pbl2[0]); else commit(1, pa2[1], pbh2[1], pbl2[1]); }
-        __syncthreads();
+        if (kt + 1 < nk) commit((kt + 1) & 1, kt + 1, cma, cmh, cml);
+        SCP_BARRIER_DMA(4);
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, pa2[0], pbh2[0], pbl2[0], pa2[1], pbh2[1], pbl2[1]);
+        if (kt + 1 < nk) step(kt + 1, pa2[1], pbh2[1], pbl2[1], pa2[0], pbh2[0], pbl2[0]);
     }
 
     // epilogue: the accumulators hold 4 B per lane per row (lane = column n); bounce each wave's 64 x 64 tile through its private
