@@ -90,6 +90,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
     constexpr int TN = 2;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int STAGE = (BM + BN) * 128;                 // bytes: 2 planes x 64 B rows
+    constexpr int MAPOFF = STAGE + (STAGE > WM * WN * 8192 ? STAGE : WM * WN * 8192);   // EXT: row maps behind the stages / bounce slices
     constexpr int OFF_AL = BM * 64, OFF_BH = 2 * BM * 64, OFF_BL = 2 * BM * 64 + BN * 64;
     constexpr int NA = BM / (16 * NW), NB = BN / (16 * NW);            // LDS-DMA instructions per plane per wave
     static_assert(NW == 8 || NW == 4, "4 or 8 waves");
@@ -205,6 +206,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
         SCP_WAIT_DMA(0);
         __syncthreads();   // DMA of step 0 landed; every wave is past the previous tile's epilogue
         if (nk > 1) stage_issue(1, m0, n0, 1);
+        if (EXT) {   // the tile's residual / output row maps -> LDS now (latency hidden by the k loop): the epilogue would otherwise
+                     // chain two dependent global loads (map entry, then the row it names) per row
+            int64_t *mapbuf = (int64_t *)(smem + MAPOFF);
+            if (tid < BM) {
+                const int m = m0 + tid < a.M ? m0 + tid : a.M - 1;
+                if (a.res_map) mapbuf[tid] = a.res_map[m];
+                if (a.out_map) mapbuf[BM + tid] = a.out_map[m];
+            }
+        }
         load_b(0, 0, 0);
         load_a(0, 0, 0, 0);
         for (int kt = 0; kt < nk; ++kt) {
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                 for (int it = 0; it < 8; ++it) {
                     const int m = mb + 4 * it;
                     const int mc = m < a.M ? m : a.M - 1;
-                    const int64_t rrow = (EXT && a.res_map) ? a.res_map[mc] : (int64_t)mc;
+                    const int64_t rrow = (EXT && a.res_map) ? ((const int64_t *)(smem + MAPOFF))[mc - cm0] : (int64_t)mc;
                     rr[it] = *(const f32x4 *)(a.res + rrow * a.ldr + nb);
                 }
             }
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                         for (int u = 0; u < 4; ++u) y[u] = apply_act_s<ACT>(y[u]);
                     }
                     if (has_c && m < a.M) {
-                        const int64_t orow = (EXT && a.out_map) ? a.out_map[m] : (int64_t)m;
+                        const int64_t orow = (EXT && a.out_map) ? ((const int64_t *)(smem + MAPOFF))[BM + m - cm0] : (int64_t)m;
                         if (orow >= 0) *(f32x4 *)(a.C + orow * a.ldc + nb) = y;
                     }
                     if (has_o) {
@@ -378,7 +388,7 @@ static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * 64;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int BOUNCE = WM * WN * 8192;
-    constexpr int LDS = STAGE + (STAGE > BOUNCE ? STAGE : BOUNCE);   // stage 0 + max(stage 1, the epilogue's 8 KiB bounce slice per wave)
+    constexpr int LDS = STAGE + (STAGE > BOUNCE ? STAGE : BOUNCE) + (EXT ? 2 * BM * 8 : 0);   // stage 0 + max(stage 1, the epilogue's 8 KiB bounce slice per wave) [+ row maps]
     static bool configured = false;
     if (!configured) {
         HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_NONE, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
