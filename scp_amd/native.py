@@ -509,8 +509,20 @@ def linear_split_scatter(a, sw, bias, out_map, table, act=ACT_NONE, cfg=0):
     """table[out_map[m], :N] = act(a[m] . W^T + bias) for out_map[m] >= 0: fp32 rows written straight to their final positions.
     table: fp32 [rows, ld >= N] with unit column stride (a row-offset view selects the chunk)."""
     t = a.t
+    N = sw.N
+    if N % 4 and table.stride(0) >= -(-N // 4) * 4 and act == ACT_NONE:
+        # ragged width (255 symbols): write the padding columns of the table row as well (zero weights -> just the padded bias) so
+        # that every wave takes the 16-byte store path instead of the element-wise edge path
+        Np = -(-N // 4) * 4
+        if bias is not None:
+            pb = getattr(sw, "_bias_pad", None)
+            if pb is None or pb[0] is not bias:
+                pb = (bias, torch.cat((bias.detach().float(), torch.zeros(Np - N, dtype=torch.float32, device=bias.device))).contiguous())
+                sw._bias_pad = pb
+            bias = pb[1]
+        N = Np
     _check(lib().scp_linear_split_scatter(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.Npad, sw.Kpad,
-                                          _opt(bias), _dev(out_map, torch.int64), table.data_ptr(), table.stride(0), a.M, sw.N, sw.K, act, cfg,
+                                          _opt(bias), _dev(out_map, torch.int64), table.data_ptr(), table.stride(0), a.M, N, sw.K, act, cfg,
                                           _stream()), "scp_linear_split_scatter")
 
 
