@@ -18,51 +18,65 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float *__rest
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             const float *__restrict__ valid, float eps, float *__restrict__ out, int64_t ldo,
                                                             int64_t rows, __bf16 *__restrict__ ohi, __bf16 *__restrict__ olo) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
+    // a wavefront takes RPW consecutive rows and issues all their loads before it reduces the first one: one row per wavefront
+    // left only ~32 KiB in flight per CU, i.e. the kernel ran at the latency, not the bandwidth, of HBM
+    constexpr int RPW = 4;
     constexpr int C = 256 * NV;
-    f32x4 v[NV];
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (r0 >= rows) return;
+    f32x4 v[RPW][NV];
 #pragma unroll
-    for (int p = 0; p < NV; ++p) {
-        // part p (256 channels) comes from x[ia[r]] (p == 0) or x[ib[r]] (p == 1); without a gather the row is x[r] itself
-        int64_t src = r;
-        if (ia) src = (p == 0) ? ia[r] : ib[r];
-        const int64_t off = ia ? 0 : (int64_t)p * 256;
-        v[p] = (src < n_src_rows) ? *(const f32x4 *)(x + src * ldx + off + 4 * lane) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < RPW; ++i) {
+        const int64_t r = r0 + i < rows ? r0 + i : rows - 1;
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            // part p (256 channels) comes from x[ia[r]] (p == 0) or x[ib[r]] (p == 1); without a gather the row is x[r] itself
+            int64_t src = r;
+            if (ia) src = (p == 0) ? ia[r] : ib[r];
+            const int64_t off = ia ? 0 : (int64_t)p * 256;
+            v[i][p] = (src < n_src_rows) ? *(const f32x4 *)(x + src * ldx + off + 4 * lane) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
-    float s = 0.f;
+    f32x4 g[NV], b[NV];
 #pragma unroll
-    for (int p = 0; p < NV; ++p) s += (v[p][0] + v[p][1]) + (v[p][2] + v[p][3]);
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s * (1.0f / C);
-    float q = 0.f;
+    for (int p = 0; p < NV; ++p) { g[p] = *(const f32x4 *)(gamma + p * 256 + 4 * lane); b[p] = *(const f32x4 *)(beta + p * 256 + 4 * lane); }
 #pragma unroll
-    for (int p = 0; p < NV; ++p)
+    for (int i = 0; i < RPW; ++i) {
+        const int64_t r = r0 + i;
+        if (r >= rows) break;                            // wave-uniform
+        float s = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const float d = v[p][u] - mean; q += d * d; }
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = rsqrtf(q * (1.0f / C) + eps);
-    const float keep = valid ? valid[r] : 1.0f;
+        for (int p = 0; p < NV; ++p) s += (v[i][p][0] + v[i][p][1]) + (v[i][p][2] + v[i][p][3]);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.0f / C);
+        float q = 0.f;
 #pragma unroll
-    for (int p = 0; p < NV; ++p) {
-        const f32x4 g = *(const f32x4 *)(gamma + p * 256 + 4 * lane), b = *(const f32x4 *)(beta + p * 256 + 4 * lane);
-        f32x4 y;
+        for (int p = 0; p < NV; ++p)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) y[u] = ((v[p][u] - mean) * rstd * g[u] + b[u]) * keep;
-        if (ohi) {   // hi/lo bf16 planes (operand format of scp_linear_split)
-            bf16x4 vh, vl;
+            for (int u = 0; u < 4; ++u) { const float d = v[i][p][u] - mean; q += d * d; }
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q * (1.0f / C) + eps);
+        const float keep = valid ? valid[r] : 1.0f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float yy = y[u];
-                asm volatile("" : "+v"(yy));   // the rounded fp32 value, not an FMA-contracted (.. * keep) - hi
-                const __bf16 hh = (__bf16)yy;
-                vh[u] = hh;
-                vl[u] = (__bf16)(yy - (float)hh);
-            }
-            *(bf16x4 *)(ohi + r * ldo + p * 256 + 4 * lane) = vh;
-            *(bf16x4 *)(olo + r * ldo + p * 256 + 4 * lane) = vl;
-        } else *(f32x4 *)(out + r * ldo + p * 256 + 4 * lane) = y;
+        for (int p = 0; p < NV; ++p) {
+            f32x4 y;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) y[u] = ((v[i][p][u] - mean) * rstd * g[p][u] + b[p][u]) * keep;
+            if (ohi) {   // hi/lo bf16 planes (operand format of scp_linear_split)
+                bf16x4 vh, vl;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float yy = y[u];
+                    asm volatile("" : "+v"(yy));   // the rounded fp32 value, not an FMA-contracted (.. * keep) - hi
+                    const __bf16 hh = (__bf16)yy;
+                    vh[u] = hh;
+                    vl[u] = (__bf16)(yy - (float)hh);
+                }
+                *(bf16x4 *)(ohi + r * ldo + p * 256 + 4 * lane) = vh;
+                *(bf16x4 *)(olo + r * ldo + p * 256 + 4 * lane) = vl;
+            } else *(f32x4 *)(out + r * ldo + p * 256 + 4 * lane) = y;
+        }
     }
 }
 
@@ -73,7 +87,7 @@ static int ln_rows(const float *x, int64_t ldx, int64_t n_src_rows, const int64_
         (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) || (ohi && (!olo || (((uintptr_t)ohi | (uintptr_t)olo) & 7))))
         return SCP_EINVAL;
     if (rows == 0) return SCP_OK;
-    const unsigned nb = (unsigned)cdiv64(rows, 4);
+    const unsigned nb = (unsigned)cdiv64(rows, 16);   // 4 wavefronts x 4 rows per workgroup
     hipStream_t st = (hipStream_t)stream;
     if (C == 256) hipLaunchKernelGGL(layernorm_rows_kernel<1>, dim3(nb), dim3(256), 0, st, x, ldx, n_src_rows, ia, ia, gamma, beta, valid, eps, out, ldo, rows, ohi, olo);
     else hipLaunchKernelGGL(layernorm_rows_kernel<2>, dim3(nb), dim3(256), 0, st, x, ldx, n_src_rows, ia, ib, gamma, beta, valid, eps, out, ldo, rows, ohi, olo);
