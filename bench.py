@@ -193,7 +193,7 @@ def main():
         bytes_C = n_nodes * (255 * 4 + 4)
         traffic = None
         try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (collected separately, see the file's note)
-            with open(os.path.join(ROOT, "profiles", "r1y_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r1z_pmc_traffic.json")) as f:
                 traffic = json.load(f)["gemm_split_all_variants"]["hbm_bytes_per_launch"]
         except Exception:
             pass
