@@ -302,20 +302,27 @@ __device__ __forceinline__ void pow2_scale(float mx, float &sc, float &isc) {
     isc = __uint_as_float((unsigned)(127 - e) << 23);
 }
 
-// one wavefront per row of A [M][lda] (K % 4 == 0): scale and inverse scale
+// A [M][lda] (K % 4 == 0) -> scale and inverse scale per row.  A wavefront takes four consecutive rows and issues all their loads
+// before it reduces the first (one row per wavefront keeps too few bytes in flight to reach the bandwidth of HBM).
 __global__ __launch_bounds__(256) void row_scale_kernel(const float *__restrict__ A, int64_t lda, int M, int K, float *__restrict__ sc,
                                                        float *__restrict__ isc) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= M) return;
-    const float *a = A + (int64_t)row * lda;
-    float mx = 0.f;
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (row0 >= M) return;
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = 4 * lane; k < K; k += 256) {
-        const f32x4 v = *(const f32x4 *)(a + k);
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *(const f32x4 *)(A + (int64_t)(row0 + i < M ? row0 + i : M - 1) * lda + k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mx[i] = fmaxf(fmaxf(mx[i], fmaxf(fabsf(v[i][0]), fabsf(v[i][1]))), fmaxf(fabsf(v[i][2]), fabsf(v[i][3])));
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if (lane == 0) { float s, is; pow2_scale(mx, s, is); sc[row] = s; isc[row] = is; }
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o));
+        if (lane == 0 && row0 + i < M) { float s, is; pow2_scale(mx[i], s, is); sc[row0 + i] = s; isc[row0 + i] = is; }
+    }
 }
 
 // one wavefront per row of W [N][K] -> scaled f16 planes [Npad][Kpad] (zero padded) + inverse row scale [Npad] (1 on padding)
@@ -355,7 +362,7 @@ extern "C" SCP_API int scp_linear_f16x3(const float *A, int64_t lda, const void 
         (Kpad % BK) || act < 0 || act > 3 || ((uintptr_t)A & 15) || lda < K || ldc < N || (residual && ldr < N))
         return SCP_EINVAL;
     float *sc = row_scale_ws, *isc = row_scale_ws + M;      // workspace: 2 M floats
-    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, A, lda, M, K, sc, isc);
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, A, lda, M, K, sc, isc);
     const dim3 grid((unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM)));
 #define GO(ACT) hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT, true>), grid, dim3(512), 0, (hipStream_t)stream, A, lda, (const __bf16 *)Whi, \
                               (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K, sc, isc, w_inv_scale)
