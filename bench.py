@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--level", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
