@@ -14,6 +14,8 @@ the reference do not exist here.  The returned dict carries the same scalars the
 import time
 from concurrent.futures import ThreadPoolExecutor
 
+import os
+
 import numpy as np
 import torch
 
@@ -251,12 +253,25 @@ class FrameEncoder:
             self._pool = ThreadPoolExecutor(max_workers=2)
             self._copy_stream = torch.cuda.Stream(device=self.device)
             self._front_stream = torch.cuda.Stream(device=self.device, priority=-1)   # high priority: its tiny kernels slip in between the model's
+            # Lanes: consecutive frames run their model part on alternating streams, so the launch gaps and tails of one frame's
+            # kernels are filled by the other's (the kernels are whole-GPU persistent launches: they interleave rather than
+            # co-run).  SCP_LANES=1 keeps every frame on the caller's stream.
+            self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(os.environ.get("SCP_LANES", "2"))))]
+            self._lane_i = 0
         # Front part on its own stream: stage G (with its small D2H syncs) and the ~600 tiny index-map kernels of the window plans
         # are launch-bound; on a side stream they run under the previous frame's model kernels instead of in front of this
         # frame's.  Everything allocated here stays referenced by the handle until finish(), i.e. past its last use on the
         # main stream, so the caching allocator cannot hand it out again early.
-        main = torch.cuda.current_stream(self.device)
+        caller = torch.cuda.current_stream(self.device)
+        if len(self._lanes) > 1:
+            main = self._lanes[self._lane_i % len(self._lanes)]
+            self._lane_i += 1
+            main.wait_stream(caller)                       # whatever produced `xyz` on the caller's stream
+        else:
+            main = caller
+        fills0 = native.CACHE_FILLS
         with torch.cuda.stream(self._front_stream):
+            self._front_stream.wait_stream(caller)
             pre = self.preprocess(xyz.to(self.device, non_blocking=True))
             plan = EncodePlan(pre["level_sizes"], self.context_size)
             if self.packed:
@@ -266,10 +281,13 @@ class FrameEncoder:
             ready = torch.cuda.Event()
             ready.record()
         main.wait_event(ready)
-        table = self.logits_in_coding_order(pre, plan)
-        lohi = native.softmax_cdf(table, sym_coded)["lohi"]
-        done = torch.cuda.Event()
-        done.record()
+        with torch.cuda.stream(main):
+            table = self.logits_in_coding_order(pre, plan)
+            lohi = native.softmax_cdf(table, sym_coded)["lohi"]
+            done = torch.cuda.Event()
+            done.record()
+            if native.CACHE_FILLS != fills0:               # device-side caches were built during this call (first frames only):
+                main.synchronize()                         # finish them before anything is enqueued on another lane
         host = torch.empty(lohi.shape, dtype=lohi.dtype, pin_memory=True)
         with torch.cuda.stream(self._copy_stream):
             self._copy_stream.wait_event(done)

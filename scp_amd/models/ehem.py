@@ -135,6 +135,7 @@ def _edge_conv(conv, feat, k):
         shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
         packed = (Wuv, scale, shift)
         conv._scp_packed = packed
+        native.note_cache_fill()
     Wuv, scale, shift = packed
     idx = native.knn_topk(feat, k)
     uv = linear(feat, Wuv, None, exact=True)          # [B,n,2C'] plain fp32: these features feed the next kNN search
@@ -157,6 +158,7 @@ def _edge_conv_packed(conv, feat, ktab):
         shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
         packed = (Wuv, scale, shift)
         conv._scp_packed = packed
+        native.note_cache_fill()
     Wuv, scale, shift = packed
     feat = feat.contiguous()
     idx = native.knn_topk_packed(feat, ktab)
@@ -202,6 +204,7 @@ def swin_layer_forward(layer, x, L, shift, query=None):
             bqkv = torch.cat((att.key.bias, att.value.bias), 0).detach().contiguous()
         packed = (Wqkv, bqkv)
         layer._scp_packed = packed
+        native.note_cache_fill()
     Wqkv, bqkv = packed
     ln = layer.layernorm_before
     h = _pad_tokens(layer_norm(x, ln), L)        # zero rows AFTER LayerNorm, like the reference

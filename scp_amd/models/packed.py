@@ -155,6 +155,7 @@ def _swin_layer(layer, x, valid, wtab, shift, query=None):
             b = torch.cat((att.key.bias, att.value.bias), 0).detach().contiguous()
         packed = (W, b, cross)
         layer._scp_packed_v = packed
+        native.note_cache_fill()
     W, b, _ = packed
     lnb = layer.layernorm_before
     # every GEMM operand is produced in the split (bf16 hi/lo) format by the kernel before it: LN -> qkv, attention -> proj,
@@ -236,6 +237,7 @@ def _concat_layer(lin, hs, parents, extra=None):
             slabs[0] = torch.cat((slabs[0], W[:, 256 * n:256 * (n + 1)]), 1).contiguous()
         cache = slabs
         lin._scp_slabs = cache
+        native.note_cache_fill()
     z = None
     for s in range(n - 1, 0, -1):
         z = linear_s(native.split_rows(hs[s + 1]), cache[s], None, residual=z, res_map=None if z is None else parents[s], res_first=z is not None)

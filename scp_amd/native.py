@@ -403,6 +403,17 @@ def swin_attention(q, k, v, bias_table, shift):
 
 ACT_NONE, ACT_LEAKY, ACT_GELU, ACT_RELU = 0, 1, 2, 3
 
+# Lazily built device-side caches (split weights, fused parameter tensors) are created on whatever stream is current.  Every
+# creation site bumps this counter; FrameEncoder.encode_async synchronises once after a call during which it moved, so that a
+# frame enqueued later on ANOTHER stream (lane) never reads a cache entry whose creating kernels are still in flight.
+CACHE_FILLS = 0
+
+
+def note_cache_fill():
+    global CACHE_FILLS
+    CACHE_FILLS += 1
+
+
 
 class SplitWeight:
     """bf16 hi/lo planes of a Linear weight [N,K], zero-padded to [Npad,Kpad] (built once per weight)."""
@@ -416,6 +427,7 @@ class SplitWeight:
         wc = w.detach().contiguous().float()
         _check(lib().scp_split_weight_bf16(_dev(wc), N, K, self.Npad, self.Kpad, _dev(self.hi), _dev(self.lo), _stream()),
                "scp_split_weight_bf16")
+        note_cache_fill()
 
 
 def linear_bf16x3(x, sw, bias=None, act=ACT_NONE, residual=None, out=None):
@@ -456,6 +468,7 @@ class SplitWeightF16:
         wc = w.detach().contiguous().float()
         _check(lib().scp_split_weight_f16(_dev(wc), N, K, self.Npad, self.Kpad, _dev(self.hi), _dev(self.lo), _dev(self.inv_scale),
                                           _stream()), "scp_split_weight_f16")
+        note_cache_fill()
 
 
 def linear_f16x3(x, sw, bias=None, act=ACT_NONE, residual=None):
@@ -519,6 +532,7 @@ def linear_split_scatter(a, sw, bias, out_map, table, act=ACT_NONE, cfg=0):
             if pb is None or pb[0] is not bias:
                 pb = (bias, torch.cat((bias.detach().float(), torch.zeros(Np - N, dtype=torch.float32, device=bias.device))).contiguous())
                 sw._bias_pad = pb
+                note_cache_fill()
             bias = pb[1]
         N = Np
     _check(lib().scp_linear_split_scatter(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.Npad, sw.Kpad,

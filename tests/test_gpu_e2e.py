@@ -105,6 +105,23 @@ def test_async_pipeline_equals_sync(enc_parts):
     assert np.array_equal(plan.coding_order_device(dev).cpu().numpy(), plan.coding_order())
 
 
+def test_two_lane_pipeline_full_size_frames_equal_sequential_encode(enc_parts):
+    """encode_async runs consecutive frames on alternating streams (lanes) with stage G on a third and the range coder on worker
+    threads; six full-size L16 mullevel frames in flight must give the bytes of one-at-a-time encode() calls - per-stream kNN
+    scratch, cache fills, allocator reuse across streams."""
+    from scp_amd.encoder import FrameEncoder
+    from scp_amd.synth import synth_frame
+    model, dev = enc_parts
+    enc = FrameEncoder(model, "kitti", 16, spher=True, mullevel=True, device=dev)
+    frames = [torch.from_numpy(synth_frame(20 + s)).to(dev) for s in range(6)]
+    hs = [enc.encode_async(f) for f in frames]                 # a fresh encoder: the first call also builds the caches
+    got = [enc.finish(h)["bytes"] for h in hs]
+    want = [enc.encode(f)["bytes"] for f in frames]
+    assert got == want
+    hs = [enc.encode_async(f) for f in frames[::-1]]
+    assert [enc.finish(h)["bytes"] for h in hs] == want[::-1]
+
+
 def test_determinism(enc_parts):
     from scp_amd.encoder import FrameEncoder
     from scp_amd.synth import synth_frame
