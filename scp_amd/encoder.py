@@ -445,19 +445,34 @@ class OctAttnFrameEncoder:
             self._pool = ThreadPoolExecutor(max_workers=2)
             self._copy_stream = torch.cuda.Stream(device=self.device)
             self._front_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            # one lane by default here: two frames in flight measured no faster for this model (its kernels leave fewer gaps)
+            self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(os.environ.get("SCP_LANES_OCTATTN", "1"))))]
+            self._lane_i = 0
         # stage G has small D2H syncs: on a high-priority side stream they wait for stage G only, not for the previous frame's
-        # model kernels still queued on the main stream
-        main = torch.cuda.current_stream(self.device)
+        # model kernels still queued on the main stream; consecutive frames run their model part on alternating streams (lanes,
+        # see FrameEncoder.encode_async)
+        caller = torch.cuda.current_stream(self.device)
+        if len(self._lanes) > 1:
+            main = self._lanes[self._lane_i % len(self._lanes)]
+            self._lane_i += 1
+            main.wait_stream(caller)
+        else:
+            main = caller
+        fills0 = native.CACHE_FILLS
         with torch.cuda.stream(self._front_stream):
+            self._front_stream.wait_stream(caller)
             xyz_dev = xyz.to(self.device, non_blocking=True)
             q, qi, _ = native.quantize(xyz_dev, self.mode, level_qs(self.data_type, self.lidar_level), self.cart_offset)
             front = self._front(q)
             ready = torch.cuda.Event()
             ready.record()
         main.wait_event(ready)
-        lohi, meta, keep = self.encode_ints(q, qi.bin_num, xyz_dev.shape[0], t0, defer=True, front=front)
-        done = torch.cuda.Event()
-        done.record()
+        with torch.cuda.stream(main):
+            lohi, meta, keep = self.encode_ints(q, qi.bin_num, xyz_dev.shape[0], t0, defer=True, front=front)
+            done = torch.cuda.Event()
+            done.record()
+            if native.CACHE_FILLS != fills0:
+                main.synchronize()
         host = torch.empty(lohi.shape, dtype=lohi.dtype, pin_memory=True)
         with torch.cuda.stream(self._copy_stream):
             self._copy_stream.wait_event(done)
