@@ -44,6 +44,12 @@ struct BitSink {
         put(bit);
         if (pending) { put_run(bit ^ 1u, pending); pending = 0; }
     }
+    inline void put_bits(uint32_t v, int k) {   // the low k (<= 31) bits of v, MSB first
+        drain();                                // nbits < 8 from here
+        acc = (acc << k) | (uint64_t)v;
+        nbits += k;
+        drain();
+    }
     inline void finish() {
         drain();
         if (nbits) { acc <<= (8 - nbits); nbits = 8; drain(); }  // zero-pad the last byte
@@ -57,12 +63,28 @@ struct Coder {
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
         high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> 16);
         low = low + (uint32_t)((span * (uint64_t)c_low) >> 16);
-        for (;;) {
-            if (high < 0x80000000u) { s.put_with_pending(0, pending); low <<= 1; high = (high << 1) | 1u; }
-            else if (low >= 0x80000000u) { s.put_with_pending(1, pending); low <<= 1; high = (high << 1) | 1u; }
-            else if (low >= 0x40000000u && high < 0xC0000000u) {
-                ++pending; low = (low << 1) & 0x7FFFFFFFu; high = (high << 1) | 0x80000001u;
-            } else break;
+        // Renormalisation, all shifts of a kind at once (the reference shifts one bit per loop iteration; the three cases cannot
+        // interleave: once the top bits differ only underflow shifts remain).
+        // (1) k leading bits shared by low and high leave as output bits: the first one followed by the pending (underflow)
+        //     bits, the other k - 1 verbatim.  low < high always (c_high > c_low, span > 2^30), so k <= 31.
+        const uint32_t diff = low ^ high;
+        if (!(diff & 0x80000000u)) {
+            const int k = __builtin_clz(diff);
+            const uint32_t top = low >> (32 - k);             // the k shared bits
+            s.put_with_pending(top >> (k - 1), pending);
+            if (k > 1) s.put_bits(top & ((1u << (k - 1)) - 1u), k - 1);
+            low <<= k;
+            high = (high << k) | ((1u << k) - 1u);
+        }
+        // (2) underflow: low = 01..., high = 10...: one shift per position where low continues with 1s and high with 0s
+        if (low >= 0x40000000u && high < 0xC0000000u) {
+            const uint32_t l1 = ~(low << 1), h1 = high << 1;  // leading 1s of low / leading 0s of high after the top bit
+            const int a = l1 ? __builtin_clz(l1) : 32, b = h1 ? __builtin_clz(h1) : 32;
+            int u = a < b ? a : b;                            // >= 1 here
+            if (u > 31) u = 31;
+            pending += (uint64_t)u;
+            low = (low << u) & 0x7FFFFFFFu;
+            high = (high << u) | 0x80000000u | ((1u << u) - 1u);
         }
     }
     inline void flush(BitSink &s) {

@@ -53,6 +53,28 @@ def test_range_coder_matches_reference_streams(orc):
     assert native.ac_encode_cdf(orc.pmf_to_cdf(pdf), z["pend_sym"]) == z["pend_bytes"].tobytes()
 
 
+def test_range_coder_equals_oracle_coder_on_adversarial_tables(orc):
+    """The product coder renormalises with count-leading-zeros bursts; the oracle (a restatement of numpyAc_backend.cpp:245-323)
+    shifts bit by bit.  Random CDF tables from flat to extremely peaked - long runs of shared leading bits, long underflow
+    (pending) runs, the 0x10000 top symbol - must give identical streams."""
+    from scp_amd import native
+    rng = np.random.default_rng(7)
+    for sharp in (0.0, 2.0, 8.0, 40.0):
+        n = 20000
+        logits = rng.standard_normal((n, 255)) * sharp
+        if sharp >= 8.0:
+            logits[:, 127] += 3 * sharp                      # mass piles up around the middle of the range: underflow runs
+        p = np.exp(logits - logits.max(1, keepdims=True))
+        pdf = (p / p.sum(1, keepdims=True)).astype(np.float32)
+        cdf = orc.pmf_to_cdf(pdf)
+        cum = np.cumsum(pdf.astype(np.float64), 1)
+        sym = np.minimum((rng.random((n, 1)) * cum[:, -1:] > cum).sum(1), 254).astype(np.int16)   # sampled from the model
+        sym[::97] = 254                                      # the top symbol (c_high = 0x10000)
+        sym[5::101] = rng.integers(0, 255, len(sym[5::101]))  # and improbable ones
+        want = orc.ac_encode(cdf.view(np.uint16), sym)
+        assert native.ac_encode_cdf(cdf, sym) == want, sharp
+
+
 def test_range_coder_argument_errors():
     from scp_amd import native
     import ctypes as C
