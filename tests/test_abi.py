@@ -89,3 +89,28 @@ def test_range_coder_argument_errors():
     cdf = np.tile(np.arange(256, dtype=np.uint16) * 255, (64, 1))
     sym = np.full(64, 3, np.int16)
     assert L.scp_ac_encode_cdf(cdf.ctypes.data, sym.ctypes.data, 64, 256, out.ctypes.data, 2, C.byref(n)) == -3
+
+
+def test_model_kernel_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument checks come before any HIP call: NULL pointers, wrong widths and misaligned strides return SCP_EINVAL (-1) on a
+    machine without a GPU - nothing is launched, nothing falls back to a CPU path."""
+    from scp_amd import native
+    L = native.lib()
+    z, one = None, 4096            # NULL and a fake (never dereferenced) non-NULL address
+    # fused Swin MLP: every operand is mandatory, strides must keep 16-byte rows
+    assert L.scp_mlp_split_fused(z, z, 256, z, z, z, z, z, z, z, 0, z, 256, 10, z) == -1
+    assert L.scp_mlp_split_fused(one, one, 250, one, one, one, one, one, one, z, 0, one, 256, 10, z) == -1     # ldx % 8
+    assert L.scp_mlp_split_fused(one, one, 256, one, one, one, one, one, one, z, 0, one, 256, 0, z) == -1       # M == 0
+    # f16x3 dense layer: K % 4, missing workspace
+    assert L.scp_linear_f16x3(one, 600, one, one, one, 608, z, z, 0, one, 600, 8, 600, 600, 0, z, z) == -1
+    assert L.scp_linear_f16x3(one, 602, one, one, one, 608, z, z, 0, one, 600, 8, 600, 602, 0, one, z) == -1
+    assert L.scp_split_weight_f16(z, 600, 600, 640, 608, one, one, one, z) == -1
+    assert L.scp_split_weight_f16(one, 600, 600, 600, 608, one, one, one, z) == -1                               # Npad % 128
+    # f16x3 OctAttention: head width other than 150, window longer than 1024, workspace too small / misaligned
+    assert L.scp_octattn_f16x3_ws_bytes(0, 1024, 4) == -1
+    need = L.scp_octattn_f16x3_ws_bytes(2, 1024, 4)
+    assert need > 2 * 32 * 4 * (22528 + 25600)
+    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 2, 1024, 4, 128, one, one, 4096, need, z) == -1
+    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 2, 2048, 4, 150, one, one, 4096, need, z) == -1
+    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 2, 1024, 4, 150, one, one, 4096, need - 1, z) == -1
+    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 2, 1024, 4, 150, one, one, 4097, need, z) == -1
