@@ -3,7 +3,7 @@
 // Drop-in for numpyAc/backend/numpyAc_backend.cpp: `encode` :245-323 (scp_ac_encode_cdf) and the stateful
 // `class decode` :134-217 (scp_ac_dec_*).  scp_ac_encode_lohi consumes the (c_low, c_high) pairs the device
 // CDF kernel emits, so the 512 B/symbol CDF table never crosses PCIe.  Bit-exact with the reference
-// (tests/test_rangecoder.py against tests/golden/ac_streams.npz).
+// (tests/test_abi.py and tests/test_gpu_e2e.py against tests/golden/ac_streams.npz).
 //
 // Output is produced through a 64-bit accumulator and written a byte at a time; pending (underflow) bits
 // are flushed in whole-word bursts instead of the reference's bit-by-bit std::string appends.
