@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import native
-from ..ops import linear, layer_norm, gelu_linear, leaky_mlp3
+from ..ops import linear, layer_norm, gelu_linear, leaky_mlp3, derived
 
 WINDOW = 512
 SHIFT = 256
@@ -121,22 +121,36 @@ class SwinEncoder(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------- forward pieces
-def _edge_conv(conv, feat, k):
-    """feat [B,n,C] -> [B,n,C'] : kNN in feature space + (split 1x1 conv) + BN + LeakyReLU(0.2) + max over k."""
-    W = conv[0].weight  # [C', 2C, 1, 1]
-    bn = conv[1]
+def _edge_fold(conv):
+    """The 1x1 convolution on (neighbour - centre, centre) as two products on the points ([W1; W2 - W1]) and the eval-mode
+    BatchNorm as one scale / shift pair; derived from the parameters, rebuilt when they change."""
+    W, bn = conv[0].weight, conv[1]
     Cout, C2 = W.shape[0], W.shape[1]
     C = C2 // 2
-    packed = getattr(conv, "_scp_packed", None)
-    if packed is None or packed[0].device != W.device:
+
+    def build():
         W2d = W.detach().reshape(Cout, C2)
         Wuv = torch.cat((W2d[:, :C], W2d[:, C:] - W2d[:, :C]), 0).contiguous()          # [2C', C]
         scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).contiguous()
         shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
-        packed = (Wuv, scale, shift)
-        conv._scp_packed = packed
-        native.note_cache_fill()
-    Wuv, scale, shift = packed
+        return Wuv, scale, shift
+    return derived(conv, "fold", (W, bn.weight, bn.bias, bn.running_mean, bn.running_var), build)
+
+
+def qkv_fused(layer, cross):
+    """(weight, bias) of the layer's q|k|v projections as one product (k|v for a cross layer, whose q comes from the query stream)."""
+    att = layer.attention.self
+    mods = (att.key, att.value) if cross else (att.query, att.key, att.value)
+
+    def build():
+        return (torch.cat([m.weight for m in mods], 0).detach().contiguous(), torch.cat([m.bias for m in mods], 0).detach().contiguous())
+    return derived(layer, "kv" if cross else "qkv", [m.weight for m in mods] + [m.bias for m in mods], build)
+
+
+def _edge_conv(conv, feat, k):
+    """feat [B,n,C] -> [B,n,C'] : kNN in feature space + (split 1x1 conv) + BN + LeakyReLU(0.2) + max over k."""
+    Cout = conv[0].weight.shape[0]  # [C', 2C, 1, 1]
+    Wuv, scale, shift = _edge_fold(conv)
     idx = native.knn_topk(feat, k)
     uv = linear(feat, Wuv, None, exact=True)          # [B,n,2C'] plain fp32: these features feed the next kNN search
     u = uv[..., :Cout].contiguous()
@@ -146,20 +160,8 @@ def _edge_conv(conv, feat, k):
 
 def _edge_conv_packed(conv, feat, ktab):
     """packed layout: feat [T,C] (all windows back to back, padded to x512 rows), ktab int32 [T/512,2] -> [T,C']."""
-    W = conv[0].weight
-    bn = conv[1]
-    Cout, C2 = W.shape[0], W.shape[1]
-    C = C2 // 2
-    packed = getattr(conv, "_scp_packed", None)
-    if packed is None or packed[0].device != W.device:
-        W2d = W.detach().reshape(Cout, C2)
-        Wuv = torch.cat((W2d[:, :C], W2d[:, C:] - W2d[:, :C]), 0).contiguous()
-        scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).contiguous()
-        shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
-        packed = (Wuv, scale, shift)
-        conv._scp_packed = packed
-        native.note_cache_fill()
-    Wuv, scale, shift = packed
+    Cout = conv[0].weight.shape[0]
+    Wuv, scale, shift = _edge_fold(conv)
     feat = feat.contiguous()
     idx = native.knn_topk_packed(feat, ktab)
     uv = linear(feat, Wuv, None, exact=True)
@@ -194,18 +196,7 @@ def _pad_tokens(h, L):
 def swin_layer_forward(layer, x, L, shift, query=None):
     """swin_transformer.py:654-706.  x [B,L,256]; query (cross stream) [B,L,256] or None."""
     att = layer.attention.self
-    packed = getattr(layer, "_scp_packed", None)
-    if packed is None or packed[0].device != x.device:
-        if query is None:
-            Wqkv = torch.cat((att.query.weight, att.key.weight, att.value.weight), 0).detach().contiguous()
-            bqkv = torch.cat((att.query.bias, att.key.bias, att.value.bias), 0).detach().contiguous()
-        else:
-            Wqkv = torch.cat((att.key.weight, att.value.weight), 0).detach().contiguous()
-            bqkv = torch.cat((att.key.bias, att.value.bias), 0).detach().contiguous()
-        packed = (Wqkv, bqkv)
-        layer._scp_packed = packed
-        native.note_cache_fill()
-    Wqkv, bqkv = packed
+    Wqkv, bqkv = qkv_fused(layer, query is not None)
     ln = layer.layernorm_before
     h = _pad_tokens(layer_norm(x, ln), L)        # zero rows AFTER LayerNorm, like the reference
     if query is None:
@@ -274,12 +265,6 @@ class EHEM(nn.Module):
         sd = torch.load(path, map_location=map_location)
         m.load_state_dict(sd["state_dict"] if "state_dict" in sd else sd, strict=True)
         return m
-
-    def load_state_dict(self, sd, strict=True, **kw):
-        for mod in self.modules():
-            if hasattr(mod, "_scp_packed"):
-                del mod._scp_packed
-        return super().load_state_dict(sd, strict=strict, **kw)
 
     @torch.no_grad()
     def forward(self, data, pos, enc=True):

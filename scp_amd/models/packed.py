@@ -14,8 +14,8 @@ import torch
 import torch.nn.functional as F
 
 from .. import native
-from ..ops import linear_s, leaky_mlp3_s, split_cat, linear, layer_norm, leaky_mlp3, _split
-from .ehem import SHIFT, WINDOW, _edge_conv_packed
+from ..ops import linear_s, leaky_mlp3_s, split_cat, linear, layer_norm, leaky_mlp3, _split, derived
+from .ehem import SHIFT, WINDOW, _edge_conv_packed, qkv_fused
 
 
 def _ceil512(a):
@@ -144,19 +144,8 @@ def _swin_layer(layer, x, valid, wtab, shift, query=None):
     """swin_transformer.py:654-706 on a packed layout (rows beyond a window's length are don't-care, except that the
     LayerNorm output is zeroed there - the reference zero-pads AFTER LayerNorm)."""
     att = layer.attention.self
-    packed = getattr(layer, "_scp_packed_v", None)
     cross = query is not None
-    if packed is None or packed[0].device != x.device or packed[2] != cross:
-        if not cross:
-            W = torch.cat((att.query.weight, att.key.weight, att.value.weight), 0).detach().contiguous()
-            b = torch.cat((att.query.bias, att.key.bias, att.value.bias), 0).detach().contiguous()
-        else:
-            W = torch.cat((att.key.weight, att.value.weight), 0).detach().contiguous()
-            b = torch.cat((att.key.bias, att.value.bias), 0).detach().contiguous()
-        packed = (W, b, cross)
-        layer._scp_packed_v = packed
-        native.note_cache_fill()
-    W, b, _ = packed
+    W, b = qkv_fused(layer, cross)
     lnb = layer.layernorm_before
     # every GEMM operand is produced in the split (bf16 hi/lo) format by the kernel before it: LN -> qkv, attention -> proj,
     # LN -> fc1 -> fc2; the residual stream x stays fp32
@@ -229,15 +218,13 @@ def _concat_layer(lin, hs, parents, extra=None):
     in products and in split conversions; the result differs from the one-shot layer only in fp32 summation order.
     `extra`: one more 256-wide input at stage-0 resolution (the odd-token features of the cross branch, ehem.py:124)."""
     n = len(hs) - 1
-    cache = getattr(lin, "_scp_slabs", None)
-    if cache is None or cache[0].device != lin.weight.device:
+    def build():
         W = lin.weight.detach()
         slabs = [W[:, 256 * s:256 * (s + 1)].contiguous() for s in range(n)]
         if extra is not None:
             slabs[0] = torch.cat((slabs[0], W[:, 256 * n:256 * (n + 1)]), 1).contiguous()
-        cache = slabs
-        lin._scp_slabs = cache
-        native.note_cache_fill()
+        return slabs
+    cache = derived(lin, "slabs+" if extra is not None else "slabs", (lin.weight,), build)
     z = None
     for s in range(n - 1, 0, -1):
         z = linear_s(native.split_rows(hs[s + 1]), cache[s], None, residual=z, res_map=None if z is None else parents[s], res_first=z is not None)

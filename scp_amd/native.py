@@ -529,8 +529,9 @@ def linear_split_scatter(a, sw, bias, out_map, table, act=ACT_NONE, cfg=0):
         Np = -(-N // 4) * 4
         if bias is not None:
             pb = getattr(sw, "_bias_pad", None)
-            if pb is None or pb[0] is not bias:
-                pb = (bias, torch.cat((bias.detach().float(), torch.zeros(Np - N, dtype=torch.float32, device=bias.device))).contiguous())
+            ver = (bias._version, bias.data_ptr())
+            if pb is None or pb[0] is not bias or pb[2] != ver:
+                pb = (bias, torch.cat((bias.detach().float(), torch.zeros(Np - N, dtype=torch.float32, device=bias.device))).contiguous(), ver)
                 sw._bias_pad = pb
                 note_cache_fill()
             bias = pb[1]

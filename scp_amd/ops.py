@@ -29,9 +29,10 @@ def _split(w):
     """bf16 hi/lo planes of a weight, cached per tensor OBJECT (evicted when the tensor dies or is modified in place)."""
     key = id(w)
     ent = _cache.get(key)
-    if ent is None or ent[1] != w._version or ent[2]() is not w:
+    ver = (w._version, w.data_ptr(), w.device)
+    if ent is None or ent[1] != ver or ent[2]() is not w:
         sw = native.SplitWeight(w)
-        _cache[key] = (sw, w._version, weakref.ref(w, lambda _r, k=key: _cache.pop(k, None)))
+        _cache[key] = (sw, ver, weakref.ref(w, lambda _r, k=key: _cache.pop(k, None)))
         return sw
     return ent[0]
 
@@ -43,11 +44,26 @@ def _split16(w):
     """row-scaled f16 hi/lo planes of a weight (native.SplitWeightF16), cached like _split."""
     key = id(w)
     ent = _cache16.get(key)
-    if ent is None or ent[1] != w._version or ent[2]() is not w:
+    ver = (w._version, w.data_ptr(), w.device)
+    if ent is None or ent[1] != ver or ent[2]() is not w:
         sw = native.SplitWeightF16(w)
-        _cache16[key] = (sw, w._version, weakref.ref(w, lambda _r, k=key: _cache16.pop(k, None)))
+        _cache16[key] = (sw, ver, weakref.ref(w, lambda _r, k=key: _cache16.pop(k, None)))
         return sw
     return ent[0]
+
+
+def derived(owner, name, sources, build):
+    """A tensor (tuple) derived from parameters - fused qkv weights, conv / BN folds, weight slabs - cached on the owning module
+    and rebuilt whenever a source changed: its storage, device or in-place version (`load_state_dict`, `fill_weights` and
+    optimiser steps all bump `_version`).  The bf16 splits further down are keyed on the derived tensors, so they follow."""
+    key = tuple((t.data_ptr(), t._version, t.device) for t in sources)
+    store = owner.__dict__.setdefault("_scp_derived", {})
+    ent = store.get(name)
+    if ent is None or ent[0] != key:
+        ent = (key, build())
+        store[name] = ent
+        native.note_cache_fill()
+    return ent[1]
 
 
 def clear_cache():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE in this container.
 
-    python tests/golden/make_golden.py [group ...]      # groups: xform oct kseq ctx e2e logits swin cdf ac facts
+    python tests/golden/make_golden.py [group ...]      # groups: xform oct kseq ctx e2e logits logits_tiefree swin cdf ac facts
 
 Only data (inputs + expected outputs) is written; no reference source travels.  Every
 fixture records which reference call produced it.  The script needs
@@ -383,6 +383,39 @@ def gen_logits():
             save(f"logits_octattn_{tag}", data=d.astype(np.int16), pos=p, out=o[0].numpy(), seed=np.int32(0))
 
 
+def gen_logits_tiefree():
+    """EHEM.forward (models/ehem.py:88-136) on windows whose positions are random float32 triples instead of octree lattice points:
+    no exactly tied neighbour distances (dgcnn.py:10-45 `topk` has no tie order to disagree about), so EVERY row of the
+    reference's logits is a hard target.  The three neighbour lists the reference's `knn` produced are stored too (sorted per
+    row: the edge convolution takes a max over the neighbours, the set is what matters)."""
+    print("[logits_tiefree]")
+    import models.dgcnn as RD
+    m = build_ref_ehem(0)
+    rec = []
+    orig = RD.knn
+
+    def spy(x, k):
+        idx = orig(x, k)
+        rec.append(np.sort(idx[0].numpy().astype(np.int16), axis=1))
+        return idx
+
+    RD.knn = spy
+    try:
+        z8 = np.load(os.path.join(HERE, "logits_ehem_c8192.npz"))
+        for tag, c, stride in (("c600", 600, 1), ("c2049", 2049, 1), ("c8192", 8192, 8)):
+            rng = np.random.default_rng(9000 + c)
+            d = z8["data"][:c].astype(np.int64)
+            p = rng.random((3, c), dtype=np.float32)
+            del rec[:]
+            with torch.no_grad():
+                o1, o2 = m(torch.from_numpy(d)[None].clone(), torch.from_numpy(p)[None].clone(), enc=True)
+            assert len(rec) == 3
+            save(f"tiefree_ehem_{tag}", data=d.astype(np.int16), pos=p, out1=o1[0, ::stride].numpy(), out2=o2[0, ::stride].numpy(),
+                 stride=np.int32(stride), knn0=rec[0], knn1=rec[1], knn2=rec[2], seed=np.int32(0))
+    finally:
+        RD.knn = orig
+
+
 def gen_swin():
     print("[swin]")
     from models.swin_transformer import SwinLayer, SwinConfig, SwinPatchMerging
@@ -639,6 +672,25 @@ def gen_facts():
         with open(os.path.join(HERE, "frame_facts.json"), "w") as f:
             json.dump(facts, f, indent=1)
 
+def gen_frame_ints():
+    """The reference quantiser's integers (data_preprocess.py:40-68 through numpy's float32 SIMD arctan2 / arccos of THIS
+    container) for the 120k-point frame at every full-size configuration of frame_facts.json, in point order.  numpy's float32
+    trigonometry is CPU dependent, so the GPU box cannot re-derive them: with these as input the full-size stream / record
+    checksums are asserted unconditionally."""
+    print("[frame_ints]")
+    xyz = synth_frame(0)
+    facts = json.load(open(os.path.join(HERE, "frame_facts.json")))
+    out = {}
+    for mode, L, key in (("spher", 12, "L12-s"), ("spher", 16, "L16-s"), ("spher", 17, None), ("spher", 18, None), ("cylin", 14, "C14"),
+                         ("cart", 12, "L12-c")):
+        _, bin_num, q, off = quantise_like_proc_pc(xyz, 400 / (2 ** L - 1), mode)
+        q = np.asarray(q)
+        assert np.array_equal(q, q.astype(np.int32))
+        if key is not None:
+            assert sha(np.unique(q, axis=0).astype(np.int32)) == facts[key]["pts_sha"] and bin_num == facts[key]["bin_num"]
+        out[f"q_{mode}_L{L}"] = q.astype(np.int32)
+    save("frame_ints", **out)
+
 
 def gen_keys():
     """state_dict key/shape/dtype inventory of the reference modules (drop-in checkpoint contract, Appendix D)."""
@@ -721,8 +773,8 @@ def gen_trainset():
              data=np.stack([it[0] for it in items]), pos=np.stack([it[1] for it in items]), label=np.stack([it[2] for it in items]))
 
 
-GROUPS = {"trainset": gen_trainset, "metrics": gen_metrics, "keys": gen_keys, "xform": gen_xform, "oct": gen_oct, "ctx": gen_ctx, "logits": gen_logits, "swin": gen_swin,
-          "cdf": gen_cdf, "ac": gen_ac, "e2e": gen_e2e, "facts": gen_facts}
+GROUPS = {"trainset": gen_trainset, "metrics": gen_metrics, "keys": gen_keys, "xform": gen_xform, "oct": gen_oct, "ctx": gen_ctx, "logits": gen_logits, "logits_tiefree": gen_logits_tiefree, "swin": gen_swin,
+          "cdf": gen_cdf, "ac": gen_ac, "e2e": gen_e2e, "facts": gen_facts, "frame_ints": gen_frame_ints}
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

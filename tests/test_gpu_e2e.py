@@ -20,6 +20,12 @@ def enc_parts():
     return fill_weights(EHEM(ehem_cfg()), 0).to(dev), dev
 
 
+# measured (profiles/parity_r2.json) minus a margin: rows whose 20th / 21st neighbours are exactly tied on the octree lattice are
+# resolved by the reference's CPU top-k and may move by more than 1e-4
+PMF_ROWS_MIN = 0.9
+BITS_REL_MAX = 0.005
+
+
 def _check_against_reference(res, z, orc, plan_levels):
     from scp_amd import native
     # structure: number of nodes, coded symbol sequence (= occupancy stream in the reference's coding order): bit-exact
@@ -32,11 +38,14 @@ def _check_against_reference(res, z, orc, plan_levels):
     pmf = out["pmf"].cpu().numpy()[::int(z["pdf_stride"])]
     close = (np.abs(pmf - z["pdf_sub"]).max(1) < 1e-4).mean()
     print(f"PMF rows within 1e-4 of the reference: {100 * close:.2f}%")
-    assert close > 0.9
+    from conftest import parity_record
+    parity_record("e2e/" + str(z["fname"]), pmf_rows_within_1e4=close, max_dpmf=np.abs(pmf - z["pdf_sub"]).max(), bits=res["bits"],
+                  reference_bits=8 * len(z["bytes"]))
+    assert close > PMF_ROWS_MIN
     # rate: same model, same symbols -> the bitstream length agrees to a fraction of a percent
     ref_bits = 8 * len(z["bytes"])
     print(f"bits {res['bits']} vs reference {ref_bits}  (bpp {res['bpp']:.4f} vs {float(z['bpp']):.4f})")
-    assert abs(res["bits"] - ref_bits) <= 0.005 * ref_bits
+    assert abs(res["bits"] - ref_bits) <= BITS_REL_MAX * ref_bits
     # the stream decodes back to the coded symbols with the oracle's decoder and this library's integer CDFs
     cdf = native.softmax_cdf(res["_debug"]["table"], want_lohi=False, want_cdf=True)["cdf"].cpu().numpy().view(np.uint16)
     dec = orc.AcDecoder(res["bytes"])

@@ -154,51 +154,56 @@ def test_octree_random_vs_oracle(dev, orc):
 
 
 def test_full_frame_checksums(dev):
-    """BASELINE-size frames: structure facts + sha256 of the code stream / records recorded from the reference."""
+    """BASELINE-size frames (configs[1..4] geometry): the REFERENCE quantiser's integers in (tests/golden/frame_ints.npz, made by
+    running data_preprocess.py:40-68 in the build container) -> node counts per level, sha256 of the occupancy stream and of the
+    [N,4,6] K-records must equal what the reference's octree builders produced (frame_facts.json) - asserted unconditionally -
+    and the device quantiser's own integers may differ from the reference's for at most the measured handful of points."""
     import torch
+    from conftest import parity_record
     from scp_amd import native
     from scp_amd.synth import synth_frame
     facts = json.load(open(os.path.join(GOLDEN, "frame_facts.json")))
+    ints = golden("frame_ints")
     xyz = torch.from_numpy(synth_frame(0)).to(dev)
-    report = {}
-    for key, mode, L in (("L12-s", native.SPHER, 12), ("L16-s", native.SPHER, 16), ("C14", native.CYLIN, 14),
-                         ("L12-c", native.CART, 12)):
-        f = facts[key]
-        q, info, _ = native.quantize(xyz, mode, 400 / (2 ** L - 1), -200.0)
-        assert info.bin_num == f["bin_num"]
-        g = native.Geom()
-        g.build(q, [(0, len(q), None, False)])
-        i = g.info[0]
-        same_pts = sha(np.unique(q.cpu().numpy(), axis=0)) == f["pts_sha"]
-        report[key] = dict(same_quantised_points=same_pts, n_nodes=int(i.n_nodes), ref_nodes=f["N"])
-        assert i.depth == f["D"]
-        if same_pts:   # identical integers in -> bit-identical stream out
-            assert g.level_counts(0) == f["per_level"] and i.n_nodes == f["N"] and i.n_leaves == f["U"]
-            assert sha(g.nodes(("occ",))["occ"].cpu().numpy()) == f["codes_sha"]
-            if "krec_sha_i32" in f:
-                assert sha(g.krecords(0).cpu().numpy().astype(np.int32)) == f["krec_sha_i32"]
-        else:
-            assert abs(i.n_nodes - f["N"]) < 0.01 * f["N"]
-    print("full frames:", report)
-    # mullevel L16: three shells
-    shells = facts["L16-m"]
-    qs_list, segs = [], []
     n = xyz.shape[0]
+    # measured on MI355X (profiles/parity_r2.json): points whose device-quantised integers differ from this fixture's
+    max_diff_pts = {"L12-s": 1200, "L16-s": 8, "C14": 8, "L12-c": 0, "L17": 8, "L18": 16}
+    for key, mode, name, L in (("L12-s", native.SPHER, "q_spher_L12", 12), ("L16-s", native.SPHER, "q_spher_L16", 16),
+                               ("C14", native.CYLIN, "q_cylin_L14", 14), ("L12-c", native.CART, "q_cart_L12", 12)):
+        f = facts[key]
+        q_dev, info, _ = native.quantize(xyz, mode, 400 / (2 ** L - 1), -200.0)
+        assert info.bin_num == f["bin_num"]
+        q_ref = ints[name]
+        ndiff = int((q_dev.cpu().numpy() != q_ref).any(1).sum())
+        parity_record(f"quantiser/{key}", points=n, points_differing_from_reference_ints=ndiff)
+        assert ndiff <= max_diff_pts[key], (key, ndiff)
+        g = native.Geom()
+        g.build(torch.from_numpy(q_ref).to(dev), [(0, n, None, False)])
+        i = g.info[0]
+        assert i.depth == f["D"] and g.level_counts(0) == f["per_level"] and i.n_nodes == f["N"] and i.n_leaves == f["U"]
+        assert sha(g.nodes(("occ",))["occ"].cpu().numpy()) == f["codes_sha"]
+        if "krec_sha_i32" in f:
+            assert sha(g.krecords(0).cpu().numpy().astype(np.int32)) == f["krec_sha_i32"]
+    # mullevel L16 (BASELINE configs[2], the bench workload): three shells in one build
+    shells = facts["L16-m"]
+    qs_list = []
     for k in range(3):
-        q, info, _ = native.quantize(xyz, native.SPHER, 400 / (2 ** (16 + k) - 1), 0.0)
+        q_dev, info, _ = native.quantize(xyz, native.SPHER, 400 / (2 ** (16 + k) - 1), 0.0)
         assert info.bin_num == shells[k]["bin_num"]
-        qs_list.append(q)
+        q_ref = ints[f"q_spher_L{16 + k}"]
+        ndiff = int((q_dev.cpu().numpy() != q_ref).any(1).sum())
+        parity_record(f"quantiser/L16-m shell {k}", points=n, points_differing_from_reference_ints=ndiff)
+        assert ndiff <= max_diff_pts[("L16-s", "L17", "L18")[k]], (k, ndiff)
+        qs_list.append(torch.from_numpy(q_ref).to(dev))
     g = native.Geom()
     g.build(torch.cat(qs_list), [(0, n, [0, 0], True), (n, n, [0, 1], True), (2 * n, n, [1], True)])
     for k in range(3):
         i = g.info[k]
-        assert i.depth == shells[k]["D"]
-        if i.n_leaves == shells[k]["leaves"] and g.rows(k) == shells[k]["records"]:
-            occ = g.nodes(("occ",))["occ"][i.node_base:i.node_base + i.n_nodes].cpu().numpy()
-            ok = sha(occ) == shells[k]["codes_sha"]
-            if ok:
-                assert sha(g.krecords(k).cpu().numpy().astype(np.int32)) == shells[k]["krec_sha_i32"]
-            print("shell", k, "identical to reference:", ok)
+        assert i.depth == shells[k]["D"] and i.n_leaves == shells[k]["leaves"] and g.rows(k) == shells[k]["records"], k
+        assert g.level_counts(k) == shells[k]["per_level"], k
+        occ = g.nodes(("occ",))["occ"][i.node_base:i.node_base + i.n_nodes].cpu().numpy()
+        assert sha(occ) == shells[k]["codes_sha"], k
+        assert sha(g.krecords(k).cpu().numpy().astype(np.int32)) == shells[k]["krec_sha_i32"], k
 
 
 # ----------------------------------------------------------------------------------------------- a8/a9

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from cfgs import ehem_cfg, octattn_cfg
-from conftest import GOLDEN, golden
+from conftest import GOLDEN, golden, parity_record
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3
@@ -102,7 +102,17 @@ def test_knn_matches_cpu_reference_topk_on_real_window(dev):
     got = native.knn_topk(pos.transpose(1, 2).contiguous().to(dev), 20).cpu().long()
     same = (torch.sort(ref, 2)[0] == torch.sort(got, 2)[0]).all(2).float().mean().item()
     print(f"kNN neighbour sets identical to CPU torch.topk for {100 * same:.2f}% of the points")
-    assert same > 0.5
+    # lattice positions: every differing point must be a TIE at the 20th / 21st neighbour, i.e. a point where the reference's own
+    # CPU and CUDA top-k disagree as well.  Squared lattice distances are integers (in lattice units) of a few tens at the 20th
+    # neighbour: distinct ones differ by >= 2 %, tied ones by the float32 rounding of the normalised coordinates (<= 1e-4).
+    x = pos[0].T.double()
+    d = ((x[:, None, :] - x[None, :, :]) ** 2).sum(-1)
+    srt = torch.sort(d, 1)[0]
+    tie = (srt[:, 19] - srt[:, 20]).abs() <= 1e-3 * srt[:, 20].abs().clamp_min(1e-30)
+    differs = ~(torch.sort(ref, 2)[0] == torch.sort(got, 2)[0]).all(2)[0]
+    parity_record("knn_pos_lattice_c1024", sets_identical=same, differing_points=int(differs.sum()), differing_not_tied=int((differs & ~tie).sum()))
+    assert not (differs & ~tie).any()
+    assert same > 0.9
 
 
 # ----------------------------------------------------------------------------------------------- edge conv
@@ -241,6 +251,144 @@ def test_swin_attention_argument_errors(dev):
 
 
 # ----------------------------------------------------------------------------------------------- EHEM
+def _ehem_case(z):
+    data = torch.from_numpy(z["data"].astype(np.int64))
+    pos = torch.from_numpy(z["pos"])
+    if data.dim() == 3:
+        data, pos = data[None], pos[None]
+    return data, pos
+
+
+def _want_rows(z):
+    """(stride, even rows, odd rows) of a logits fixture, batch axis first."""
+    if "out1_sub" in z:
+        return int(z["stride"]), z["out1_sub"][None], z["out2_sub"][None]
+    st = int(z["stride"]) if "stride" in z else 1
+    w1, w2 = z["out1"], z["out2"]
+    if w1.ndim == 2:
+        w1, w2 = w1[None], w2[None]
+    return st, w1, w2
+
+
+def _run_packed(ehem, data, pos, dev):
+    """The product path (FrameEncoder / decoder): every batch entry is one window of ONE packed forward."""
+    B, c = data.shape[:2]
+    ctx = data.reshape(B * c, 12).to(torch.uint8).to(dev)
+    p = pos.transpose(1, 2).reshape(B * c, 3).contiguous().to(dev)
+    ev, od = ehem.forward_packed(ctx, p, [c] * B)
+    return ev.reshape(B, (c + 1) // 2, 255).cpu().numpy(), od.reshape(B, c // 2, 255).cpu().numpy()
+
+
+def _row_err(o1, o2, st, w1, w2):
+    e1 = np.abs(o1[:, ::st] - w1).reshape(-1, 255)
+    e2 = np.abs(o2[:, ::st] - w2).reshape(-1, 255)
+    return np.concatenate([e1, e2]) if e2.size else e1
+
+
+class _KnnSpy:
+    """Records (features, neighbour lists) of every kNN call of a forward (both entry points)."""
+
+    def __init__(self, monkeypatch):
+        from scp_amd import native
+        self.calls = []
+        k1, k2 = native.knn_topk, native.knn_topk_packed
+
+        def topk(x, k):
+            idx = k1(x, k)
+            self.calls.append((x[0].detach().cpu(), idx[0].cpu().long()))
+            return idx
+
+        def topk_packed(x, ctab, thr0=None):
+            idx = k2(x, ctab, thr0)
+            self.calls.append((x.detach().cpu(), idx.cpu().long()))
+            return idx
+
+        monkeypatch.setattr(native, "knn_topk", topk)
+        monkeypatch.setattr(native, "knn_topk_packed", topk_packed)
+
+
+def _knn_sets_vs_reference(feat, idx, want_sorted, c):
+    """Fraction of points whose neighbour SET equals the reference's; every other point must be a near-tie: all exchanged
+    candidates lie within fp32 rounding of the 20th-best distance (float64 distances of the features the kernel saw)."""
+    got = np.sort(idx[:c].numpy().astype(np.int64), axis=1)
+    want = want_sorted.astype(np.int64)
+    bad = np.where((got != want).any(1))[0]
+    worst = 0.0
+    x = feat[:c].double()
+    sq = (x * x).sum(1)
+    for i in bad:
+        d = sq[i] + sq - 2 * (x @ x[i])                       # float64 squared distances to every candidate
+        kth = torch.sort(d)[0][19]
+        swapped = np.setxor1d(got[i], want[i])
+        scale = float(sq[i] + sq.max())
+        worst = max(worst, float((d[swapped] - kth).abs().max()) / scale)
+    return 1.0 - len(bad) / c, worst
+
+
+TIEFREE = ["tiefree_ehem_c600", "tiefree_ehem_c2049", "tiefree_ehem_c8192"]
+
+
+@pytest.mark.parametrize("path", ["window", "packed"])
+@pytest.mark.parametrize("name", TIEFREE)
+def test_ehem_tiefree_every_row_vs_reference(dev, ehem, monkeypatch, name, path):
+    """The strict pin of a11/a12 against the reference itself (models/ehem.py:88-136, dgcnn.py:10-45): random float positions,
+    so no neighbour distance is exactly tied and EVERY logit row of the reference is a hard target (1e-3, BASELINE.json) on the
+    default arithmetic (f16x3 feature kNN, bf16x3 dense layers and attention) - through the per-window forward and through the
+    packed forward the encoder / decoder use.  The neighbour SETS of the three searches must be the reference's; a point may
+    differ only by candidates within fp32 rounding of its 20th-best distance."""
+    z = golden(name)
+    data, pos = _ehem_case(z)
+    c = data.shape[1]
+    spy = _KnnSpy(monkeypatch)
+    if path == "window":
+        o1, o2 = ehem(data.to(dev), pos.to(dev), enc=True)
+        o1, o2 = o1.cpu().numpy(), o2.cpu().numpy()
+    else:
+        o1, o2 = _run_packed(ehem, data, pos, dev)
+    st, w1, w2 = _want_rows(z)
+    e = _row_err(o1, o2, st, w1, w2)
+    assert len(spy.calls) == 3
+    rec = dict(max_dlogit=e.max(), rows=e.shape[0], rows_within_1e3=(e.max(1) <= LOGIT_TOL).mean())
+    for i, (feat, idx) in enumerate(spy.calls):
+        same, worst = _knn_sets_vs_reference(feat, idx, z[f"knn{i}"], c)
+        rec[f"knn{i}_sets_identical"] = same
+        rec[f"knn{i}_worst_exchange_rel"] = worst
+        # search 0 is the exact fp32 chain on tie-free positions: the reference's sets, all of them
+        assert same == 1.0 if i == 0 else same >= 0.995, (i, same)
+        assert worst <= 4e-6, (i, worst)
+    parity_record(f"{name}/{path}", **rec)
+    print(name, path, rec)
+    assert e.max() <= LOGIT_TOL, rec
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_ehem_*.npz"))))
+def test_ehem_logits_vs_reference_packed_path(dev, ehem, name):
+    """The lattice-position goldens through forward_packed (the kernels the bench / CLI / decoder run: layernorm_rows,
+    gemm_split, mlp_fused, hierarchical concat) with the same two assertions as the per-window test below."""
+    z = golden(name)
+    data, pos = _ehem_case(z)
+    o1, o2 = _run_packed(ehem, data, pos, dev)
+    st, w1, w2 = _want_rows(z)
+    e = _row_err(o1, o2, st, w1, w2)
+    rows_ok = (e.max(1) <= LOGIT_TOL).mean()
+    from oracle import models_ref
+    sd = {k: v.cpu() for k, v in ehem.state_dict().items()}
+    models_ref.KNN_OVERRIDE = gpu_knn_for_oracle(dev)
+    try:
+        with torch.no_grad():
+            r1, r2 = models_ref.ehem_forward(sd, data, pos)
+    finally:
+        models_ref.KNN_OVERRIDE = None
+    d = max(np.abs(o1 - r1.numpy()).max(), np.abs(o2 - r2.numpy()).max() if o2.size else 0.0)
+    parity_record(f"{name}/packed", max_dlogit_vs_reference=e.max(), rows_within_1e3_vs_reference=rows_ok, max_dlogit_vs_oracle_same_knn=d)
+    assert rows_ok >= ROWS_OK_MIN.get(name, 0.97), (e.max(), rows_ok)
+    assert d <= LOGIT_TOL, d
+
+
+# measured fractions of rows within 1e-3 of the reference's golden logits (lattice positions: exact distance ties at the 20th /
+# 21st neighbour are resolved by the reference's top-k implementation) minus a small margin; profiles/parity_r2.json has the values
+ROWS_OK_MIN = {}
+
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_ehem_*.npz"))))
 def test_ehem_logits_vs_reference(dev, ehem, name):
     z = golden(name)
@@ -264,10 +412,11 @@ def test_ehem_logits_vs_reference(dev, ehem, name):
     rows_ok = (e.max(1) <= LOGIT_TOL).mean()
     print(f"{name}: vs reference (its own CPU top-k tie-breaking): max|dlogit| = {e.max():.3e}, "
           f"rows within 1e-3: {100 * rows_ok:.2f}%")
+    parity_record(f"{name}/window", max_dlogit_vs_reference=e.max(), rows_within_1e3_vs_reference=rows_ok)
     # The reference's neighbour choice among EXACTLY tied distances is an artefact of its top-k implementation
     # (std::partial_sort on CPU, radix-select on CUDA); rows whose 20th/21st neighbours tie can differ.  Demand
     # that the bulk of the rows agree with the golden logits ...
-    assert rows_ok >= 0.85, (e.max(), rows_ok)
+    assert rows_ok >= ROWS_OK_MIN.get(name, 0.97), (e.max(), rows_ok)
     # ... and that ALL rows agree to 1e-3 with the CPU oracle once it is given the same neighbour sets.
     from oracle import models_ref
     sd = {k: v.cpu() for k, v in ehem.state_dict().items()}
@@ -279,7 +428,33 @@ def test_ehem_logits_vs_reference(dev, ehem, name):
         models_ref.KNN_OVERRIDE = None
     d = max(np.abs(o1 - r1.numpy()).max(), np.abs(o2 - r2.numpy()).max() if o2.size else 0.0)
     print(f"{name}: vs CPU oracle with identical neighbour sets: max|dlogit| = {d:.3e}")
+    parity_record(f"{name}/window", max_dlogit_vs_oracle_same_knn=d)
     assert d <= LOGIT_TOL, d
+
+
+def test_weights_replaced_after_a_forward_take_effect(dev):
+    """Derived weights (fused q|k|v, conv / BN folds, concat slabs, bf16 planes) are caches keyed on their sources' versions:
+    load_state_dict / in-place updates after a forward must give the logits of a freshly built model - on both paths."""
+    from scp_amd.models import EHEM
+    from scp_amd.weights import fill_weights
+    z = golden("logits_ehem_c600")
+    data, pos = _ehem_case(z)
+    a = fill_weights(EHEM(ehem_cfg()), 0).to(dev)
+    a0 = _run_packed(a, data, pos, dev)
+    w0 = [t.cpu().numpy() for t in a(data.to(dev), pos.to(dev))]
+    b = fill_weights(EHEM(ehem_cfg()), 5).to(dev)
+    want_p = _run_packed(b, data, pos, dev)
+    want_w = [t.cpu().numpy() for t in b(data.to(dev), pos.to(dev))]
+    assert np.abs(want_p[0] - a0[0]).max() > 1e-2                  # the two seeds really differ
+    a.load_state_dict(b.state_dict())
+    got_p = _run_packed(a, data, pos, dev)
+    got_w = [t.cpu().numpy() for t in a(data.to(dev), pos.to(dev))]
+    for g, w in zip(list(got_p) + got_w, list(want_p) + want_w):
+        assert np.array_equal(g, w)
+    fill_weights(a, 0)                                             # in-place copy_ of every tensor
+    back = _run_packed(a, data, pos, dev)
+    assert np.array_equal(back[0], a0[0]) and np.array_equal(back[1], a0[1])
+    assert np.array_equal(a(data.to(dev), pos.to(dev))[0].cpu().numpy(), w0[0])
 
 
 def test_ehem_forward_ctx_equals_reference_signature(dev, ehem):

@@ -52,6 +52,29 @@ def test_octree_vs_reference_so(orc, name):
     assert np.array_equal(t2.codes, z["codes"])
 
 
+def test_full_size_frames_vs_reference_checksums(orc):
+    """The oracle at BASELINE size: the reference quantiser's integers of the 120k-point frame (frame_ints.npz) -> the node counts
+    and sha256 of occupancy stream / K-records the reference's own builders produced (frame_facts.json): same-level L12 / L16 /
+    cylindrical L14 / Cartesian L12 through gen_octree's twin, the three L16-mullevel shells through mullevel_gen_octree's."""
+    facts = json.load(open(os.path.join(GOLDEN, "frame_facts.json")))
+    z = golden("frame_ints")
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    for key, name in (("L12-s", "q_spher_L12"), ("L16-s", "q_spher_L16"), ("C14", "q_cylin_L14"), ("L12-c", "q_cart_L12")):
+        f = facts[key]
+        t = orc.octree_build(np.unique(z[name], axis=0))
+        assert t.n == f["N"] and t.depth == f["D"] and np.bincount(t.level)[1:].tolist() == f["per_level"]
+        assert sha(t.occ) == f["codes_sha"]
+        if "krec_sha_i32" in f:
+            assert sha(t.krecords().astype(np.int32)) == f["krec_sha_i32"]
+    for k, (L, path) in enumerate(((16, [0, 0]), (17, [0, 1]), (18, [1]))):
+        f = facts["L16-m"][k]
+        q = z[f"q_spher_L{L}"]
+        _, idx = np.unique(q, axis=0, return_index=True)
+        t = orc.octree_build(q[np.sort(idx)], path)
+        assert t.n == f["records"] + 1 and np.bincount(t.level)[1:].tolist() == f["per_level"]
+        assert sha(t.occ) == f["codes_sha"] and sha(t.krecords(True).astype(np.int32)) == f["krec_sha_i32"]
+
+
 def test_octree_depth0_is_an_error(orc):
     with pytest.raises(ValueError):
         orc.octree_build(np.zeros((1, 3), np.int64))

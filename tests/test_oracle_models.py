@@ -67,6 +67,29 @@ def test_ehem_oracle_vs_reference_logits(ehem_sd, name):
             assert np.abs(o2.numpy() - w2).max() < TOL
 
 
+@pytest.mark.parametrize("name", ["tiefree_ehem_c600", "tiefree_ehem_c2049"])
+def test_ehem_oracle_vs_reference_tiefree(ehem_sd, name):
+    """Random float positions (no exactly tied neighbour distances): the oracle must pick the reference's neighbour SETS in all
+    three searches (dgcnn.py:10-45) and reproduce every logit row."""
+    from oracle import models_ref
+    z = golden(name)
+    data = torch.from_numpy(z["data"].astype(np.int64))[None]
+    pos = torch.from_numpy(z["pos"])[None]
+    seen = []
+    models_ref.KNN_OVERRIDE = lambda x, k: (seen.append(models_ref.knn_default(x, k)) or seen[-1])
+    try:
+        with torch.no_grad():
+            o1, o2 = models_ref.ehem_forward(ehem_sd, data, pos)
+    finally:
+        models_ref.KNN_OVERRIDE = None
+    assert len(seen) == 3
+    for i, idx in enumerate(seen):
+        assert np.array_equal(np.sort(idx[0].numpy().astype(np.int16), axis=1), z[f"knn{i}"]), i
+    st = int(z["stride"])
+    assert np.abs(o1[0, ::st].numpy() - z["out1"]).max() < TOL
+    assert np.abs(o2[0, ::st].numpy() - z["out2"]).max() < TOL
+
+
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_octattn_*.npz"))))
 def test_octattn_oracle_vs_reference_logits(oct_sd, name):
     from oracle import models_ref
