@@ -618,10 +618,10 @@ __global__ __launch_bounds__(256) void knn_generic_kernel(const float *__restric
 // concurrently on two streams (FrameEncoder lanes); launches of one stream are ordered, so its buffer can be reused call after call
 struct KnnScratch { void *stream; bool used; DevBuf buf; };
 static KnnScratch g_xx_tab[8];
-static DevBuf &knn_scratch(hipStream_t st) {
-    for (auto &e : g_xx_tab) if (e.used && e.stream == (void *)st) return e.buf;
-    for (auto &e : g_xx_tab) if (!e.used) { e.used = true; e.stream = (void *)st; return e.buf; }
-    return g_xx_tab[0].buf;   // more than 8 streams: share the first (callers with that many streams must serialise themselves)
+static DevBuf *knn_scratch(hipStream_t st) {
+    for (auto &e : g_xx_tab) if (e.used && e.stream == (void *)st) return &e.buf;
+    for (auto &e : g_xx_tab) if (!e.used) { e.used = true; e.stream = (void *)st; return &e.buf; }
+    return nullptr;   // a ninth stream: refused (sharing a buffer between unordered streams would be a data race)
 }
 
 static int g_knn_mode = -1;
@@ -636,7 +636,9 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
     const size_t xx_bytes = ((size_t)npts * sizeof(float) + 1023) & ~(size_t)1023;
     const bool split = (C == 144 || C == 192) && knn_mode() == 1;
     const int RB = C * 4;
-    DevBuf &sbuf = knn_scratch(st);
+    DevBuf *sp = knn_scratch(st);
+    if (!sp) return SCP_EINVAL;
+    DevBuf &sbuf = *sp;
     int rc = sbuf.reserve(xx_bytes * (split ? 2 : 1) + (C <= 4 ? (size_t)npts * 16 : (split ? (size_t)npts * RB : 0)));
     if (rc) return rc;
     float *xx = sbuf.as<float>();
@@ -666,7 +668,9 @@ extern "C" int scp_knn_topk(const float *x, int32_t B, int32_t n, int32_t C, int
     const int64_t npts = (int64_t)B * n;
     if (C <= 4 || ((C == 144 || C == 192) && ((uintptr_t)x & 15) == 0))
         return knn_launch(x, npts, C, dim3((n + 127) / 128, B), n, k, idx, nullptr, st);
-    DevBuf &sbuf = knn_scratch(st);
+    DevBuf *sp = knn_scratch(st);
+    if (!sp) return SCP_EINVAL;
+    DevBuf &sbuf = *sp;
     int rc = sbuf.reserve((size_t)npts * sizeof(float));
     if (rc) return rc;
     float *xx = sbuf.as<float>();

@@ -10,12 +10,101 @@ Like the reference decoder, the last BFS node of every multi-level shell is not 
 Phase 1 (ancestors only) runs once per level for all its windows; phase 2 is sequential per window (the bitstream interleaves
 them).  Decoding is not on the metric path.
 """
+import json
+import math
+import os
+
 import numpy as np
 import torch
 
 from . import native
 
 KITTI = "kitti"
+SIDECAR = ".scp.json"
+
+
+def extract_info(binfile):
+    """decode_ehem.py:20-27 / decode_ehem_mullevel.py:20-27: everything the reference's decoders know about a stream - coordinate
+    system from the file name, (levels, bin_num, z_offset) = its last three `_` fields (integers: the encoder wrote
+    `int(z_offset)`), and the per-level (min, max) pairs from `<binfile>.dat` for the polar systems."""
+    name = os.path.basename(binfile)
+    spher, cylin = "spher" in name, "cylin" in name
+    n_levels, bin_num, z_offset = (int(x) for x in name[:-len(".bin")].split("_")[-3:])
+    pos_mm = torch.load(binfile + ".dat").numpy() if (spher or cylin) else np.zeros((0, 2), np.float32)
+    return spher, cylin, pos_mm, n_levels, bin_num, z_offset
+
+
+def write_sidecar(outfile, enc, res, model_name):
+    """`<outfile>.scp.json` - what the reference's two side-info carriers cannot hold (an extension; the `.bin` / `.dat` pair stays
+    exactly the reference's): lidar level and dataset type (the reference decoder takes the level count for the lidar level,
+    decode_ehem.py:218), each shell's own bin_num (the file name has the first shell's only, but every shell de-quantises its
+    angles with its own), the un-truncated z offset, and the numeric profile of the kernels that produced the CDFs."""
+    side = dict(model=model_name, type=enc.data_type, lidar_level=int(enc.lidar_level), mullevel=bool(enc.mullevel),
+                spher=bool(enc.spher), cylin=bool(enc.cylin), n_points=int(res["n_points"]), n_nodes=int(res["n_nodes"]),
+                bin_nums=[float(b) for b in res.get("bin_nums", [res["bin_num"]])],
+                z_offset=float(res["z_offset"]), profile=native.numeric_profile(model_name))
+    with open(outfile + SIDECAR, "w") as f:
+        json.dump(side, f)
+    return side
+
+
+def read_sidecar(binfile):
+    p = binfile + SIDECAR
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        return json.load(f)
+
+
+def shell_qs(data_type, lidar_level, mullevel):
+    f = (lambda l: 400 / (2 ** l - 1)) if data_type == KITTI else (lambda l: 2 ** (18 - l))
+    return [f(lidar_level + k) for k in range(3)] if mullevel else [f(lidar_level)]
+
+
+def dequantise_leaves(leaves, qs, bin_num, z_offset, spher, cylin, data_type=KITTI):
+    """Leaf integers -> Cartesian points, decode_ehem.py:237-253 (`pt_rec * qs + offset`, then spher2cart / cylin2cart,
+    data_preprocess.py:186-229), float64 on the device."""
+    from . import metrics
+    if spher:
+        q, off = [qs, 2 * math.pi / (bin_num - 1), math.pi / (bin_num - 1)], [0.0, 0.0, 0.0]
+    elif cylin:
+        q, off = [qs, 2 * math.pi / (bin_num - 1), qs], [0.0, 0.0, float(z_offset)]
+    else:
+        o = -200.0 if data_type == KITTI else -float(2 ** 17)
+        q, off = [qs, qs, qs], [o, o, o]
+    return metrics.dequantize(leaves, q, off, spher=spher, cylin=cylin)
+
+
+def decode_file(binfile, model, lidar_level=None, data_type=None, mullevel=False, device=None):
+    """A stream file written by the encode CLIs -> dict(codes per shell, leaves per shell, points [U,3] float64 Cartesian).
+    Side information exactly as the reference's decoders take it (`extract_info`); the `.scp.json` written next to the stream
+    supplies what that cannot carry.  Without it the reference's own rules apply: lidar level = the level count (decode_ehem.py:218),
+    integer z offset, and - for the two outer shells - bin numbers extrapolated from the first shell's."""
+    spher, cylin, pos_mm, n_levels, bin_num, z_offset = extract_info(binfile)
+    side = read_sidecar(binfile)
+    if side is not None:
+        prof = native.numeric_profile(side.get("model", "EHEM"))
+        if side["profile"] != prof:
+            raise native.ScpError(f"{binfile}: coded under numeric profile {side['profile']!r}, this process runs {prof!r}: the "
+                                  "integer CDFs would differ and the range decoder would desynchronise")
+        lidar_level = side["lidar_level"] if lidar_level is None else lidar_level
+        data_type = side["type"] if data_type is None else data_type
+        z_offset = side["z_offset"]
+    data_type = data_type or ("ford" if "ford" in binfile else KITTI)                       # decode_ehem.py:241
+    if lidar_level is None:
+        lidar_level = n_levels // 3 - 1 if mullevel else n_levels                            # the reference's rule
+    qs = shell_qs(data_type, lidar_level, mullevel)
+    if side is not None and len(side["bin_nums"]) == len(qs):
+        bins = side["bin_nums"]
+    else:
+        bins = [bin_num] + [round((bin_num - 1) * qs[0] / q) + 1 for q in qs[1:]]
+    dec = FrameDecoder(model, lidar_level, mullevel=mullevel, polar=spher or cylin, device=device)
+    with open(binfile, "rb") as f:
+        stream = f.read()
+    shells = dec.decode(stream, n_levels, pos_mm)
+    pts = [dequantise_leaves(lv, q, b, z_offset, spher, cylin, data_type) for (_, lv), q, b in zip(shells, qs, bins)]
+    return dict(codes=[torch.cat(c) for c, _ in shells], leaves=[lv for _, lv in shells], points=torch.cat(pts),
+                spher=spher, cylin=cylin, n_levels=n_levels, bin_num=bin_num, z_offset=z_offset, lidar_level=lidar_level)
 
 
 class FrameDecoder:

@@ -29,6 +29,22 @@ def init(backend=None):
     return rank, world, local
 
 
+def pin_rank_threads(local, local_world):
+    """Give every rank its own slice of the host cores (launch thread, range-coder worker, file reader): with 8 ranks the host
+    side is the expected limiter, and threads of different ranks migrating over each other's cores is the first
+    thing that hurts.  A rank needs ~3 cores; with fewer than 2 per rank the affinity is left alone.  SCP_PIN=0 disables."""
+    if os.environ.get("SCP_PIN", "1") == "0" or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // local_world
+    if per < 2:
+        return None
+    mine = cpus[local * per:(local + 1) * per]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(per, 4)))
+    return mine
+
+
 def shard(items, rank, world):
     """Round-robin frame sharding: item i belongs to rank i % world."""
     return [(i, it) for i, it in enumerate(items) if i % world == rank]

@@ -124,7 +124,9 @@ class FrameEncoder:
 
     def preprocess(self, xyz_dev):
         qs, bin_num, z_off = self.quantize(xyz_dev)
-        return self.preprocess_ints(qs, bin_num, z_off, xyz_dev.shape[0])
+        pre = self.preprocess_ints(qs, bin_num, z_off, xyz_dev.shape[0])
+        pre["bin_nums"] = [float(i.bin_num) for i in self._infos]      # every shell's own (the file name carries the first)
+        return pre
 
     def preprocess_ints(self, qs, bin_num, z_offset, n_points):
         """qs: per-shell quantised integer clouds (device int32 [P_s,3]) - the entry point for already-quantised input
@@ -309,7 +311,7 @@ class FrameEncoder:
         bits = 8 * len(stream)
         return dict(bytes=stream, bits=bits, bpp=bits / pre["n_points"], n_nodes=plan.n_rows, n_points=pre["n_points"],
                     bin_num=pre["bin_num"], z_offset=pre["z_offset"], n_levels=len(pre["level_sizes"]),
-                    pos_mm=pre["pos_mm"].cpu().numpy(), level_sizes=pre["level_sizes"],
+                    pos_mm=pre["pos_mm"].cpu().numpy(), level_sizes=pre["level_sizes"], bin_nums=pre.get("bin_nums", [float(pre["bin_num"])]),
                     times=dict(total=time.perf_counter() - h["t0"]))
 
     def _encode_pre(self, pre, t0, timing):
@@ -330,7 +332,7 @@ class FrameEncoder:
         bits = 8 * len(stream)
         return dict(bytes=stream, bits=bits, bpp=bits / pre["n_points"], n_nodes=plan.n_rows, n_points=pre["n_points"],
                     bin_num=pre["bin_num"], z_offset=pre["z_offset"], n_levels=len(pre["level_sizes"]),
-                    pos_mm=pre["pos_mm"].cpu().numpy(), level_sizes=pre["level_sizes"],
+                    pos_mm=pre["pos_mm"].cpu().numpy(), level_sizes=pre["level_sizes"], bin_nums=pre.get("bin_nums", [float(pre["bin_num"])]),
                     times=dict(geom=t1 - t0, model=t2 - t1, cdf=t3 - t2, coder=t4 - t3, total=t4 - t0),
                     _debug=dict(table=table, sym_coded=sym_coded, order=order, pre=pre))
 
@@ -344,38 +346,62 @@ class FrameEncoder:
 
 
 class OctAttnFrameEncoder:
-    """OctAttention path (encode.py:23-82 `compress` + dataloaders/encode_dataset.py:32-55): one BFS sequence, front-padded
-    with context_size-1 rows (occ 255), cut into consecutive 1024-windows; node r is predicted at position (r+1023) % 1024
-    of window (r+1023) // 1024.  Plain BFS coding order.  `--cylin` is wired here (the reference forgot to, SURVEY B-7)."""
+    """OctAttention path.  Same-level (encode.py:23-82 `compress` + dataloaders/encode_dataset.py:32-55): one BFS sequence,
+    front-padded with context_size-1 rows (occ 255), cut into consecutive 1024-windows; node r is predicted at position
+    (r+1023) % 1024 of window (r+1023) // 1024.  Plain BFS coding order.  `--cylin` is wired here (the reference forgot to, SURVEY B-7).
 
-    def __init__(self, model, data_type=KITTI, lidar_level=12, spher=True, cylin=False, max_batch=128, device=None):
+    Multi-level / level-wise (encode_mullevel.py:23-86 `compress` + dataloaders/encode_dataset_mullevel.py:27-119): the frame is a
+    LIST of sequences ("chunks") - one per rho shell ([0,0] at qs(L), [0,1] at qs(L+1), [1] at qs(L+2); records without the last
+    BFS node, Octree.py:259-262), and with `level_wise` one per octree level of every shell - each front-padded and windowed on
+    its own, positions divided by 2^(the shell's deepest level); the PMF rows of the chunks are stacked in order
+    (`probabilities[:-1023]`) and coded as one stream.  File name `<base>[_spher]_<chunks>_<bin_num>_0.bin`."""
+
+    def __init__(self, model, data_type=KITTI, lidar_level=12, spher=True, cylin=False, max_batch=128, device=None, mullevel=False,
+                 level_wise=False, named=False):
         self.model = model
         self.data_type = data_type
         self.lidar_level = lidar_level
         self.mode = native.CYLIN if cylin else (native.SPHER if spher else native.CART)
         self.spher, self.cylin = spher and not cylin, cylin
+        self.mullevel = mullevel
+        self.level_wise = level_wise
+        self.named = named or mullevel        # encode_mullevel.py's file-name scheme (also for its single-shell Cartesian input)
+        if mullevel and self.mode != native.SPHER:
+            # encode_dataset_mullevel.py:76-86: the three-shell records exist for --spher only
+            raise native.ScpError("OctAttention multi-level encoding needs --spher (encode_dataset_mullevel.py:76)")
         self.max_batch = max_batch
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.context_size = model.cfg.model.context_size
         self.geom = native.Geom()
         self.cart_offset = -200.0 if data_type == KITTI else -float(2 ** 17)
 
+    def shells(self):
+        L = self.lidar_level
+        return [([0, 0], L), ([0, 1], L + 1), ([1], L + 2)] if self.mullevel else [(None, L)]
+
+    def quantize(self, xyz_dev):
+        qs, bin_num = [], None
+        for path, lv in self.shells():
+            q, qi, _ = native.quantize(xyz_dev, self.mode, level_qs(self.data_type, lv), 0.0 if self.mullevel else self.cart_offset)
+            qs.append(q)
+            bin_num = qi.bin_num if bin_num is None else bin_num
+        return qs, bin_num
+
     def encode(self, xyz, timing=False, sequential=False):
         t0 = time.perf_counter()
         if isinstance(xyz, np.ndarray):
             xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
         xyz_dev = xyz.to(self.device)
-        q, qi, _ = native.quantize(xyz_dev, self.mode, level_qs(self.data_type, self.lidar_level), self.cart_offset)
-        return self.encode_ints(q, qi.bin_num, xyz_dev.shape[0], t0, sequential=sequential)
+        qs, bin_num = self.quantize(xyz_dev)
+        return self.encode_ints(qs, bin_num, xyz_dev.shape[0], t0, sequential=sequential)
 
-    def _sequential_table(self, seq_ctx, seq_pos, N):
+    def _sequential_rows(self, seq_ctx, seq_pos, N, table):
         """`--sequential` (encode.py:38-41,55-56): a window starts at EVERY row of the padded sequence and only the prediction
         of its last position is kept, i.e. node r is predicted from its full 1023-node history (window r .. r + 1023).
         The reference's loop runs past the last full window with shrinking windows that all end at the last node and
         overwrite its row; the last one (that node alone) wins - reproduced.  ~context_size x the model calls of the default
         mode: batches of `max_batch` windows are gathered with a strided view, one forward each."""
         cs = self.context_size
-        table = torch.empty((N, 255), dtype=torch.float32, device=self.device)
         wc = seq_ctx.unfold(0, cs, 1).permute(0, 2, 1)               # [N, cs, 12] view: window i = rows i .. i + cs - 1
         wp = seq_pos.unfold(0, cs, 1).permute(0, 3, 1, 2)            # [N, cs, 4, 3]
         for b0 in range(0, N, self.max_batch):
@@ -384,51 +410,93 @@ class OctAttnFrameEncoder:
             table[b0:b1] = out[:, -1]
         if cs > 1:
             table[N - 1] = self.model(seq_ctx[-1:].reshape(1, 1, 4, 3), seq_pos[-1:].reshape(1, 1, 4, 3))[0, -1]
-        return table
 
-    def _front(self, q):
-        """stage G + the front-padded context sequence (encode_dataset.py:32-55) on the current stream"""
-        self.geom.build(q.contiguous(), [(0, q.shape[0], None, False)])
-        ctx, pos, sym = self.geom.context_octattn(0)
+    def _front(self, qs):
+        """stage G + the front-padded context sequences (encode_dataset.py:32-55 / encode_dataset_mullevel.py:44-73) on the
+        current stream.  qs: one integer cloud, or the list of per-shell clouds.  -> (chunks [(seq_ctx, seq_pos, n)], sym, N)."""
+        if not isinstance(qs, (list, tuple)):
+            qs = [qs]
+        if len(qs) != len(self.shells()):
+            raise native.ScpError(f"expected {len(self.shells())} integer cloud(s), got {len(qs)}")
+        segs, off = [], 0
+        for (path, _), qq in zip(self.shells(), qs):
+            segs.append((off, qq.shape[0], path, self.mullevel))
+            off += qq.shape[0]
+        self.geom.build((torch.cat(qs) if len(qs) > 1 else qs[0]).contiguous(), segs)
         cs = self.context_size
         pad_ctx = torch.zeros((cs - 1, 12), dtype=torch.uint8, device=self.device)
         pad_ctx[:, 0::3] = 255
-        seq_ctx = torch.cat((pad_ctx, ctx))
-        seq_pos = torch.cat((torch.zeros((cs - 1, 4, 3), dtype=torch.float32, device=self.device), pos))
-        return seq_ctx, seq_pos, sym, ctx.shape[0]
+        pad_pos = torch.zeros((cs - 1, 4, 3), dtype=torch.float32, device=self.device)
+        chunks, syms = [], []
+        for s in range(len(segs)):
+            ctx, pos, sym = self.geom.context_octattn(s)
+            counts = self.geom.level_counts(s)
+            if self.mullevel:
+                counts[-1] -= 1                      # the records drop the last BFS node (Octree.py:259-262)
+                if counts[-1] == 0:                  # ... and with it the deepest level: positions are over 2^(max level present)
+                    counts.pop()
+                    pos = pos * 2.0
+            syms.append(sym)
+            cuts = counts if self.level_wise else [ctx.shape[0]]
+            a = 0
+            for n in cuts:
+                chunks.append((torch.cat((pad_ctx, ctx[a:a + n])), torch.cat((pad_pos, pos[a:a + n])), n))
+                a += n
+        sym = torch.cat(syms) if len(syms) > 1 else syms[0]
+        return chunks, sym, int(sym.shape[0])
+
+    def _chunk_rows(self, chunks, table):
+        """Default mode: consecutive windows of context_size over every padded chunk; all FULL windows of the frame (whatever chunk
+        they belong to) share batched forwards, each chunk's shorter tail window runs on its own."""
+        cs = self.context_size
+        full_c, full_p, dst = [], [], []       # full windows + (table row of the window's first real node, leading pad rows)
+        row = 0
+        for seq_ctx, seq_pos, n in chunks:
+            total = n + cs - 1
+            n_full = total // cs
+            for w in range(n_full):
+                full_c.append(seq_ctx[w * cs:(w + 1) * cs])
+                full_p.append(seq_pos[w * cs:(w + 1) * cs])
+                lo = max(w * cs - (cs - 1), 0)
+                dst.append((row + lo, lo + (cs - 1) - w * cs))
+            if total % cs:
+                out = self.model(seq_ctx[n_full * cs:].reshape(1, -1, 4, 3), seq_pos[n_full * cs:].reshape(1, -1, 4, 3))[0]
+                lo = n_full * cs - (cs - 1)
+                table[row + max(lo, 0):row + n] = out[max(-lo, 0):]
+            row += n
+        for b0 in range(0, len(dst), self.max_batch):
+            b1 = min(len(dst), b0 + self.max_batch)
+            if len(chunks) == 1:               # one sequence: its full windows are one contiguous block (no copy)
+                d = chunks[0][0][b0 * cs:b1 * cs].reshape(b1 - b0, cs, 4, 3)
+                p = chunks[0][1][b0 * cs:b1 * cs].reshape(b1 - b0, cs, 4, 3)
+            else:
+                d = torch.stack(full_c[b0:b1]).reshape(b1 - b0, cs, 4, 3)
+                p = torch.stack(full_p[b0:b1])
+            out = self.model(d, p)
+            for i, (r0, skip) in enumerate(dst[b0:b1]):
+                table[r0:r0 + cs - skip] = out[i, skip:]
 
     def encode_ints(self, q, bin_num, n_points, t0=None, sequential=False, defer=False, front=None):
+        """q: integer cloud (numpy / tensor int32 [P,3]) or the list of per-shell clouds of the multi-level form."""
         t0 = t0 or time.perf_counter()
-        if isinstance(q, np.ndarray):
-            q = torch.from_numpy(np.ascontiguousarray(q, np.int32))
-        q = q.to(self.device)
-        front = self._front(q) if front is None else front
-        seq_ctx, seq_pos, sym, N = front
-        cs = self.context_size
-        total = N + cs - 1
+        if front is None:
+            qs = q if isinstance(q, (list, tuple)) else [q]
+            qs = [(torch.from_numpy(np.ascontiguousarray(x, np.int32)) if isinstance(x, np.ndarray) else x).to(self.device) for x in qs]
+            front = self._front(qs)
+        chunks, sym, N = front
         table = torch.empty((N, 255), dtype=torch.float32, device=self.device)
-        n_full = total // cs
         if sequential:
-            table = self._sequential_table(seq_ctx, seq_pos, N)
-            n_full = 0
-        for b0 in range(0, n_full, self.max_batch):
-            b1 = min(n_full, b0 + self.max_batch)
-            d = seq_ctx[b0 * cs:b1 * cs].reshape(b1 - b0, cs, 4, 3)
-            p = seq_pos[b0 * cs:b1 * cs].reshape(b1 - b0, cs, 4, 3)
-            out = self.model(d, p).reshape(-1, 255)
-            lo = max(b0 * cs - (cs - 1), 0)                     # first real node covered by this batch
-            skip = lo + (cs - 1) - b0 * cs                      # pad rows at the head of the first window
-            table[lo:b1 * cs - (cs - 1)] = out[skip:]
-        if total % cs and not sequential:
-            d = seq_ctx[n_full * cs:].reshape(1, -1, 4, 3)
-            p = seq_pos[n_full * cs:].reshape(1, -1, 4, 3)
-            out = self.model(d, p)[0]
-            lo = n_full * cs - (cs - 1)
-            table[max(lo, 0):] = out[max(-lo, 0):]
+            row = 0
+            for seq_ctx, seq_pos, n in chunks:
+                self._sequential_rows(seq_ctx, seq_pos, n, table[row:row + n])
+                row += n
+        else:
+            self._chunk_rows(chunks, table)
         lohi = native.softmax_cdf(table, sym)["lohi"]
-        meta = dict(n_nodes=N, n_points=n_points, bin_num=bin_num, z_offset=0.0, n_levels=1, pos_mm=np.zeros((0, 2)), level_sizes=[N])
+        meta = dict(n_nodes=N, n_points=n_points, bin_num=bin_num, z_offset=0.0, n_levels=len(chunks), pos_mm=np.zeros((0, 2)),
+                    level_sizes=[c[2] for c in chunks])
         if defer:
-            return lohi, meta, (table, sym, seq_ctx, seq_pos)
+            return lohi, meta, (table, sym, chunks)
         stream = native.ac_encode_lohi(lohi.cpu().numpy())
         bits = 8 * len(stream)
         return dict(bytes=stream, bits=bits, bpp=bits / n_points, times=dict(total=time.perf_counter() - t0),
@@ -462,13 +530,13 @@ class OctAttnFrameEncoder:
         with torch.cuda.stream(self._front_stream):
             self._front_stream.wait_stream(caller)
             xyz_dev = xyz.to(self.device, non_blocking=True)
-            q, qi, _ = native.quantize(xyz_dev, self.mode, level_qs(self.data_type, self.lidar_level), self.cart_offset)
+            q, bin_num = self.quantize(xyz_dev)
             front = self._front(q)
             ready = torch.cuda.Event()
             ready.record()
         main.wait_event(ready)
         with torch.cuda.stream(main):
-            lohi, meta, keep = self.encode_ints(q, qi.bin_num, xyz_dev.shape[0], t0, defer=True, front=front)
+            lohi, meta, keep = self.encode_ints(q, bin_num, xyz_dev.shape[0], t0, defer=True, front=front)
             done = torch.cuda.Event()
             done.record()
             if native.CACHE_FILLS != fills0:
@@ -493,4 +561,11 @@ class OctAttnFrameEncoder:
         return dict(bytes=stream, bits=bits, bpp=bits / h["meta"]["n_points"], times=dict(total=time.perf_counter() - h["t0"]), **h["meta"])
 
     def outfile(self, base, res):
-        return base + ".bin"
+        """encode.py:24 (`<base>.bin`) / encode_mullevel.py:68-72 (`<base>[_spher|_cylin]_<chunks>_<bin_num>_0.bin`)."""
+        if not self.named:
+            return base + ".bin"
+        if self.spher:
+            base += "_spher"
+        elif self.cylin:
+            base += "_cylin"
+        return base + "_" + str(res["n_levels"]) + "_" + str(int(res["bin_num"])) + "_0.bin"

@@ -361,9 +361,25 @@ def edge_gather_max_rows(u, v, idx, scale, shift):
     return out
 
 
+_MODES = {"knn": "f32" if os.environ.get("SCP_KNN", "")[:1] == "f" else "f16x3",
+          "attn": "f32" if os.environ.get("SCP_ATTN", "")[:1] == "f" else "bf16x3"}
+
+
 def set_knn_mode(f16x3):
     """True (default): f16x3 distances for the 144-/192-feature searches; False: exact fp32 MFMA chain."""
     _check(lib().scp_set_knn_mode(1 if f16x3 else 0), "scp_set_knn_mode")
+    _MODES["knn"] = "f16x3" if f16x3 else "f32"
+
+
+def numeric_profile(model_name):
+    """The arithmetic variants that decide the logits' last bits - hence the integer CDFs a decoder must reproduce.  The encoder
+    writes this string into its side-info file and the decoder refuses a stream coded under another profile (the alternates are
+    test / benchmark brackets: SCP_GEMM, SCP_KNN, SCP_ATTN, SCP_CONCAT, SCP_OCTATTN; SCP_MLP=split is bit-identical)."""
+    from . import ops
+    from .models import packed
+    if model_name == "OctAttention":
+        return f"octattn/1:gemm={ops.MODE},attn={OCTATTN_MODE}"
+    return f"ehem/1:gemm={ops.MODE},knn={_MODES['knn']},attn={_MODES['attn']},concat={'hier' if packed.HIER else 'direct'}"
 
 
 def edge_gather_max(u, v, idx, scale, shift, out=None):
@@ -384,6 +400,7 @@ def edge_gather_max(u, v, idx, scale, shift, out=None):
 def set_attention_mode(bf16x3=True):
     """True (default): QK^T / PV as bf16x3 splits on bf16 MFMA; False: plain fp32 MFMA."""
     _check(lib().scp_set_attention_mode(1 if bf16x3 else 0), "scp_set_attention_mode")
+    _MODES["attn"] = "bf16x3" if bf16x3 else "f32"
 
 
 def swin_attention(q, k, v, bias_table, shift):

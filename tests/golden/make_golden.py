@@ -525,9 +525,9 @@ def gen_ac():
 
 
 # ----------------------------------------------------------------------------- end-to-end (reference driver)
-def gen_e2e():
-    """Run the reference's own compress_ehem / compress drivers on CPU (Tensor.cuda patched to identity)."""
-    print("[e2e]")
+def _e2e_setup():
+    """The reference's drivers importable and runnable on CPU: hydra stubbed, Tensor.cuda patched to identity, the range coder's
+    `encode` wrapped so the PMF table and symbol vector it receives are captured."""
     import types
     hy = types.ModuleType("hydra")
     hy.initialize = lambda **k: None
@@ -541,8 +541,6 @@ def gen_e2e():
     import importlib
     enc = importlib.import_module("encode")
     encm = importlib.import_module("encode_mullevel")
-    from torch.utils.data import DataLoader
-
     captured = {}
     orig_encode = NA.arithmeticCoding.encode
 
@@ -552,6 +550,70 @@ def gen_e2e():
         return orig_encode(self, pdf, sym, binfile)
 
     NA.arithmeticCoding.encode = spy
+
+    def restore():
+        NA.arithmeticCoding.encode = orig_encode
+    return enc, encm, captured, restore
+
+
+def gen_e2e_octattn_mul():
+    """encode_mullevel.py:23-86 `compress` (OctAttention over the three rho shells) fed by dataloaders/encode_dataset_mullevel.py
+    `get_data` (:44-73), without and with --level_wise.  The dataset's own `preproc` cannot run (it unpacks the 3-value
+    `_meta.npy` of the multi-level test-set generator into 2 names, :80), so the batch is put together from `get_data` the way
+    `__getitem__` (:27-42) + the DataLoader's collate do."""
+    print("[e2e_octattn_mul]")
+    enc, encm, captured, restore = _e2e_setup()
+    from dataloaders.encode_dataset_mullevel import EncodeDataset as MulDS
+    xyz = frame5k(0)
+    mo = build_ref_octattn(0)
+    L = 12
+    with tempfile.TemporaryDirectory() as tmp:
+        binf = os.path.join(tmp, "seq", "f0.bin")
+        os.makedirs(os.path.dirname(binf))
+        write_kitti_bin(binf, xyz)
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            outs3 = [RDP.mul_proc_pc(binf, os.path.join(tmp, "ppm"), "f0", qs=400 / (2 ** (L + k) - 1), test=True, spher=True, morton_path=path)
+                     for k, path in enumerate(([0, 0], [0, 1], [1]))]
+            bin_num = int(outs3[0][3])
+            for lw in (False, True):
+                ds = MulDS([binf], 1024, "kitti", lw, L, True, os.path.join(tmp, "ppm") + "/")
+                ids, pos, data, oct_seq = ds.get_data(outs3[0][0])
+                for o in outs3[1:]:
+                    i2, p2, d2, s2 = ds.get_data(o[0])
+                    ids += i2; pos += p2; data += d2
+                    oct_seq = np.vstack((oct_seq, s2))
+                batch = ([torch.from_numpy(a)[None] for a in ids], [torch.from_numpy(a)[None] for a in pos],
+                         [torch.from_numpy(a)[None] for a in data], torch.from_numpy(oct_seq)[None], torch.tensor([len(xyz)]),
+                         torch.tensor([bin_num]))
+
+                class A:
+                    spher = True
+                    cylin = False
+                    sequential = False
+
+                tag = "lw_" if lw else ""
+                odir = os.path.join(tmp, "out" + tag)
+                bpp, _ = encm.compress(batch, os.path.join(odir, "f0"), mo, A)
+                outs = [f for f in os.listdir(odir) if f.endswith(".bin")]
+                assert len(outs) == 1
+                bs = open(os.path.join(odir, outs[0]), "rb").read()
+                pdf = captured["pdf"]
+                save(f"e2e_octattn_mul_{tag}spher_L{L}", xyz=xyz, fname=np.array(outs[0]), bytes=np.frombuffer(bs, np.uint8),
+                     sym_coded=captured["sym"], pdf_sub=pdf[::37], pdf_stride=np.int32(37), bpp=np.float64(bpp), n_nodes=np.int64(len(pdf)),
+                     chunk_sizes=np.array([d.shape[0] - 1023 for d in data], np.int64), cdf_sha=np.array(sha(ref_cdf_int(pdf))), wseed=np.int32(0))
+                print("   octattn mullevel", "level-wise" if lw else "per shell", "bpp", bpp, "bytes", len(bs), outs[0])
+        finally:
+            os.chdir(cwd)
+            restore()
+
+
+def gen_e2e():
+    """Run the reference's own compress_ehem / compress drivers on CPU (Tensor.cuda patched to identity)."""
+    print("[e2e]")
+    enc, encm, captured, restore = _e2e_setup()
+    from torch.utils.data import DataLoader
 
     class A:
         spher = True
@@ -622,7 +684,7 @@ def gen_e2e():
             print("   octattn bpp", bpp, "bytes", len(bs))
         finally:
             os.chdir(cwd)
-            NA.arithmeticCoding.encode = orig_encode
+            restore()
 
 
 # ----------------------------------------------------------------------------- full-frame facts
@@ -688,7 +750,7 @@ def gen_frame_ints():
         assert np.array_equal(q, q.astype(np.int32))
         if key is not None:
             assert sha(np.unique(q, axis=0).astype(np.int32)) == facts[key]["pts_sha"] and bin_num == facts[key]["bin_num"]
-        out[f"q_{mode}_L{L}"] = q.astype(np.int32)
+        out[f"q_{mode}_L{L}"] = np.ascontiguousarray(q.astype(np.int32))
     save("frame_ints", **out)
 
 
@@ -774,7 +836,7 @@ def gen_trainset():
 
 
 GROUPS = {"trainset": gen_trainset, "metrics": gen_metrics, "keys": gen_keys, "xform": gen_xform, "oct": gen_oct, "ctx": gen_ctx, "logits": gen_logits, "logits_tiefree": gen_logits_tiefree, "swin": gen_swin,
-          "cdf": gen_cdf, "ac": gen_ac, "e2e": gen_e2e, "facts": gen_facts, "frame_ints": gen_frame_ints}
+          "cdf": gen_cdf, "ac": gen_ac, "e2e": gen_e2e, "e2e_octattn_mul": gen_e2e_octattn_mul, "facts": gen_facts, "frame_ints": gen_frame_ints}
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

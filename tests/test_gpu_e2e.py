@@ -165,6 +165,48 @@ def test_octattn_frame_vs_reference_driver(orc):
     assert orc.ac_encode(cdf, sym.astype(np.int16)) == res["bytes"]
 
 
+@pytest.mark.parametrize("lw", [False, True])
+def test_octattn_mullevel_frame_vs_reference_driver(orc, lw):
+    """encode_mullevel.py:23-86 `compress` over dataloaders/encode_dataset_mullevel.py:27-73 (three rho shells; --level_wise: one
+    padded sequence per octree level): chunk sizes, coded symbols and file name equal the reference driver's, PMF rows within
+    1e-4, bytes reproduced by the oracle coder from this library's CDF integers."""
+    from cfgs import octattn_cfg
+    from conftest import parity_record
+    from scp_amd import native
+    from scp_amd.encoder import OctAttnFrameEncoder
+    from scp_amd.models import OctAttention
+    from scp_amd.weights import fill_weights
+    dev = torch.device("cuda:0")
+    model = fill_weights(OctAttention(octattn_cfg()), 0).to(dev)
+    z = golden("e2e_octattn_mul_lw_spher_L12" if lw else "e2e_octattn_mul_spher_L12")
+    ints, bin0 = [], None
+    for k in range(3):
+        _, bin_num, _, _, pt = orc.quantise(z["xyz"], 400 / (2 ** (12 + k) - 1), "spher")
+        bin0 = bin_num if bin0 is None else bin0
+        ints.append(np.ascontiguousarray(pt, np.int32))
+    enc = OctAttnFrameEncoder(model, "kitti", 12, spher=True, device=dev, mullevel=True, level_wise=lw)
+    res = enc.encode_ints(ints, bin0, len(z["xyz"]))
+    assert res["n_nodes"] == int(z["n_nodes"]) and res["level_sizes"] == z["chunk_sizes"].tolist()
+    assert enc.outfile("f0", res) == str(z["fname"])
+    sym = res["_debug"]["sym_coded"].cpu().numpy()
+    assert np.array_equal(sym.astype(np.int16), z["sym_coded"])
+    pmf = native.softmax_cdf(res["_debug"]["table"], want_pmf=True, want_lohi=False)["pmf"].cpu().numpy()[::int(z["pdf_stride"])]
+    ref_bits = 8 * len(z["bytes"])
+    parity_record("e2e/octattn_mul_" + ("lw_" if lw else "") + str(z["fname"]), max_dpmf=np.abs(pmf - z["pdf_sub"]).max(), bits=res["bits"],
+                  reference_bits=ref_bits)
+    assert np.abs(pmf - z["pdf_sub"]).max() < 1e-4
+    assert abs(res["bits"] - ref_bits) <= 0.002 * ref_bits
+    cdf = native.softmax_cdf(res["_debug"]["table"], want_lohi=False, want_cdf=True)["cdf"].cpu().numpy().view(np.uint16)
+    assert orc.ac_encode(cdf, sym.astype(np.int16)) == res["bytes"]
+    # the pipelined entry point produces the same stream; so does the whole path from the float frame on this frame
+    assert enc.finish(enc.encode_async(z["xyz"]))["bytes"] == enc.encode(z["xyz"])["bytes"]
+    # sequential mode runs per chunk as well (one window per node): same symbols, different context -> another valid stream
+    if lw:
+        small = OctAttnFrameEncoder(model, "kitti", 12, spher=True, device=dev, mullevel=True, level_wise=True, max_batch=64)
+        r2 = small.encode_ints([q[:300] for q in ints], bin0, 300, sequential=True)
+        assert r2["n_nodes"] == sum(r2["level_sizes"]) and r2["bits"] > 0
+
+
 def test_octattn_async_pipeline_equals_sync():
     """OctAttnFrameEncoder.encode_async / finish (range coder on a worker thread) give the bytes of encode(), frames in flight."""
     from cfgs import octattn_cfg
@@ -215,6 +257,102 @@ def test_cli_encode_mullevel_writes_reference_named_files(tmp_path):
     bins = sorted(p.name for p in out.iterdir() if p.name.endswith(".bin"))
     assert len(bins) == 2 and bins[0].startswith("seq07000000_spher_") and (out / (bins[0] + ".dat")).exists()
     assert (tmp_path / "test_results_mul_kitti_12.txt").exists()
+
+
+def _run_cli(script, args, cwd):
+    import subprocess, sys, os
+    from conftest import ROOT
+    return subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, capture_output=True, text=True, cwd=str(cwd), timeout=900)
+
+
+def test_cli_refuses_what_the_reference_cannot_run(tmp_path):
+    """Accepted-but-broken flag combinations of the reference fail loudly here instead of encoding something else."""
+    from scp_amd.synth import synth_frame, write_kitti_bin
+    f = str(tmp_path / "a.bin")
+    write_kitti_bin(f, synth_frame(0)[::200])
+    base = ["--test_files", f, "--type", "kitti", "--lidar_level", "10", "--random_weights", "0", "--out_dir", str(tmp_path / "o")]
+    for script, extra, msg in (("encode.py", ["--spher", "--spher_circle"], "spher_circle"),
+                               ("encode.py", ["--spher", "--model", "OctAttention", "--level_wise"], "level_wise"),
+                               ("encode.py", ["--spher", "--sequential"], "sequential"),
+                               ("encode_mullevel.py", ["--type", "obj", "--spher"], "obj")):
+        r = _run_cli(script, base + extra, tmp_path)
+        assert r.returncode != 0 and "ScpError" in r.stderr and msg in r.stderr, (script, extra, r.stderr[-500:])
+
+
+def test_cli_obj_and_octattn_mullevel(tmp_path, orc):
+    """`--type obj` (qs 1, per-axis minimum offset, data_preprocess.py:13-70) and encode_mullevel.py with OctAttention."""
+    from scp_amd.data_preproc.pt import write_ply_data
+    from scp_amd.synth import synth_frame, write_kitti_bin
+    rng = np.random.default_rng(5)
+    pts = np.unique(rng.integers(0, 64, size=(3000, 3)), axis=0).astype(np.float32) + np.float32(7.0)
+    ply = str(tmp_path / "thing_vox6.ply")
+    write_ply_data(ply, pts)
+    r = _run_cli("encode.py", ["--test_files", ply, "--model", "OctAttention", "--random_weights", "0", "--out_dir", str(tmp_path / "o1")], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    t = orc.octree_build(np.unique((pts - pts.min(0)).astype(np.int64), axis=0))
+    assert f"oct num                     : {t.n}" in r.stdout and (tmp_path / "o1" / "thing_vox6.bin").exists()
+    f = str(tmp_path / "s1" / "000003.bin")
+    os.makedirs(os.path.dirname(f))
+    write_kitti_bin(f, synth_frame(2)[::50])
+    for lw in ([], ["--level_wise"]):
+        out = tmp_path / ("o2" + "".join(lw))
+        r = _run_cli("encode_mullevel.py", ["--test_files", f, "--type", "kitti", "--lidar_level", "12", "--spher", "--model", "OctAttention",
+                                            "--random_weights", "0", "--out_dir", str(out)] + lw, tmp_path)
+        assert r.returncode == 0, r.stderr[-2000:]
+        bins = [p.name for p in out.iterdir() if p.name.endswith(".bin")]
+        assert len(bins) == 1 and bins[0].startswith("000003_spher_") and bins[0].endswith("_0.bin")
+        assert (int(bins[0].split("_")[2]) == 3) == (not lw)
+
+
+@pytest.mark.parametrize("mullevel,mode", [(False, "spher"), (True, "spher"), (False, "cylin"), (False, "cart")])
+def test_cli_encode_then_decode_files(tmp_path, orc, mullevel, mode):
+    """f1 through the FILES: encode CLI -> `.bin` + `.dat` (+ `.scp.json`) -> decode CLI (side info parsed like
+    decode_ehem.py:20-27) -> occupancy codes checked against the --preproc_path records, leaf sets equal the oracle's DeOctree of
+    the oracle's code lists for the same integers, and the written cloud equals the oracle's de-quantised cloud (spher2cart /
+    cylin2cart, data_preprocess.py:186-229)."""
+    from scp_amd import native
+    from scp_amd.cli import decode_main
+    from scp_amd.data_preproc.data_preprocess import write_testset
+    from scp_amd.data_preproc.pt import ptread
+    from scp_amd.synth import synth_frame, write_kitti_bin
+    L = 12
+    seq = tmp_path / "seq05"
+    seq.mkdir()
+    xyz = synth_frame(7)[::40].copy()
+    f = str(seq / "000002.bin")
+    write_kitti_bin(f, xyz)
+    out = tmp_path / "out"
+    flags = {"spher": ["--spher"], "cylin": ["--cylin"], "cart": []}[mode]
+    enc_script, dec_script = ("encode_mullevel.py", "decode_ehem_mullevel.py") if mullevel else ("encode.py", "decode_ehem.py")
+    r = _run_cli(enc_script, ["--test_files", f, "--type", "kitti", "--lidar_level", str(L), "--random_weights", "0", "--out_dir", str(out)] + flags,
+                 tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # the records the reference's decoder wants for its assert (decode_ehem.py:184): written by the test-set generator
+    pp = tmp_path / "pp"
+    write_testset(f, str(pp), "kitti", L, spher=mode == "spher", cylin=mode == "cylin", mullevel=mullevel, chamfer=False)
+    r = _run_cli(dec_script, ["--test_files", f, "--random_weights", "0", "--out_dir", str(out), "--preproc_path", str(pp)], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "checked against" in r.stdout and "decode succeeded" in r.stdout
+    got = ptread(str(out / "000002.ply"))
+    # oracle: same device integers -> octree -> code list -> DeOctree -> de-quantise
+    dev = torch.device("cuda:0")
+    want = []
+    md = {"spher": native.SPHER, "cylin": native.CYLIN, "cart": native.CART}[mode]
+    for k, path in enumerate(([0, 0], [0, 1], [1]) if mullevel else (None,)):
+        q, info, _ = native.quantize(torch.from_numpy(xyz).to(dev), md, 400 / (2 ** (L + k) - 1), 0.0 if mullevel else -200.0)
+        qn = q.cpu().numpy().astype(np.int64)
+        _, idx = np.unique(qn, axis=0, return_index=True)
+        t = orc.octree_build(qn[np.sort(idx)], path)
+        dq = orc.deoctree(t.codes)
+        if mullevel:                       # the last BFS node is not coded (Octree.py:259-262): the leaves below it are lost
+            dq = dq[:-bin(int(t.codes[-1])).count("1")]
+        p = dq * np.array(list(info.qs))[None] + np.array(list(info.offset))[None]
+        want.append(orc.spher2cart(p) if mode == "spher" else orc.cylin2cart(p) if mode == "cylin" else p)
+    want = np.vstack(want)
+    assert got.shape == want.shape
+    a, b = torch.from_numpy(got.astype(np.float64)).to(dev), torch.from_numpy(want).to(dev)
+    # same point SET (the reader returns float32): nearest-neighbour distance both ways far below the quantisation step
+    assert native.nn_sqdist(a, b).max().item() ** 0.5 < 2e-5 and native.nn_sqdist(b, a).max().item() ** 0.5 < 2e-5
 
 
 @pytest.mark.parametrize("mullevel,level", [(False, 12), (True, 12)])

@@ -173,7 +173,7 @@ def test_full_frame_checksums(dev):
         f = facts[key]
         q_dev, info, _ = native.quantize(xyz, mode, 400 / (2 ** L - 1), -200.0)
         assert info.bin_num == f["bin_num"]
-        q_ref = ints[name]
+        q_ref = np.ascontiguousarray(ints[name])
         ndiff = int((q_dev.cpu().numpy() != q_ref).any(1).sum())
         parity_record(f"quantiser/{key}", points=n, points_differing_from_reference_ints=ndiff)
         assert ndiff <= max_diff_pts[key], (key, ndiff)
@@ -190,7 +190,7 @@ def test_full_frame_checksums(dev):
     for k in range(3):
         q_dev, info, _ = native.quantize(xyz, native.SPHER, 400 / (2 ** (16 + k) - 1), 0.0)
         assert info.bin_num == shells[k]["bin_num"]
-        q_ref = ints[f"q_spher_L{16 + k}"]
+        q_ref = np.ascontiguousarray(ints[f"q_spher_L{16 + k}"])
         ndiff = int((q_dev.cpu().numpy() != q_ref).any(1).sum())
         parity_record(f"quantiser/L16-m shell {k}", points=n, points_differing_from_reference_ints=ndiff)
         assert ndiff <= max_diff_pts[("L16-s", "L17", "L18")[k]], (k, ndiff)

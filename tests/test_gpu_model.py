@@ -310,8 +310,9 @@ class _KnnSpy:
 def _knn_sets_vs_reference(feat, idx, want_sorted, c):
     """Fraction of points whose neighbour SET equals the reference's; every other point must be a near-tie: all exchanged
     candidates lie within fp32 rounding of the 20th-best distance (float64 distances of the features the kernel saw)."""
-    got = np.sort(idx[:c].numpy().astype(np.int64), axis=1)
     want = want_sorted.astype(np.int64)
+    c = want.shape[0]                 # odd windows: the reference searched the padded window (pad token at position 0, ehem.py:92-99)
+    got = np.sort(idx[:c].numpy().astype(np.int64), axis=1)
     bad = np.where((got != want).any(1))[0]
     worst = 0.0
     x = feat[:c].double()

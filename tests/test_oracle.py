@@ -134,6 +134,36 @@ def test_ehem_context_mullevel(orc):
     assert np.allclose(q, z["quant_pc"], atol=1e-4)
 
 
+@pytest.mark.parametrize("lw", [False, True])
+def test_octattn_mullevel_context_vs_reference_driver(orc, lw):
+    """encode_dataset_mullevel.py:27-73 + encode_mullevel.py:23-86 restated: chunk sizes, coded symbols, file name and (first two
+    chunks, through the oracle model) PMF rows of the reference driver's run (e2e_octattn_mul_*)."""
+    import torch
+    from cfgs import octattn_cfg
+    from oracle import models_ref
+    from scp_amd.models import OctAttention
+    from scp_amd.weights import fill_weights
+    z = golden("e2e_octattn_mul_lw_spher_L12" if lw else "e2e_octattn_mul_spher_L12")
+    shells = orc.mullevel_shells(z["xyz"], 12, "spher")
+    ids, pos, data, seq = orc.octattn_mullevel_context([s["records"] for s in shells], 1024, lw)
+    assert [len(d) - 1023 for d in data] == z["chunk_sizes"].tolist()
+    assert np.array_equal(seq[:, -1, 0].astype(np.int16), z["sym_coded"])
+    assert orc.octattn_outfile_mullevel("f0", len(data), shells[0]["bin_num"], True, False) == str(z["fname"])
+    sd = fill_weights(OctAttention(octattn_cfg()), 0).state_dict()
+    rows, row0 = [], 0
+    for d, p in list(zip(data, pos))[:2]:
+        tab = np.zeros((len(d), 255), np.float32)
+        with torch.no_grad():
+            for i in range(0, len(d), 1024):
+                o = models_ref.octattn_forward(sd, torch.from_numpy(d[i:i + 1024])[None], torch.from_numpy(p[i:i + 1024])[None])
+                tab[i:i + 1024] = torch.softmax(o[0], 1).numpy()
+        rows.append(tab[1023:])
+    pmf = np.vstack(rows)
+    st = int(z["pdf_stride"])
+    k = len(pmf[::st])
+    assert np.abs(pmf[::st] - z["pdf_sub"][:k]).max() < 1e-5
+
+
 def test_octattn_context(orc):
     z = golden("ctx_octattn_spher_L12")
     r = orc.proc_pc(z["xyz"], 400 / (2 ** 12 - 1), "spher")
