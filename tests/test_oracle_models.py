@@ -132,3 +132,15 @@ def test_patch_merge_oracle_vs_reference(L):
     with torch.no_grad():
         y = models_ref.patch_merge(sd, "m", torch.from_numpy(x), L)
     assert np.abs(y[0].numpy() - z["y"]).max() < TOL
+
+
+@pytest.mark.parametrize("name,level,mul", [("e2e_ehem_spher_L12", 12, False), ("e2e_ehem_mul_spher_L14", 14, True)])
+def test_cpu_encode_path_vs_reference_driver(ehem_sd, name, level, mul):
+    """oracle/cpu_encode.py (the CPU baseline bench.py times) is the reference's encode flow: same node count and a stream of the
+    reference driver's length (compress_ehem, encode.py:85-160 / encode_mullevel.py:88-154) on the e2e fixtures' frame."""
+    from oracle import cpu_encode
+    z = golden(name)
+    r = cpu_encode.encode_frame(z["xyz"], ehem_sd, level, mullevel=mul, mode="spher")
+    assert r["n_nodes"] == int(z["n_nodes"]) and r["rows_coded"] == r["n_nodes"]
+    assert abs(r["bits"] - 8 * len(z["bytes"])) <= 16
+    assert set(r["stage_s"]) == {"quantise_octree_records", "context", "model", "cdf_rangecoder"}
