@@ -136,7 +136,7 @@ def cpu_baseline(cfg, xyz, full=False):
     """The CPU oracle (a port of the reference path: C octree / records / CDF / range coder + the functional PyTorch-CPU model,
     oracle/cpu_encode.py) on ONE frame of the bench's own workload, every stage timed.  Bounded sample: all windows shorter than
     the model's context are run; full windows (identical shapes, data-independent cost) are run three times - one warm-up, the
-    median of the other two stands for the rest.  `--cpu-baseline full` runs every window (minutes per frame)."""
+    the faster of the other two stands for the rest.  `--cpu-baseline full` runs every window (minutes per frame)."""
     from cfgs import ehem_cfg, octattn_cfg
     from oracle import cpu_encode
     from scp_amd.models import EHEM, OctAttention
@@ -152,7 +152,7 @@ def cpu_baseline(cfg, xyz, full=False):
         r = cpu_encode.encode_frame_octattn(xyz, sd, cfg["level"], mode=cfg["mode"], full_window_runs=runs)
     what = (f"one whole frame, all {r['windows']} windows run" if full else
             f"one frame: quantiser/octree/records/context of the whole frame, all {r['partial_windows']} partial windows, "
-            f"{r['full_windows_run']} of the {r['full_windows']} full windows (first = warm-up, median of the rest x {r['full_windows']}), "
+            f"{r['full_windows_run']} of the {r['full_windows']} full windows (first = warm-up, the fastest of the rest x {r['full_windows']}), "
             f"CDF + range coder on the {r['rows_coded']} rows produced, scaled to {r['n_nodes']} nodes")
     return dict(value=1.0 / r["total_s"], unit="frames/s", cores=threads, kind="port", sample=what, seconds_per_frame=r["total_s"],
                 stage_s=r["stage_s"], full_window_s=r["full_window_s"], host_cpu=cpu_encode.cpu_model_name(), host_cores=os.cpu_count())

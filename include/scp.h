@@ -147,6 +147,10 @@ SCP_API int scp_knn_topk_packed(const float *x, const int32_t *ctab, int32_t tot
  * f16 MFMA products, fp32 accumulate: distance values within ~1e-6 relative of the fp32 chain), 0 = exact fp32 MFMA chain
  * (bit-identical distance values to PyTorch-CPU).  The 3-feature position search is always exact. */
 SCP_API int scp_set_knn_mode(int32_t f16x3);
+/* workgroup shape of the packed f16x3 search (identical neighbour lists, a performance bracket for microbenchmarks): 256 (default)
+ * = 256-query workgroups on the XCD-affine schedule with the half-step stagger of waves 4-7, 257 = the same without the stagger,
+ * 128 = 128-query workgroups in launch order. */
+SCP_API int scp_set_knn_workgroup(int32_t shape);
 /* scp_knn_topk_packed with an a-priori pruning bound per row: thr0[row] = a value of (2 x.y - |x|^2 - |y|^2) that at least 20
  * candidates of the row's sequence are known to reach (e.g. the 20th best over last layer's neighbours); same result, fewer
  * list insertions.  thr0 may be NULL. */

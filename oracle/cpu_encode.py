@@ -32,8 +32,9 @@ def encode_frame(xyz, sd, level, mullevel=True, mode="spher", full_window_runs=N
 
     full_window_runs=None: every window is run (a whole-frame measurement, bits are the real stream's).
     full_window_runs=k   : windows of exactly `context_size` nodes all cost the same (same shapes, data-independent work), so only
-                           the first k of them are run (the first is a warm-up when k > 1) and their median stands for the
-                           others; every shorter window is run.  Coder time is measured on the rows that exist and scaled by the
+                           the first k of them are run (the first is a warm-up when k > 1) and the FASTEST of the rest stands
+                           for the others (the choice that favours the CPU: measured against a run of every window it is
+                           within a few percent, profiles/cpu_calibration_r2.json); every shorter window is run.  Coder time is measured on the rows that exist and scaled by the
                            node count.  The returned dict says what was measured and what was multiplied."""
     t = {}
     t0 = time.perf_counter()
@@ -83,7 +84,7 @@ def encode_frame(xyz, sd, level, mullevel=True, mode="spher", full_window_runs=N
             else:
                 part_time += dt
     use = full_times[1:] if len(full_times) > 1 and full_window_runs is not None else full_times
-    full_med = float(np.median(use)) if use else 0.0
+    full_med = float(np.min(use)) if use else 0.0
     t["model"] = part_time + (full_med * n_full if full_window_runs is not None else float(sum(full_times)))
     sym_coded = sym_all[order]
     rows = np.where(have)[0]
@@ -139,7 +140,7 @@ def encode_frame_octattn(xyz, sd, level, mode="spher", full_window_runs=None, co
             else:
                 part_time += dt
     use = full_times[1:] if len(full_times) > 1 and full_window_runs is not None else full_times
-    full_med = float(np.median(use)) if use else 0.0
+    full_med = float(np.min(use)) if use else 0.0
     t["model"] = part_time + (full_med * n_full if full_window_runs is not None else float(sum(full_times)))
     real = np.where(have[context_size - 1:])[0]
     sym = oct_seq[:, -1, 0].astype(np.int16)

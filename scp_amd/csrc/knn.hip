@@ -467,6 +467,236 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
     knn_merge_write(key, (float *)pool, (int *)(pool + 128 * 2 * TK * 4), tid, w, col, h, q0, n, k, row0, ctab, idx);
 }
 
+// ---- 256-query workgroups on an XCD-affine schedule (packed mode) ------------------------------------------------------------
+// The 128-query kernel above streams a window's whole candidate set (8192 rows x 4K bytes = 6.3 MB at K = 192) through every one of
+// its 64 workgroups, and consecutive workgroups land on different XCDs: every XCD's 4 MB L2 sees ~8 windows at once and the tiles
+// come back from the Infinity Cache - 24 GB of fabric traffic per launch for 0.5 GB of data (profiles/r1z_pmc_traffic.json).
+// Here (a) a workgroup is 8 waves = 256 queries sharing each candidate tile (half the tile fills per query), (b) workgroups are
+// dealt to XCDs by a table (knn_sched_kernel): the blocks of a launch are cut into 8 runs of equal work, run x is executed by the
+// blocks with blockIdx % 8 == x (observed round-robin placement: a speed assumption only), in window order, so an XCD's 32 CUs
+// work on ONE window at a time, and (c) after the tiles holding its own queries a workgroup sweeps the window in ABSOLUTE tile
+// order, so the co-resident workgroups of a window ask for the same tile at about the same time and L2 serves all but the first.
+// (d) waves 4-7 (the second wave of every SIMD) run half a step behind: they select on the previous tile's products while waves
+// 0-3 have the matrix pipe, and multiply while those select (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+// Distance arithmetic, selection and the order of insertions per lane are those of knn_f16x3_kernel: identical neighbour lists.
+struct KnnWg { int32_t row0, n, q0, pad; };
+
+// tab: [nslots][8] entries for (slot, blockIdx % 8), then `nspill` overflow entries that take whatever an XCD's run holds beyond
+// nslots blocks (runs are cut by WORK, so a launch with many short windows can put more blocks into one run than any useful
+// nslots; the spill region has room for every block of the launch, so nothing is ever dropped).  Entries left zero are empty.
+__global__ __launch_bounds__(1024) void knn_sched_kernel(const int *__restrict__ ctab, int nchunks, KnnWg *__restrict__ tab, int nslots, int nspill) {
+    // sequences = chunks that start one (base == own first row); work of a 256-query block ~ n (its sweep length)
+    __shared__ int seq_base[2048], seq_n[2048], seq_blk0[2049];
+    __shared__ unsigned long long seq_w0[2049];
+    __shared__ int nseq_s, first_blk[9], spill_s;
+    __shared__ unsigned long long wtot_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) { nseq_s = 0; spill_s = 0; }
+    if (tid < 9) first_blk[tid] = INT_MAX;
+    __syncthreads();
+    if (tid < 64) {   // one wavefront compacts the sequence starts in chunk order
+        int cnt = 0;
+        for (int g = 0; g < nchunks; g += 64) {
+            const int c = g + tid;
+            const bool st = c < nchunks && ctab[2 * c] == c * 512 && ctab[2 * c + 1] > 0;
+            const unsigned long long m = __ballot(st);
+            if (st) {
+                const int o = cnt + __popcll(m & ((1ull << tid) - 1ull));
+                if (o < 2048) { seq_base[o] = ctab[2 * c]; seq_n[o] = ctab[2 * c + 1]; }
+            }
+            cnt += __popcll(m);
+        }
+        if (tid == 0) nseq_s = cnt < 2048 ? cnt : 2048;
+    }
+    __syncthreads();
+    const int nseq = nseq_s;
+    if (tid == 0) {   // prefix sums over <= ~130 windows: serial is a few microseconds
+        int b = 0;
+        unsigned long long wsum = 0;
+        for (int q = 0; q < nseq; ++q) {
+            seq_blk0[q] = b; seq_w0[q] = wsum;
+            const int nb = (seq_n[q] + 255) >> 8;
+            b += nb; wsum += (unsigned long long)nb * (unsigned)seq_n[q];
+        }
+        seq_blk0[nseq] = b; seq_w0[nseq] = wsum; wtot_s = wsum ? wsum : 1ull;
+    }
+    __syncthreads();
+    const int nblk = seq_blk0[nseq];
+    const unsigned long long wtot = wtot_s;
+    auto xcd_of = [&](int q, int j) { const unsigned long long cw = seq_w0[q] + (unsigned long long)j * (unsigned)seq_n[q]; const int x = (int)(cw * 8ull / wtot); return x > 7 ? 7 : x; };
+    for (int q = tid; q < nseq; q += 1024) {
+        const int nb = seq_blk0[q + 1] - seq_blk0[q];
+        for (int j = 0; j < nb; ++j) atomicMin(&first_blk[xcd_of(q, j)], seq_blk0[q] + j);
+    }
+    __syncthreads();
+    for (int q = tid; q < nseq; q += 1024) {
+        const int nb = seq_blk0[q + 1] - seq_blk0[q];
+        for (int j = 0; j < nb; ++j) {
+            const int x = xcd_of(q, j), slot = seq_blk0[q] + j - first_blk[x];
+            KnnWg e; e.row0 = seq_base[q]; e.n = seq_n[q]; e.q0 = j * 256; e.pad = 0;
+            if (slot < nslots) tab[slot * 8 + x] = e;
+            else { const int k = atomicAdd(&spill_s, 1); if (k < nspill) tab[nslots * 8 + k] = e; }
+        }
+    }
+    (void)nblk;
+}
+
+#define KNN_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int K, bool STAGGER>
+__global__ __launch_bounds__(512, 2) void knn_f16x3_wg256_kernel(const _Float16 *__restrict__ planes, const float *__restrict__ xx,
+                                                                const float *__restrict__ inv_scale, const KnnWg *__restrict__ tab,
+                                                                int *__restrict__ idx, const float *__restrict__ thr0) {
+    constexpr int RB = 4 * K;                       // bytes per row
+    constexpr int R = RB / 16;                      // chunks per row (48 / 36)
+    constexpr int NC = K / 16;                      // k-chunks of 16 features
+    constexpr int STAGE_B = 32 * RB;                // bytes per stage (32 candidates): 24 / 18 KiB
+    constexpr int NDMA = STAGE_B / 1024;            // 1 KiB DMA instructions per stage (24 / 18)
+    constexpr int NDMA_W = (NDMA + 7) / 8;
+    constexpr int NST = 4;                          // tile ring: tiles are requested three sweep steps ahead
+    constexpr int NXX = NST + 1;                    // |x|^2 / scale ring: one slot more (the staggered waves select one step late)
+    constexpr int MERGE_B = 2 * 256 * 2 * TK * 4;
+    constexpr int TILES_B = NST * STAGE_B + NXX * 64 * 4;
+    constexpr int POOL_B = TILES_B > MERGE_B ? TILES_B : MERGE_B;
+    static_assert(STAGE_B % 1024 == 0, "layout");
+    __shared__ __attribute__((aligned(1024))) char pool[POOL_B];
+    float *txx = (float *)(pool + NST * STAGE_B);   // [NXX][64]: |x|^2 of the 32 candidates, then their inverse scales
+
+    const KnnWg wg = tab[blockIdx.x];
+    const int n = wg.n;
+    if (n <= 0) return;                             // slot beyond this XCD's run
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t row0 = (size_t)wg.row0;
+    const int q0 = wg.q0;
+    const char *pb = (const char *)planes + row0 * RB;
+    const float *xxb = xx + row0, *isb = inv_scale + row0;
+    const int qi = q0 + w * 32 + col;
+    const int nt = (n + 31) >> 5;
+
+    f16x8 qa[NC], qb[NC];
+    const int qc = qi < n ? qi : n - 1;
+    {
+        const char *src = pb + (size_t)qc * RB + 16 * h;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            qa[c] = *(const f16x8 *)(src + 32 * c);
+            qb[c] = *(const f16x8 *)(src + 2 * K + 32 * c);
+        }
+    }
+    const float xxi = (qi < n) ? xxb[qi] : 0.f;
+    const float thr0v = (thr0 && qi < n) ? thr0[row0 + qi] : -INFINITY;
+    const float isq = isb[qc];
+
+    u64 key[TK];
+#pragma unroll
+    for (int t = 0; t < TK; ++t) key[t] = KEY_EMPTY;
+
+    auto issue = [&](int t, int s) {                // candidate tile t -> ring slot of sweep step s
+        const int c0 = t * 32;
+        char *sb = pool + (s % NST) * STAGE_B;
+        int ln;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));   // see knn_mfma_kernel
+#pragma unroll
+        for (int j = 0; j < NDMA_W; ++j) {
+            const int ii = w + 8 * j;
+            if (ii < NDMA) {
+                const int ci = ii * 64 + ln;
+                const int r = ci / R, p = ci - r * R;
+                const int q = (R % 16 == 0) ? (p ^ (r & 15)) : (p ^ ((r >> 2) & 3));
+                int c = c0 + r;
+                c = c < n ? c : n - 1;
+                __builtin_amdgcn_global_load_lds((knn_glb_ptr_t)(pb + (size_t)c * RB + 16 * q), (knn_lds_ptr_t)(sb + ii * 1024), 16, 0, 0);
+            }
+        }
+        if (w == 7) {   // lanes 0..31: |x|^2, lanes 32..63: inverse scale of candidate lane & 31 (the wave with the fewest tile pieces)
+            int c = c0 + (ln & 31);
+            c = c < n ? c : n - 1;
+            const float *src = (ln < 32 ? xxb : isb) + c;
+            __builtin_amdgcn_global_load_lds((knn_glb_ptr_t)src, (knn_lds_ptr_t)((char *)(txx + (s % NXX) * 64)), 4, 0, 0);
+        }
+    };
+    // sweep order: the tiles that hold this workgroup's own queries (every query meets its Morton neighbours first: the pruning
+    // bound is useful from the start), then the window front to back
+    const int own0 = q0 >> 5;
+    int own1 = own0 + 8;
+    own1 = own1 < nt ? own1 : nt;
+    const int nown = own1 - own0;
+    auto tile_of = [&](int s) { if (s < nown) return own0 + s; const int r = s - nown; return r < own0 ? r : r + nown; };
+    // DMA instructions this wave issues per stage; a stage has landed when at most the younger stages' are still in flight
+    const int per_stage = (NDMA - w + 7) / 8 + (w == 7 ? 1 : 0);
+    issue(tile_of(0), 0);
+    if (nt > 1) issue(tile_of(1), 1);
+    if (nt > 2) issue(tile_of(2), 2);
+
+    f32x16 accp;                                    // staggered waves: the previous tile's products
+    int curp = 0;
+    const bool late = STAGGER && w >= 4;
+    for (int s = 0; s < nt; ++s) {
+        // stage s has landed; every wave is done with the tile of step s - 1, whose slot is refilled now (raw barrier: the
+        // younger stages' DMAs stay in flight, scp_internal.h)
+        const int young = (s + 2 < nt ? 2 : (s + 1 < nt ? 1 : 0)) * per_stage;
+        if (young >= 8) KNN_WAIT_BARRIER(8); else if (young == 6) KNN_WAIT_BARRIER(6); else if (young == 4) KNN_WAIT_BARRIER(4);
+        else if (young == 3) KNN_WAIT_BARRIER(3); else if (young == 2) KNN_WAIT_BARRIER(2); else KNN_WAIT_BARRIER(0);
+        if (s + 3 < nt) issue(tile_of(s + 3), s + 3);
+        const int cur = tile_of(s);
+        if (late && s > 0) {
+            const float *sxp = txx + ((s - 1) % NXX) * 64;
+            knn_select<true>(accp, sxp, sxp + 32, 2.f * isq, xxi, curp * 32, n, h, key, thr0v);
+        }
+        const char *arow = pool + (s % NST) * STAGE_B + col * RB;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f16x8 ca = *(const f16x8 *)(arow + 16 * ((2 * c + h) ^ ((R % 16 == 0) ? (col & 15) : ((col >> 2) & 3))));
+            const f16x8 cb = *(const f16x8 *)(arow + 16 * ((K / 8 + 2 * c + h) ^ ((R % 16 == 0) ? (col & 15) : ((col >> 2) & 3))));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cb, qa[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, qb[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, qa[c], acc, 0, 0, 0);
+        }
+        if (late) { accp = acc; curp = cur; }
+        else {
+            const float *sxx = txx + (s % NXX) * 64;
+            knn_select<true>(acc, sxx, sxx + 32, 2.f * isq, xxi, cur * 32, n, h, key, thr0v);
+        }
+    }
+    if (late) {
+        const float *sxp = txx + ((nt - 1) % NXX) * 64;
+        knn_select<true>(accp, sxp, sxp + 32, 2.f * isq, xxi, curp * 32, n, h, key, thr0v);
+    }
+    __syncthreads();
+    // merge the two half-lists of every query and write TK global indices per row
+    {
+        float *mval = (float *)pool;
+        int *midx = (int *)(pool + 256 * 2 * TK * 4);
+        const int ql = w * 32 + col;
+#pragma unroll
+        for (int t = 0; t < TK; ++t) { mval[(ql * 2 + h) * TK + t] = knn_key_val(key[t]); midx[(ql * 2 + h) * TK + t] = knn_key_idx(key[t]); }
+        __syncthreads();
+        if (tid < 256 && q0 + tid < n) {
+            int h0 = 0, h1 = 0;
+            const int kk = n < TK ? n : TK;
+            int *out = idx + (row0 + q0 + tid) * (size_t)TK;
+            const float *va = mval + (tid * 2) * TK, *vb = va + TK;
+            const int *ia = midx + (tid * 2) * TK, *ib = ia + TK;
+            int first = 0;
+            for (int o = 0; o < TK; ++o) {
+                if (o < kk) {
+                    const float a = h0 < TK ? va[h0] : -INFINITY, b = h1 < TK ? vb[h1] : -INFINITY;
+                    const int ja = h0 < TK ? ia[h0] : INT_MAX, jb = h1 < TK ? ib[h1] : INT_MAX;
+                    const bool takea = (a > b) || (a == b && ja < jb);
+                    const int j = (takea ? ja : jb) + (int)row0;
+                    if (o == 0) first = j;
+                    out[o] = j;
+                    if (takea) ++h0; else ++h1;
+                } else out[o] = first;
+            }
+        }
+    }
+}
+
 // fp32 rows -> row scale 2^e (largest |x| into [2^13, 2^14)), two f16 planes of the scaled row ([row][2][K]), 1 / scale, and
 // |x|^2 of the UNscaled row (same sequential summation as sqnorm_kernel).  A workgroup stages 64 rows in LDS (coalesced
 // 16-byte loads; row stride K + 1 floats so that one thread per row can walk its row without bank conflicts), then one
@@ -630,6 +860,11 @@ static int knn_mode() {   // 1 = f16x3 (default), 0 = exact fp32 MFMA (SCP_KNN=f
     return g_knn_mode;
 }
 extern "C" SCP_API int scp_set_knn_mode(int32_t f16x3) { g_knn_mode = f16x3 ? 1 : 0; return SCP_OK; }
+// workgroup shape of the packed f16x3 search: 256 queries on the XCD schedule with the half-step stagger (default), SCP_KNN_WG=257: the
+// same without the stagger, SCP_KNN_WG=128: the 128-query kernel in launch order (the three give identical neighbour lists)
+static int g_knn_wg = -1;
+static int knn_wg() { if (g_knn_wg < 0) { const char *e = getenv("SCP_KNN_WG"); g_knn_wg = e ? atoi(e) : 256; } return g_knn_wg; }
+extern "C" SCP_API int scp_set_knn_workgroup(int32_t v) { g_knn_wg = v; return SCP_OK; }
 
 static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int k, int *idx, const int *ctab, hipStream_t st,
                       const float *thr0 = nullptr) {
@@ -639,7 +874,7 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
     DevBuf *sp = knn_scratch(st);
     if (!sp) return SCP_EINVAL;
     DevBuf &sbuf = *sp;
-    int rc = sbuf.reserve(xx_bytes * (split ? 2 : 1) + (C <= 4 ? (size_t)npts * 16 : (split ? (size_t)npts * RB : 0)));
+    int rc = sbuf.reserve(xx_bytes * (split ? 2 : 1) + (C <= 4 ? (size_t)npts * 16 : (split ? (size_t)npts * RB + 256 + ((size_t)(npts / 256) * 2 + 520) * sizeof(KnnWg) : 0)));
     if (rc) return rc;
     float *xx = sbuf.as<float>();
     void *aux = (char *)sbuf.p + xx_bytes;
@@ -647,6 +882,23 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
         float *isc = (float *)aux;
         _Float16 *pl = (_Float16 *)((char *)aux + xx_bytes);
         hipLaunchKernelGGL(split2_kernel, dim3((unsigned)cdiv64(npts, 64)), dim3(256), 0, st, x, npts, C, pl, xx, isc);
+        if (ctab && knn_wg() != 128) {
+            // XCD-affine schedule of 256-query workgroups (see knn_f16x3_wg256_kernel); the table lives behind the planes
+            const int nchunks = (int)(npts / 512);
+            const int nspill = (int)(npts / 256);                   // every block of the launch fits
+            const int nslots = nspill / 8 + 64;                      // an XCD's run: its share of the blocks + slack for short windows
+            const int nblocks = nslots * 8 + nspill;
+            KnnWg *tab = (KnnWg *)((char *)pl + (((size_t)npts * RB + 255) & ~(size_t)255));
+            HIP_TRY(hipMemsetAsync(tab, 0, (size_t)nblocks * sizeof(KnnWg), st));
+            hipLaunchKernelGGL(knn_sched_kernel, dim3(1), dim3(1024), 0, st, ctab, nchunks, tab, nslots, nspill);
+            const bool stg = knn_wg() != 257;
+            if (C == 144) { if (stg) hipLaunchKernelGGL((knn_f16x3_wg256_kernel<144, true>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, (const KnnWg *)tab, idx, thr0);
+                            else hipLaunchKernelGGL((knn_f16x3_wg256_kernel<144, false>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, (const KnnWg *)tab, idx, thr0); }
+            else { if (stg) hipLaunchKernelGGL((knn_f16x3_wg256_kernel<192, true>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, (const KnnWg *)tab, idx, thr0);
+                   else hipLaunchKernelGGL((knn_f16x3_wg256_kernel<192, false>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, (const KnnWg *)tab, idx, thr0); }
+            LAUNCH_CHECK();
+            return SCP_OK;
+        }
         if (C == 144) hipLaunchKernelGGL(knn_f16x3_kernel<144>, grid, dim3(256), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, n, k, idx, ctab, thr0);
         else hipLaunchKernelGGL(knn_f16x3_kernel<192>, grid, dim3(256), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, n, k, idx, ctab, thr0);
         LAUNCH_CHECK();

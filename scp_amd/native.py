@@ -73,6 +73,7 @@ def lib():
         "scp_swin_attention_packed_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, i64, _vp]),
         "scp_set_attention_mode": (C.c_int, [i32]),
         "scp_set_knn_mode": (C.c_int, [i32]),
+        "scp_set_knn_workgroup": (C.c_int, [i32]),
         "scp_nn_sqdist_f64": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp]),
         "scp_edge_gather_max_ld": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_embed_gather": (C.c_int, [_vp, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp]),
@@ -369,6 +370,11 @@ def set_knn_mode(f16x3):
     """True (default): f16x3 distances for the 144-/192-feature searches; False: exact fp32 MFMA chain."""
     _check(lib().scp_set_knn_mode(1 if f16x3 else 0), "scp_set_knn_mode")
     _MODES["knn"] = "f16x3" if f16x3 else "f32"
+
+
+def set_knn_workgroup(shape):
+    """256 (default): 256-query workgroups, XCD-affine schedule, staggered; 257: no stagger; 128: the 128-query kernel.  Same results."""
+    _check(lib().scp_set_knn_workgroup(int(shape)), "scp_set_knn_workgroup")
 
 
 def numeric_profile(model_name):

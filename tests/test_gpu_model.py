@@ -93,6 +93,41 @@ def test_knn_exact_order_under_heavy_ties(dev, n, C, span):
     assert torch.equal(got, want), (got[:2], want[:2])
 
 
+def test_knn_packed_workgroup_shapes_agree_on_ragged_windows(dev):
+    """The packed f16x3 search in its three workgroup shapes (256 queries on the XCD schedule with / without the stagger, 128 queries in
+    launch order) and the dense per-window entry point return the SAME lists: ragged windows (1 ... 8192 rows), heavily tied
+    integer features, 144 and 192 features."""
+    from scp_amd import native
+    lengths = [1, 7, 20, 33, 300, 513, 2049, 8192, 600, 5000]
+    g = torch.Generator().manual_seed(11)
+    for C in (144, 192):
+        rows = sum(-(-n // 512) * 512 for n in lengths)
+        x = torch.zeros((rows, C))
+        tab, base = [], 0
+        for n in lengths:
+            x[base:base + n] = torch.randint(0, 3, (n, C), generator=g).float()
+            tab += [[base, n]] * (-(-n // 512))
+            base += -(-n // 512) * 512
+        xd, td = x.to(dev), torch.tensor(tab, dtype=torch.int32, device=dev)
+        outs = {}
+        try:
+            for sh in (128, 257, 256):
+                native.set_knn_workgroup(sh)
+                outs[sh] = native.knn_topk_packed(xd, td).cpu()
+        finally:
+            native.set_knn_workgroup(256)
+        base = 0
+        for n in lengths:
+            k = min(20, n)
+            want = native.knn_topk(xd[base:base + n][None].contiguous(), k).cpu()[0].long() + base
+            for sh, o in outs.items():
+                got = o[base:base + n].long()
+                assert torch.equal(got[:, :k], want), (C, n, sh)
+                if k < 20:
+                    assert (got[:, k:] == got[:, :1]).all()
+            base += -(-n // 512) * 512
+
+
 def test_knn_matches_cpu_reference_topk_on_real_window(dev):
     from scp_amd import native
     from oracle import models_ref
