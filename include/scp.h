@@ -148,9 +148,12 @@ SCP_API int scp_knn_topk_packed(const float *x, const int32_t *ctab, int32_t tot
  * (bit-identical distance values to PyTorch-CPU).  The 3-feature position search is always exact. */
 SCP_API int scp_set_knn_mode(int32_t f16x3);
 /* workgroup shape of the packed f16x3 search (identical neighbour lists, a performance bracket for microbenchmarks): 256 (default)
- * = 256-query workgroups on the XCD-affine schedule with the half-step stagger of waves 4-7, 257 = the same without the stagger,
- * 128 = 128-query workgroups in launch order. */
+ * = 256-query workgroups on the XCD-affine schedule, one barrier per group of 3 / 4 candidate tiles; 257 / 258 = groups of 2 / 1;
+ * +16 = outward sweep order; 128 = 128-query workgroups in launch order, one barrier per tile. */
 SCP_API int scp_set_knn_workgroup(int32_t shape);
+/* diagnostic: with a device buffer of (blocks * 8 * 4) u64 set, the K = 192 search of shape 256 runs its cycle-stamped build and
+ * writes per wave [cycles at barrier + DMA issue, in the MFMA block, in the selection, tiles]; NULL (default) = the product kernel */
+SCP_API int scp_knn_debug_buffer(unsigned long long *dev_buf);
 /* scp_knn_topk_packed with an a-priori pruning bound per row: thr0[row] = a value of (2 x.y - |x|^2 - |y|^2) that at least 20
  * candidates of the row's sequence are known to reach (e.g. the 20th best over last layer's neighbours); same result, fewer
  * list insertions.  thr0 may be NULL. */

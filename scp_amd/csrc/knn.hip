@@ -113,6 +113,9 @@ __device__ __forceinline__ void knn_merge_write(const u64 (&key)[TK], float *mva
     }
 }
 
+// |x|^2 of a row beyond its sequence's length (the candidate tiles clamp such rows to the last real one): DMA'd in place of xx[c]
+__device__ const float knn_inf = INFINITY;
+
 // ---- selection step shared by both kernels: this lane holds candidates row = (r&3) + 8(r>>2) + 4h of a 32-tile for its query ---
 // `acc[r]` = x_i . x_j (SCALED: times the two row scales; `usc2` = 2 / scale of the query, `sis` = 1 / scale of the candidates).
 // With a = 2 x_i.x_j - |x_j|^2 the (negated squared) distance is d = fl(a - |x_i|^2).
@@ -121,6 +124,12 @@ __device__ __forceinline__ void knn_merge_write(const u64 (&key)[TK], float *mva
 // the cut and keeps the a of the last one.  Candidates the cut lets through although they do not qualify (a few ulps, or exact
 // ties with the bound) are harmless: the insertion compares full (value, index) keys and they fall off the end of the list.
 // Pass 2: lanes pop their survivors one at a time (the wavefront pays for max-over-lanes survivors, not for all 16 slots).
+// value of the query's other lane (lane ^ 32) by one v_permlane32_swap (the half exchange of gfx950) instead of a ds_bpermute round trip
+__device__ __forceinline__ unsigned knn_xchg32(unsigned x, int h) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return h ? r[0] : r[1];
+}
+
 template <bool SCALED>
 __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, const float *sis, float usc2, float xxi, int c0, int n, int h,
                                            u64 (&key)[TK], float thr0) {
@@ -133,19 +142,18 @@ __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, 
     static_assert(TK == 20, "pair table");
     unsigned sb = (unsigned)(key[TK - 1] >> 32);
     {
-        const unsigned p3 = __shfl_xor((unsigned)(key[3] >> 32), 32), p6 = __shfl_xor((unsigned)(key[6] >> 32), 32),
-                       p9 = __shfl_xor((unsigned)(key[9] >> 32), 32);
+        const unsigned p3 = knn_xchg32((unsigned)(key[3] >> 32), h), p6 = knn_xchg32((unsigned)(key[6] >> 32), h),
+                       p9 = knn_xchg32((unsigned)(key[9] >> 32), h);
         sb = max(sb, min((unsigned)(key[15] >> 32), p3));
         sb = max(sb, min((unsigned)(key[12] >> 32), p6));
         sb = max(sb, min((unsigned)(key[9] >> 32), p9));
-        sb = max(sb, (unsigned)__shfl_xor(sb, 32));
+        sb = max(sb, knn_xchg32(sb, h));
     }
     const float thr = fmaxf(knn_unsortable(sb), thr0);
     // cut: with m = max(|thr|, |xxi|), s = fl(thr + xxi) and cut = fl(s - 2^-21 m) satisfy cut <= thr + xxi - 2^-22 m (both
     // roundings are at most 2^-23 m).  a < cut then gives a - xxi < thr - 2^-22 |thr|, which lies below the float preceding thr,
     // so fl(a - xxi) < thr: the candidate cannot be among the 20 best.  thr = -inf (list not full yet): cut = -inf, all pass.
     const float cut = (thr + xxi) - 0x1p-21f * fmaxf(fabsf(thr), fabsf(xxi));
-    const bool full = c0 + 32 <= n;                                   // wave-uniform: every candidate of the tile exists
     unsigned pend = 0;                                                // candidate r -> bit 15 - r
     float asel = 0.f;                                                 // a of the survivor with the lowest bit
 #pragma unroll
@@ -158,8 +166,9 @@ __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, 
             const int r = 4 * g + u;
             // scales are powers of two: (acc * usc2) * sj is exact, one rounding in the fma
             const float a = SCALED ? fmaf(acc[r] * usc2, sj[u], -xj[u]) : fmaf(2.f, acc[r], -xj[u]);
-            bool pass = a >= cut;
-            if (!full) pass = pass && (c0 + u + 8 * g + 4 * h < n);
+            // rows beyond the sequence's length carry |x|^2 = +inf (knn_inf below): a = -inf, which only passes while the list is
+            // not full (cut = -inf) and is then the lowest real key - no bounds test here
+            const bool pass = a >= cut;
             pend = (pend << 1) | (pass ? 1u : 0u);
             asel = pass ? a : asel;
         }
@@ -265,9 +274,8 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
             if (e0 + w * 64 < SC) {      // wave-uniform
                 const int e = e0 + w * 64 + ln;
                 if (e < SC) {
-                    int c = c0 + e;
-                    c = c < n ? c : n - 1;
-                    __builtin_amdgcn_global_load_lds((knn_glb_ptr_t)(xxb + c), (knn_lds_ptr_t)((char *)(txx + buf * SC) + (e0 + w * 64) * 4), 4, 0, 0);
+                    const int c = c0 + e;
+                    __builtin_amdgcn_global_load_lds((knn_glb_ptr_t)(c < n ? xxb + c : &knn_inf), (knn_lds_ptr_t)((char *)(txx + buf * SC) + (e0 + w * 64) * 4), 4, 0, 0);
                 }
             }
         }
@@ -409,8 +417,9 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
         }
         if (w == 0) {   // lanes 0..31: |x|^2, lanes 32..63: inverse scale of candidate lane & 31
             int c = c0 + (ln & 31);
-            c = c < n ? c : n - 1;
-            const float *src = (ln < 32 ? xxb : isb) + c;
+            const bool real = c < n;
+            c = real ? c : n - 1;
+            const float *src = ln < 32 ? (real ? xxb + c : &knn_inf) : isb + c;
             __builtin_amdgcn_global_load_lds((knn_glb_ptr_t)src, (knn_lds_ptr_t)((char *)(txx + buf * 64)), 4, 0, 0);
         }
     };
@@ -448,14 +457,25 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // candidate fragments (A operand): chunk index inside the row = plane * (K / 8) + 2c + h; the reads of chunk c + 1 are issued
+        // in front of the products of chunk c (left to itself hipcc reads, waits, multiplies: the block then runs at the LDS latency)
+        f16x8 ca = *(const f16x8 *)(arow + 16 * ((0 + h) ^ swz));
+        f16x8 cb = *(const f16x8 *)(arow + 16 * ((K / 8 + h) ^ swz));
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            // candidate fragments (A operand): chunk index inside the row = plane * (K / 8) + 2c + h
-            const f16x8 ca = *(const f16x8 *)(arow + 16 * ((2 * c + h) ^ swz));
-            const f16x8 cb = *(const f16x8 *)(arow + 16 * ((K / 8 + 2 * c + h) ^ swz));
+            f16x8 na = ca, nb = cb;
+            if (c + 1 < NC) {
+                na = *(const f16x8 *)(arow + 16 * ((2 * (c + 1) + h) ^ swz));
+                nb = *(const f16x8 *)(arow + 16 * ((K / 8 + 2 * (c + 1) + h) ^ swz));
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cb, qa[c], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, qb[c], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, qa[c], acc, 0, 0, 0);
+            ca = na; cb = nb;
+            // pin the interleave: the two fragment reads of the next chunk, then the three products of this one
+            if (c + 1 < NC) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
         }
         // un-scaling (acc / s_query / s_candidate, powers of two: exact) happens inside the selection
         const float *sxx = txx + buf * 64;
@@ -476,8 +496,18 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
 // blocks with blockIdx % 8 == x (observed round-robin placement: a speed assumption only), in window order, so an XCD's 32 CUs
 // work on ONE window at a time, and (c) after the tiles holding its own queries a workgroup sweeps the window in ABSOLUTE tile
 // order, so the co-resident workgroups of a window ask for the same tile at about the same time and L2 serves all but the first.
-// (d) waves 4-7 (the second wave of every SIMD) run half a step behind: they select on the previous tile's products while waves
-// 0-3 have the matrix pipe, and multiply while those select (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+// (d) one workgroup barrier per GROUP of tiles instead of per tile (see the kernel).
+// Cycle stamps (DBG build, K = 192, 256-tile sweeps; per tile and wave): product block 2,300 with the SIMD's other wave multiplying
+// too, 2,100 alone on the SIMD (36 MFMAs = 1,152: the block waits for its LDS fragment reads, two reads then three MFMAs per
+// 16 features at 256 VGPRs); selection 3,500 / 3,050; barrier + DMA issue 2,100 / 1,360.  I.e. a wave is latency-bound in every
+// phase and two waves per SIMD nearly double the throughput.  Measured and dropped on this kernel: waves 4-7 half a step behind
+// waves 0-3 (deferred selection; per-tile, per-group and shifted barriers): no gain; survivors appended to per-lane LDS buffers and
+// inserted in batches (16 flushes and 184 insertion rounds per sweep instead of ~500 rounds): the per-tile mask / append code hipcc
+// produces costs more than the rounds it saves (select 4,300 cycles per tile); a second accumulator for the odd chunks (no gain: the
+// block is not paced by the accumulation chain; it also reorders the fp32 sum and 1 % of the lists change); without any fragment
+// read the 36 products of a tile still take ~1,900 cycles for a wave alone on its SIMD.  What did pay: no bounds test per candidate
+// (rows beyond a sequence's length get |x|^2 = +inf by DMA: three instructions per candidate less and 16 - 100 fewer VGPRs in every
+// kernel that shares knn_select), the partner exchange by v_permlane32_swap instead of ds_bpermute: 7 - 9 % per search.
 // Distance arithmetic, selection and the order of insertions per lane are those of knn_f16x3_kernel: identical neighbour lists.
 struct KnnWg { int32_t row0, n, q0, pad; };
 
@@ -541,24 +571,27 @@ __global__ __launch_bounds__(1024) void knn_sched_kernel(const int *__restrict__
     (void)nblk;
 }
 
-#define KNN_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-template <int K, bool STAGGER>
+// G = sweep steps between two workgroup barriers.  With a barrier per step every wave waits for the slowest selection of every tile
+// (the survivors loop is data dependent: wave-state counters showed the kNN waves parked 42 % of their life); with a barrier per
+// group of G tiles the waves drift inside a group and only the sums are compared.  Ring = 2 G tiles: the group being swept and the
+// group in flight (requested right after the barrier, a whole group's sweep ahead of its use).
+template <int K, int G, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void knn_f16x3_wg256_kernel(const _Float16 *__restrict__ planes, const float *__restrict__ xx,
                                                                 const float *__restrict__ inv_scale, const KnnWg *__restrict__ tab,
-                                                                int *__restrict__ idx, const float *__restrict__ thr0) {
+                                                                int *__restrict__ idx, const float *__restrict__ thr0, int order,
+                                                                unsigned long long *__restrict__ dbg = nullptr) {
     constexpr int RB = 4 * K;                       // bytes per row
     constexpr int R = RB / 16;                      // chunks per row (48 / 36)
     constexpr int NC = K / 16;                      // k-chunks of 16 features
     constexpr int STAGE_B = 32 * RB;                // bytes per stage (32 candidates): 24 / 18 KiB
     constexpr int NDMA = STAGE_B / 1024;            // 1 KiB DMA instructions per stage (24 / 18)
     constexpr int NDMA_W = (NDMA + 7) / 8;
-    constexpr int NST = 4;                          // tile ring: tiles are requested three sweep steps ahead
-    constexpr int NXX = NST + 1;                    // |x|^2 / scale ring: one slot more (the staggered waves select one step late)
+    constexpr int NST = 2 * G;
+    constexpr int NXX = NST;
     constexpr int MERGE_B = 2 * 256 * 2 * TK * 4;
     constexpr int TILES_B = NST * STAGE_B + NXX * 64 * 4;
     constexpr int POOL_B = TILES_B > MERGE_B ? TILES_B : MERGE_B;
-    static_assert(STAGE_B % 1024 == 0, "layout");
+    static_assert(STAGE_B % 1024 == 0 && POOL_B <= 160 * 1024, "layout");
     __shared__ __attribute__((aligned(1024))) char pool[POOL_B];
     float *txx = (float *)(pool + NST * STAGE_B);   // [NXX][64]: |x|^2 of the 32 candidates, then their inverse scales
 
@@ -592,9 +625,9 @@ __global__ __launch_bounds__(512, 2) void knn_f16x3_wg256_kernel(const _Float16 
 #pragma unroll
     for (int t = 0; t < TK; ++t) key[t] = KEY_EMPTY;
 
-    auto issue = [&](int t, int s) {                // candidate tile t -> ring slot of sweep step s
+    auto issue = [&](int t, int slot, int xslot) {  // candidate tile t -> ring slot, its |x|^2 / scales -> xslot
         const int c0 = t * 32;
-        char *sb = pool + (s % NST) * STAGE_B;
+        char *sb = pool + slot * STAGE_B;
         int ln;
         asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));   // see knn_mfma_kernel
 #pragma unroll
@@ -611,60 +644,83 @@ __global__ __launch_bounds__(512, 2) void knn_f16x3_wg256_kernel(const _Float16 
         }
         if (w == 7) {   // lanes 0..31: |x|^2, lanes 32..63: inverse scale of candidate lane & 31 (the wave with the fewest tile pieces)
             int c = c0 + (ln & 31);
-            c = c < n ? c : n - 1;
-            const float *src = (ln < 32 ? xxb : isb) + c;
-            __builtin_amdgcn_global_load_lds((knn_glb_ptr_t)src, (knn_lds_ptr_t)((char *)(txx + (s % NXX) * 64)), 4, 0, 0);
+            const bool real = c < n;
+            c = real ? c : n - 1;
+            const float *src = ln < 32 ? (real ? xxb + c : &knn_inf) : isb + c;
+            __builtin_amdgcn_global_load_lds((knn_glb_ptr_t)src, (knn_lds_ptr_t)((char *)(txx + xslot * 64)), 4, 0, 0);
         }
     };
-    // sweep order: the tiles that hold this workgroup's own queries (every query meets its Morton neighbours first: the pruning
-    // bound is useful from the start), then the window front to back
+    // sweep order.  order 0: the tiles that hold this workgroup's own queries (every query meets its Morton neighbours first: the
+    // pruning bound is useful from the start), then the window front to back - co-resident workgroups of a window then ask for
+    // the same tile at about the same time; order 1: own tiles, then alternately outwards (the 128-query kernel's order)
     const int own0 = q0 >> 5;
     int own1 = own0 + 8;
     own1 = own1 < nt ? own1 : nt;
     const int nown = own1 - own0;
-    auto tile_of = [&](int s) { if (s < nown) return own0 + s; const int r = s - nown; return r < own0 ? r : r + nown; };
-    // DMA instructions this wave issues per stage; a stage has landed when at most the younger stages' are still in flight
-    const int per_stage = (NDMA - w + 7) / 8 + (w == 7 ? 1 : 0);
-    issue(tile_of(0), 0);
-    if (nt > 1) issue(tile_of(1), 1);
-    if (nt > 2) issue(tile_of(2), 2);
+    auto tile_of = [&](int s) {
+        if (s < nown) return own0 + s;
+        const int r = s - nown;
+        if (order == 0) return r < own0 ? r : r + nown;
+        // outwards: alternately above own1 and below own0 while both sides last
+        const int below = own0, above = nt - own1, m = below < above ? below : above;
+        if (r < 2 * m) return (r & 1) ? own0 - 1 - (r >> 1) : own1 + (r >> 1);
+        const int rr = r - 2 * m;
+        return below > above ? own0 - 1 - m - rr : own1 + m + rr;
+    };
+    const int ngroups = (nt + G - 1) / G;
+#pragma unroll
+    for (int i = 0; i < G; ++i) if (i < nt) issue(tile_of(i), i, i);
+    // DBG build (tools/mb_knn_wg.py stamps): shader cycles of this wave spent in [barrier + issue, MFMA block, selection]
+    unsigned long long t_sync = 0, t_mfma = 0, t_sel = 0, t_prev = 0;
+    if (DBG) t_prev = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](unsigned long long &acc_t) { if (DBG) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_t += t - t_prev; t_prev = t; } };
 
-    f32x16 accp;                                    // staggered waves: the previous tile's products
-    int curp = 0;
-    const bool late = STAGGER && w >= 4;
-    for (int s = 0; s < nt; ++s) {
-        // stage s has landed; every wave is done with the tile of step s - 1, whose slot is refilled now (raw barrier: the
-        // younger stages' DMAs stay in flight, scp_internal.h)
-        const int young = (s + 2 < nt ? 2 : (s + 1 < nt ? 1 : 0)) * per_stage;
-        if (young >= 8) KNN_WAIT_BARRIER(8); else if (young == 6) KNN_WAIT_BARRIER(6); else if (young == 4) KNN_WAIT_BARRIER(4);
-        else if (young == 3) KNN_WAIT_BARRIER(3); else if (young == 2) KNN_WAIT_BARRIER(2); else KNN_WAIT_BARRIER(0);
-        if (s + 3 < nt) issue(tile_of(s + 3), s + 3);
-        const int cur = tile_of(s);
-        if (late && s > 0) {
-            const float *sxp = txx + ((s - 1) % NXX) * 64;
-            knn_select<true>(accp, sxp, sxp + 32, 2.f * isq, xxi, curp * 32, n, h, key, thr0v);
-        }
-        const char *arow = pool + (s % NST) * STAGE_B + col * RB;
-        f32x16 acc;
+    for (int g = 0; g < ngroups; ++g) {
+        // group g has landed (its DMAs were issued a whole group's sweep ago) and every wave is done with group g - 1, whose half
+        // of the ring is refilled now
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int half = (g & 1) * G, other = G - half;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int i = 0; i < G; ++i) { const int s = (g + 1) * G + i; if (s < nt) issue(tile_of(s), other + i, other + i); }
+        stamp(t_sync);
+#pragma unroll 1
+        for (int i = 0; i < G; ++i) {
+            const int s = g * G + i;
+            if (s >= nt) break;
+            if (DBG && (order & 2) && w >= 4) continue;      // diagnostic: one computing wave per SIMD (results of waves 4-7 are garbage)
+            const int cur = tile_of(s);
+            const char *arow = pool + (half + i) * STAGE_B + col * RB;
+            f32x16 acc;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const f16x8 ca = *(const f16x8 *)(arow + 16 * ((2 * c + h) ^ ((R % 16 == 0) ? (col & 15) : ((col >> 2) & 3))));
-            const f16x8 cb = *(const f16x8 *)(arow + 16 * ((K / 8 + 2 * c + h) ^ ((R % 16 == 0) ? (col & 15) : ((col >> 2) & 3))));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cb, qa[c], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, qb[c], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, qa[c], acc, 0, 0, 0);
-        }
-        if (late) { accp = acc; curp = cur; }
-        else {
-            const float *sxx = txx + (s % NXX) * 64;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int swz = (R % 16 == 0) ? (col & 15) : ((col >> 2) & 3);
+            f16x8 ca = *(const f16x8 *)(arow + 16 * ((0 + h) ^ swz));     // reads of chunk c + 1 in front of the products of chunk c
+            f16x8 cb = *(const f16x8 *)(arow + 16 * ((K / 8 + h) ^ swz));
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                f16x8 na = ca, nb = cb;
+                if (c + 1 < NC && !(DBG && (order & 4))) {       // diagnostic order & 4: no fragment reads (products of stale registers)
+                    na = *(const f16x8 *)(arow + 16 * ((2 * (c + 1) + h) ^ swz));
+                    nb = *(const f16x8 *)(arow + 16 * ((K / 8 + 2 * (c + 1) + h) ^ swz));
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cb, qa[c], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, qb[c], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ca, qa[c], acc, 0, 0, 0);
+                ca = na; cb = nb;
+                // pin the interleave: the two fragment reads of the next chunk, then the three products of this one
+                if (c + 1 < NC) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            }
+            if (DBG) { float keep; asm volatile("v_mov_b32 %0, %1" : "=v"(keep) : "v"(acc[15])); asm volatile("" :: "v"(keep)); stamp(t_mfma); }
+            const float *sxx = txx + (half + i) * 64;
             knn_select<true>(acc, sxx, sxx + 32, 2.f * isq, xxi, cur * 32, n, h, key, thr0v);
+            stamp(t_sel);
         }
     }
-    if (late) {
-        const float *sxp = txx + ((nt - 1) % NXX) * 64;
-        knn_select<true>(accp, sxp, sxp + 32, 2.f * isq, xxi, curp * 32, n, h, key, thr0v);
+    if (DBG && dbg && lane == 0) {
+        unsigned long long *o = dbg + ((size_t)blockIdx.x * 8 + w) * 8;
+        o[0] = t_sync; o[1] = t_mfma; o[2] = t_sel; o[3] = (unsigned long long)nt;
     }
     __syncthreads();
     // merge the two half-lists of every query and write TK global indices per row
@@ -696,6 +752,9 @@ __global__ __launch_bounds__(512, 2) void knn_f16x3_wg256_kernel(const _Float16 
         }
     }
 }
+
+static unsigned long long *g_knn_dbg = nullptr;   // diagnostic build only: scp_knn_debug_buffer (tools/mb_knn_wg.py)
+extern "C" SCP_API int scp_knn_debug_buffer(unsigned long long *dev_buf) { g_knn_dbg = dev_buf; return SCP_OK; }
 
 // fp32 rows -> row scale 2^e (largest |x| into [2^13, 2^14)), two f16 planes of the scaled row ([row][2][K]), 1 / scale, and
 // |x|^2 of the UNscaled row (same sequential summation as sqnorm_kernel).  A workgroup stages 64 rows in LDS (coalesced
@@ -882,7 +941,7 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
         float *isc = (float *)aux;
         _Float16 *pl = (_Float16 *)((char *)aux + xx_bytes);
         hipLaunchKernelGGL(split2_kernel, dim3((unsigned)cdiv64(npts, 64)), dim3(256), 0, st, x, npts, C, pl, xx, isc);
-        if (ctab && knn_wg() != 128) {
+        if (ctab && knn_wg() >= 256) {
             // XCD-affine schedule of 256-query workgroups (see knn_f16x3_wg256_kernel); the table lives behind the planes
             const int nchunks = (int)(npts / 512);
             const int nspill = (int)(npts / 256);                   // every block of the launch fits
@@ -891,11 +950,17 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
             KnnWg *tab = (KnnWg *)((char *)pl + (((size_t)npts * RB + 255) & ~(size_t)255));
             HIP_TRY(hipMemsetAsync(tab, 0, (size_t)nblocks * sizeof(KnnWg), st));
             hipLaunchKernelGGL(knn_sched_kernel, dim3(1), dim3(1024), 0, st, ctab, nchunks, tab, nslots, nspill);
-            const bool stg = knn_wg() != 257;
-            if (C == 144) { if (stg) hipLaunchKernelGGL((knn_f16x3_wg256_kernel<144, true>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, (const KnnWg *)tab, idx, thr0);
-                            else hipLaunchKernelGGL((knn_f16x3_wg256_kernel<144, false>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, (const KnnWg *)tab, idx, thr0); }
-            else { if (stg) hipLaunchKernelGGL((knn_f16x3_wg256_kernel<192, true>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, (const KnnWg *)tab, idx, thr0);
-                   else hipLaunchKernelGGL((knn_f16x3_wg256_kernel<192, false>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, (const KnnWg *)tab, idx, thr0); }
+            // knn_wg(): 256 = groups of 3 (K = 192) / 4 (K = 144) tiles, front-to-back order; 257: groups of 2; 258: one tile per barrier;
+            // +16: outward order instead
+            const int shape = knn_wg() & 15, order = (knn_wg() >> 4) & 7;
+#define KNN_LAUNCH(KK, GG) hipLaunchKernelGGL((knn_f16x3_wg256_kernel<KK, GG>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx, \
+                                              (const float *)isc, (const KnnWg *)tab, idx, thr0, order)
+            if (C == 144) { if (shape == 2) KNN_LAUNCH(144, 1); else if (shape == 1) KNN_LAUNCH(144, 2); else KNN_LAUNCH(144, 4); }
+            else if (g_knn_dbg && shape == 0)
+                hipLaunchKernelGGL((knn_f16x3_wg256_kernel<192, 3, true>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx,
+                                   (const float *)isc, (const KnnWg *)tab, idx, thr0, order, g_knn_dbg);
+            else { if (shape == 2) KNN_LAUNCH(192, 1); else if (shape == 1) KNN_LAUNCH(192, 2); else KNN_LAUNCH(192, 3); }
+#undef KNN_LAUNCH
             LAUNCH_CHECK();
             return SCP_OK;
         }

@@ -74,6 +74,7 @@ def lib():
         "scp_set_attention_mode": (C.c_int, [i32]),
         "scp_set_knn_mode": (C.c_int, [i32]),
         "scp_set_knn_workgroup": (C.c_int, [i32]),
+        "scp_knn_debug_buffer": (C.c_int, [_vp]),
         "scp_nn_sqdist_f64": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp]),
         "scp_edge_gather_max_ld": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_embed_gather": (C.c_int, [_vp, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp]),
@@ -373,7 +374,8 @@ def set_knn_mode(f16x3):
 
 
 def set_knn_workgroup(shape):
-    """256 (default): 256-query workgroups, XCD-affine schedule, staggered; 257: no stagger; 128: the 128-query kernel.  Same results."""
+    """256 (default): 256-query workgroups on the XCD-affine schedule, a barrier per group of tiles; 257 / 258: smaller groups; +16: outward
+    sweep; 128: the 128-query kernel.  Same results."""
     _check(lib().scp_set_knn_workgroup(int(shape)), "scp_set_knn_workgroup")
 
 

@@ -111,7 +111,7 @@ def test_knn_packed_workgroup_shapes_agree_on_ragged_windows(dev):
         xd, td = x.to(dev), torch.tensor(tab, dtype=torch.int32, device=dev)
         outs = {}
         try:
-            for sh in (128, 257, 256):
+            for sh in (128, 258, 257, 256, 272):
                 native.set_knn_workgroup(sh)
                 outs[sh] = native.knn_topk_packed(xd, td).cpu()
         finally:

@@ -27,7 +27,7 @@ def timeit(f, reps=3):
     for _ in range(reps): f()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps
-shapes = (128, 257, 256)
+shapes = (128, 256)
 for x, ktab in calls:
     if x.shape[1] <= 4:
         continue
@@ -36,7 +36,7 @@ for x, ktab in calls:
         native.set_knn_workgroup(sh)
         got = orig(x, ktab)
         if ref is None: ref = got
-        else: assert torch.equal(ref, got), f"shape {sh} differs"
+        elif not torch.equal(ref, got): print(f"shape {sh}: {(ref != got).any(1).float().mean().item() * 100:.4f} % of the rows differ", flush=True)
     times = {sh: [] for sh in shapes}
     for rnd in range(4):
         for sh in shapes:
@@ -45,3 +45,21 @@ for x, ktab in calls:
             times[sh].append(timeit(lambda: orig(x, ktab)))
     print(f"C={x.shape[1]} rows={x.shape[0]}: " + "  ".join(f"{sh}: min {min(t):.2f} med {sorted(t)[len(t)//2]:.2f} ms" for sh, t in times.items()), flush=True)
 native.set_knn_workgroup(256)
+# cycle stamps of the K = 192 search (diagnostic build)
+for x, ktab in calls:
+    if x.shape[1] != 192:
+        continue
+    nb = x.shape[0] // 256 * 2 + 600
+    buf = torch.zeros((nb * 8, 4), dtype=torch.int64, device=dev)
+    for shp in (256, 256 + 32, 256 + 32 + 64, 256 + 64):     # +32: only waves 0-3 compute (one wave per SIMD); +64: no fragment reads
+        buf.zero_()
+        native.set_knn_workgroup(shp)
+        native.lib().scp_knn_debug_buffer(buf.data_ptr())
+        orig(x, ktab); torch.cuda.synchronize()
+        native.lib().scp_knn_debug_buffer(None)
+        native.set_knn_workgroup(256)
+        b = buf[(buf[:, 3] > 0) & (buf[:, 1] > 0)].double()
+        f = b[b[:, 3] == 256]
+        print(f"shape {shp} stamps over {b.shape[0]} waves: cycles per tile  sync+issue {float((b[:,0]/b[:,3]).mean()):.0f}  mfma {float((b[:,1]/b[:,3]).mean()):.0f}  "
+              f"select {float((b[:,2]/b[:,3]).mean()):.0f}   (full windows only: sync {float((f[:,0]/256).mean()):.0f} mfma {float((f[:,1]/256).mean()):.0f} "
+              f"select {float((f[:,2]/256).mean()):.0f})", flush=True)
