@@ -22,8 +22,8 @@ def enc_parts():
 
 # measured (profiles/parity_r2.json) minus a margin: rows whose 20th / 21st neighbours are exactly tied on the octree lattice are
 # resolved by the reference's CPU top-k and may move by more than 1e-4
-PMF_ROWS_MIN = 0.9
-BITS_REL_MAX = 0.005
+PMF_ROWS_MIN = 0.995        # measured 1.0 (L12 same-level) and 0.9986 (L14 multi-level)
+BITS_REL_MAX = 0.0005       # measured: bit counts identical to the reference driver's on both frames
 
 
 def _check_against_reference(res, z, orc, plan_levels):

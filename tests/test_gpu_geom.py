@@ -167,7 +167,7 @@ def test_full_frame_checksums(dev):
     xyz = torch.from_numpy(synth_frame(0)).to(dev)
     n = xyz.shape[0]
     # measured on MI355X (profiles/parity_r2.json): points whose device-quantised integers differ from this fixture's
-    max_diff_pts = {"L12-s": 1200, "L16-s": 8, "C14": 8, "L12-c": 0, "L17": 8, "L18": 16}
+    max_diff_pts = {"L12-s": 900, "L16-s": 0, "C14": 0, "L12-c": 0, "L17": 0, "L18": 8}      # measured: 853, 0, 0, 0, 0, 6
     for key, mode, name, L in (("L12-s", native.SPHER, "q_spher_L12", 12), ("L16-s", native.SPHER, "q_spher_L16", 16),
                                ("C14", native.CYLIN, "q_cylin_L14", 14), ("L12-c", native.CART, "q_cart_L12", 12)):
         f = facts[key]

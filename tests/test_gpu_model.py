@@ -147,7 +147,7 @@ def test_knn_matches_cpu_reference_topk_on_real_window(dev):
     differs = ~(torch.sort(ref, 2)[0] == torch.sort(got, 2)[0]).all(2)[0]
     parity_record("knn_pos_lattice_c1024", sets_identical=same, differing_points=int(differs.sum()), differing_not_tied=int((differs & ~tie).sum()))
     assert not (differs & ~tie).any()
-    assert same > 0.9
+    assert same > 0.95      # measured 0.969: 32 of 1024 points differ, all of them exact ties
 
 
 # ----------------------------------------------------------------------------------------------- edge conv
@@ -423,7 +423,8 @@ def test_ehem_logits_vs_reference_packed_path(dev, ehem, name):
 
 # measured fractions of rows within 1e-3 of the reference's golden logits (lattice positions: exact distance ties at the 20th /
 # 21st neighbour are resolved by the reference's top-k implementation) minus a small margin; profiles/parity_r2.json has the values
-ROWS_OK_MIN = {}
+ROWS_OK_MIN = {"logits_ehem_b2_c256": 0.985, "logits_ehem_c1024": 0.994, "logits_ehem_c600": 0.99, "logits_ehem_c1": 1.0, "logits_ehem_c7": 1.0,
+               "logits_ehem_c8192": 1.0, "logits_ehem_lvl1_c6": 1.0}      # measured: 0.9902 / 0.9971 / 0.9933 / 1 / 1 / 1 / 1
 
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_ehem_*.npz"))))
 def test_ehem_logits_vs_reference(dev, ehem, name):
