@@ -232,6 +232,10 @@ SCP_API int scp_split_rows(const float *src, int64_t ld_src, int64_t n_src, cons
 SCP_API int scp_layernorm_rows_split(const float *x, int64_t ldx, int64_t n_src_rows, const int64_t *ia, const int64_t *ib, int32_t C,
                              const float *gamma, const float *beta, const float *valid, float eps, void *ohi, void *olo, int64_t ldo,
                              int64_t rows, void *stream);
+/* out = LayerNorm(a + b) over rows of C floats (C % 4 == 0, C <= 1024; b may be NULL): the `norm(x + residual)` of
+ * models/attention_model.py:117,123 (OctAttention, C = 600) in one pass. */
+SCP_API int scp_layernorm_add(const float *a, const float *b, int64_t rows, int32_t C, const float *gamma, const float *beta, float eps,
+                              float *out, void *stream);
 SCP_API int scp_swin_attention_packed_split(const float *q, const float *k, const float *v, const float *bias_table, const int32_t *wtab,
                                     int32_t total_windows, int32_t shift, int32_t ldq, int32_t ldkv, void *ohi, void *olo, int64_t ldo,
                                     void *stream);

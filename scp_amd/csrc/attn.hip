@@ -183,6 +183,10 @@ __global__ __launch_bounds__(256, 2) void swin_attn_kernel(const float *__restri
 //   O^T = V^T . P^T: A = V^T tile [d][key'] staged TRANSPOSED with the keys of each 16-group permuted (swap bits 2 and 3) so that
 //                    the 8 keys a lane needs are contiguous AND are exactly the 8 keys its S^T accumulator registers 8c..8c+7
 //                    hold (rows (r&3) + 8(r>>2) + 4h of the 32x32 tile); B = those registers, split to bf16 - P never moves.
+// Measured and dropped (round 2): the scores of both 32-key halves as two interleaved accumulation chains with one softmax update per
+// 64 keys.  A lone dependent chain issues one v_mfma_f32_32x32x16 per 45 - 52 cycles instead of 32 (tools/src/mb_mfma_chain.cpp), so
+// the interleave helps a wave that is alone in its matrix phase - but the second score tile costs 16 VGPRs (168 -> 188) and with
+// them the third wave per SIMD: 156 us against 146 us per 128 windows.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define LDB 72   // bf16 elements per LDS row (64 + 8): 144-byte rows -> conflict-free 16-byte fragment reads

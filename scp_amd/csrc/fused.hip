@@ -110,6 +110,67 @@ extern "C" SCP_API int scp_layernorm_rows_split(const float *x, int64_t ldx, int
     return ln_rows(x, ldx, n_src_rows, ia, ib, C, gamma, beta, valid, eps, nullptr, (__bf16 *)ohi, (__bf16 *)olo, ldo, rows, stream);
 }
 
+// LayerNorm(a + b) for any row width C = 4 * NQ (OctAttention: 600; attention_model.py:117,123 `norm(x + residual)`): one wavefront per
+// row, the row's float4 pieces round-robin over the lanes, both operands read once, the sum never written.  b may be null.
+template <int NP>   // float4 pieces per lane (C <= 256 * NP)
+__global__ __launch_bounds__(256) void layernorm_add_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t rows, int C,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                           float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int nq = C >> 2;
+    f32x4 v[NP];
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int q = lane + 64 * p;
+        v[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (q < nq) {
+            v[p] = *(const f32x4 *)(a + r * C + 4 * q);
+            if (b) v[p] += *(const f32x4 *)(b + r * C + 4 * q);
+            s += (v[p][0] + v[p][1]) + (v[p][2] + v[p][3]);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float qs = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+        if (lane + 64 * p < nq)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const float d = v[p][u] - mean; qs += d * d; }
+    for (int o = 32; o > 0; o >>= 1) qs += __shfl_xor(qs, o);
+    const float rstd = rsqrtf(qs / (float)C + eps);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int q = lane + 64 * p;
+        if (q < nq) {
+            const f32x4 g = *(const f32x4 *)(gamma + 4 * q), bb = *(const f32x4 *)(beta + 4 * q);
+            f32x4 y;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) y[u] = (v[p][u] - mean) * rstd * g[u] + bb[u];
+            *(f32x4 *)(out + r * C + 4 * q) = y;
+        }
+    }
+}
+
+extern "C" SCP_API int scp_layernorm_add(const float *a, const float *b, int64_t rows, int32_t C, const float *gamma, const float *beta, float eps,
+                                         float *out, void *stream) {
+    if (!a || !gamma || !beta || !out || rows < 0 || C <= 0 || (C & 3) || C > 1024 ||
+        (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15))
+        return SCP_EINVAL;
+    if (rows == 0) return SCP_OK;
+    const unsigned nb = (unsigned)cdiv64(rows, 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (C <= 256) hipLaunchKernelGGL(layernorm_add_kernel<1>, dim3(nb), dim3(256), 0, st, a, b, rows, C, gamma, beta, eps, out);
+    else if (C <= 512) hipLaunchKernelGGL(layernorm_add_kernel<2>, dim3(nb), dim3(256), 0, st, a, b, rows, C, gamma, beta, eps, out);
+    else if (C <= 768) hipLaunchKernelGGL(layernorm_add_kernel<3>, dim3(nb), dim3(256), 0, st, a, b, rows, C, gamma, beta, eps, out);
+    else hipLaunchKernelGGL(layernorm_add_kernel<4>, dim3(nb), dim3(256), 0, st, a, b, rows, C, gamma, beta, eps, out);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, int64_t lds, const int64_t *__restrict__ idx, int C4,
                                                          float *__restrict__ out, int64_t ldo, int64_t total /* rows * C4 */) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;

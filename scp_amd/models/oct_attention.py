@@ -116,8 +116,8 @@ class OctAttention(nn.Module):
             q_u = linear(E[1], a.mlp_query.weight, a.mlp_query.bias)
             att = torch.empty_like(E)
             native.octattn_attention(q_u, key[0], key[1], val[0], val[1], self.heads, out=att[0], out_u=att[1])
-            E = F.layer_norm(att + E, (D,), lyr.norm1.weight, lyr.norm1.bias, 1e-5)
-            E = F.layer_norm(linear(linear(E, lyr.linear1.weight, lyr.linear1.bias, act="relu"), lyr.linear2.weight,
-                                    lyr.linear2.bias, residual=E), (D,), lyr.norm2.weight, lyr.norm2.bias, 1e-5)
+            E = native.layernorm_add(att, E, lyr.norm1.weight, lyr.norm1.bias, 1e-5)          # norm(x + residual), one pass
+            E = native.layernorm_add(linear(linear(E, lyr.linear1.weight, lyr.linear1.bias, act="relu"), lyr.linear2.weight,
+                                            lyr.linear2.bias, residual=E), None, lyr.norm2.weight, lyr.norm2.bias, 1e-5)
         emu = E[1]
         return linear(linear(emu, self.decoder0.weight, self.decoder0.bias, act="relu"), self.decoder1.weight, self.decoder1.bias)

@@ -73,6 +73,7 @@ def lib():
         "scp_swin_attention_packed_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, i64, _vp]),
         "scp_set_attention_mode": (C.c_int, [i32]),
         "scp_set_knn_mode": (C.c_int, [i32]),
+        "scp_layernorm_add": (C.c_int, [_vp, _vp, i64, i32, _vp, _vp, C.c_float, _vp, _vp]),
         "scp_set_knn_workgroup": (C.c_int, [i32]),
         "scp_knn_debug_buffer": (C.c_int, [_vp]),
         "scp_nn_sqdist_f64": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp]),
@@ -645,6 +646,17 @@ def layernorm_rows(x, gamma, beta, eps=1e-5, valid=None, ia=None, ib=None, out=N
                                   None if valid is None else _dev(valid, torch.float32), float(eps), out.data_ptr(), out.stride(0),
                                   rows, _stream())
     _check(rc, "scp_layernorm_rows")
+    return out
+
+
+def layernorm_add(a, b, gamma, beta, eps=1e-5):
+    """LayerNorm(a + b) over the last axis (contiguous fp32 tensors of one shape; b may be None) in one kernel."""
+    Cc = a.shape[-1]
+    if not a.is_contiguous() or (b is not None and (not b.is_contiguous() or b.shape != a.shape)):
+        raise ScpError("layernorm_add: contiguous operands of one shape expected")
+    out = torch.empty_like(a)
+    _check(lib().scp_layernorm_add(_dev(a, torch.float32), None if b is None else _dev(b, torch.float32), a.numel() // Cc, Cc, _dev(gamma), _dev(beta),
+                                   float(eps), out.data_ptr(), _stream()), "scp_layernorm_add")
     return out
 
 

@@ -151,6 +151,23 @@ def test_knn_matches_cpu_reference_topk_on_real_window(dev):
 
 
 # ----------------------------------------------------------------------------------------------- edge conv
+@pytest.mark.parametrize("rows,C", [(1, 600), (7, 600), (4099, 600), (33, 256), (5, 1024), (9, 12)])
+def test_layernorm_add_vs_torch(dev, rows, C):
+    """norm(x + residual) of attention_model.py:117,123 in one pass, any row width."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(rows + C)
+    a, b = torch.randn((rows, C), generator=g) * 30, torch.randn((rows, C), generator=g)
+    gm, bt = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    want = torch.nn.functional.layer_norm((a + b).double(), (C,), gm.double(), bt.double(), 1e-5)
+    got = native.layernorm_add(a.to(dev), b.to(dev), gm.to(dev), bt.to(dev)).cpu()
+    assert (got.double() - want).abs().max() < 2e-5
+    got1 = native.layernorm_add(a.to(dev), None, gm.to(dev), bt.to(dev)).cpu()
+    want1 = torch.nn.functional.layer_norm(a.double(), (C,), gm.double(), bt.double(), 1e-5)
+    assert (got1.double() - want1).abs().max() < 2e-5
+    with pytest.raises(native.ScpError):
+        native.layernorm_add(a.to(dev)[:, :C - 1], None, gm.to(dev), bt.to(dev))
+
+
 def test_edge_gather_max_vs_torch(dev):
     from scp_amd import native
     g = torch.Generator().manual_seed(3)
@@ -395,6 +412,27 @@ def test_ehem_tiefree_every_row_vs_reference(dev, ehem, monkeypatch, name, path)
     parity_record(f"{name}/{path}", **rec)
     print(name, path, rec)
     assert e.max() <= LOGIT_TOL, rec
+
+
+def test_ehem_tiefree_exact_knn_mode(dev, ehem, monkeypatch):
+    """The same pin under `scp_set_knn_mode(0)` (all three searches on the exact k-ordered fp32 chain): the reference's neighbour sets
+    for every point of every search, every row within 1e-3."""
+    from scp_amd import native
+    z = golden("tiefree_ehem_c2049")
+    data, pos = _ehem_case(z)
+    spy = _KnnSpy(monkeypatch)
+    native.set_knn_mode(False)
+    try:
+        o1, o2 = _run_packed(ehem, data, pos, dev)
+    finally:
+        native.set_knn_mode(True)
+    st, w1, w2 = _want_rows(z)
+    e = _row_err(o1, o2, st, w1, w2)
+    for i, (feat, idx) in enumerate(spy.calls):
+        same, worst = _knn_sets_vs_reference(feat, idx, z[f"knn{i}"], data.shape[1])
+        assert same >= 0.999 and worst <= 4e-6, (i, same, worst)
+    parity_record("tiefree_ehem_c2049/packed, exact fp32 kNN", max_dlogit=e.max(), rows_within_1e3=(e.max(1) <= LOGIT_TOL).mean())
+    assert e.max() <= LOGIT_TOL
 
 
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_ehem_*.npz"))))
