@@ -1,31 +1,38 @@
 // Stage C: softmax -> numpyAc integer CDF on device (gfx950).
 //
 // numpyAc defines the integer CDF through a SERIAL float32 cumsum (numpyAc/numpyAc.py:111), so the prefix
-// sums cannot be re-associated: one lane walks one row.  A wavefront stages 64 rows in LDS with coalesced
-// loads (row stride 255 dwords is odd -> conflict-free for ds_read_b32), each lane then makes its serial
-// passes out of LDS.  Only (cdf[sym], cdf[sym+1]) leave the chip on the encode path: 4 B/node instead of the
+// sums cannot be re-associated: one lane walks one row.  A workgroup stages 64 rows in LDS with coalesced
+// loads (row stride 255 dwords is odd -> conflict-free for ds_read_b32), the serial passes run out of LDS.  Only (cdf[sym], cdf[sym+1]) leave the chip on the encode path: 4 B/node instead of the
 // reference's 1020 B PMF row + 512 B CDF row over PCIe.
 #include "scp_internal.h"
 
 #define ROWS 64
 #define MAXSYM 255
 
+// Workgroup = 4 wavefronts on 64 rows.  Everything that is not order-sensitive - stage-in, row maximum, exp, the division by
+// the row sum, the stores - is spread over the four wavefronts (wavefront q owns columns 64 q .. 64 q + 63 of every row: lane =
+// row, so the odd row stride keeps ds_read_b32 conflict-free); the two serial float32 passes (row sum, cumsum - both in column
+// order: the PMF this library defines and numpyAc's prefix sums) are walked by one lane per row on wavefront 0.  The first
+// version ran one wavefront per 65 KB tile, i.e. two wavefronts per CU doing 255 exp and 255 float64 divisions per lane:
+// 1.35 ms per 577k-row frame, 0.44 TB/s.  (e / sum: a correctly rounded float32 division - HIP's default, and what the float64
+// division rounded to float32 of the first version produced: 53 >= 2 * 24 + 2 bits make that double rounding innocuous.)
 template <bool FROM_LOGITS>
-__global__ __launch_bounds__(64) void cdf_kernel(const float *__restrict__ in, int64_t ld, int64_t n, int nsym,
-                                                 const uint8_t *__restrict__ sym, float *__restrict__ pmf_out,
-                                                 uint32_t *__restrict__ lohi, uint16_t *__restrict__ cdf_full) {
+__global__ __launch_bounds__(256) void cdf_kernel(const float *__restrict__ in, int64_t ld, int64_t n, int nsym,
+                                                  const uint8_t *__restrict__ sym, float *__restrict__ pmf_out,
+                                                  uint32_t *__restrict__ lohi, uint16_t *__restrict__ cdf_full) {
     __shared__ float tile[ROWS * MAXSYM];
-    const int lane = threadIdx.x;
+    __shared__ float part[4 * ROWS];     // per (column quarter, row): partial maxima, then [0 .. 63] the row sums
+    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
     const int64_t row0 = (int64_t)blockIdx.x * ROWS;
     const int nrow = (int)((n - row0) < ROWS ? (n - row0) : ROWS);
     const int total = nrow * nsym;
     // coalesced stage-in
     if (ld == nsym) {
         const float *src = in + row0 * ld;
-        for (int i = lane; i < total; i += 64) tile[i] = src[i];
+        for (int i = tid; i < total; i += 256) tile[i] = src[i];
     } else if (ld == 256 && nsym <= 256 && (((uintptr_t)in) & 15) == 0) {
         // 16-byte aligned rows of 256 floats (the coding-order table the probability heads write into): one 16-byte load per lane and row
-        for (int r = 0; r < nrow; ++r) {
+        for (int r = wq; r < nrow; r += 4) {
             const float4 v = *(const float4 *)(in + (row0 + r) * 256 + 4 * lane);
             const int c = 4 * lane;
             float *d = tile + r * nsym + c;
@@ -35,38 +42,47 @@ __global__ __launch_bounds__(64) void cdf_kernel(const float *__restrict__ in, i
             if (c + 3 < nsym) d[3] = v.w;
         }
     } else {
-        for (int i = lane; i < total; i += 64) { const int r = i / nsym, c = i - r * nsym; tile[i] = in[(row0 + r) * ld + c]; }
+        for (int i = tid; i < total; i += 256) { const int r = i / nsym, c = i - r * nsym; tile[i] = in[(row0 + r) * ld + c]; }
     }
     __syncthreads();
     float *row = tile + lane * nsym;
-    float c_lo = 0.f, c_hi = 0.f, c_last = 1.f;
-    int s = 0;
-    if (lane < nrow) {
-        if (FROM_LOGITS) {
-            float m = row[0];
-            for (int j = 1; j < nsym; ++j) m = fmaxf(m, row[j]);
+    const int c0 = 64 * wq, c1 = (c0 + 64 < nsym) ? c0 + 64 : nsym;      // this wavefront's columns of every row
+    if (FROM_LOGITS) {
+        float m = -INFINITY;
+        if (lane < nrow) for (int j = c0; j < c1; ++j) m = fmaxf(m, row[j]);
+        part[wq * ROWS + lane] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(part[lane], part[ROWS + lane]), fmaxf(part[2 * ROWS + lane], part[3 * ROWS + lane]));
+        if (lane < nrow) for (int j = c0; j < c1; ++j) row[j] = expf(row[j] - m);
+        __syncthreads();
+        if (wq == 0 && lane < nrow) {   // serial float32 sum in column order
             float sum = 0.f;
-            for (int j = 0; j < nsym; ++j) { const float e = expf(row[j] - m); row[j] = e; sum += e; }
-            for (int j = 0; j < nsym; ++j) row[j] = (float)((double)row[j] / (double)sum);  // the PMF this library defines (float32)
+            for (int j = 0; j < nsym; ++j) sum += row[j];
+            part[lane] = sum;
+        }
+        __syncthreads();
+        if (lane < nrow) {
+            const float sum = part[lane];
+            for (int j = c0; j < c1; ++j) row[j] = row[j] / sum;          // correctly rounded: the PMF this library defines (float32)
+        }
+        __syncthreads();
+        if (pmf_out) {
+            float *dst = pmf_out + row0 * nsym;
+            for (int i = tid; i < total; i += 256) dst[i] = tile[i];
+            __syncthreads();
         }
     }
-    __syncthreads();
-    if (FROM_LOGITS && pmf_out) {
-        float *dst = pmf_out + row0 * nsym;
-        for (int i = lane; i < total; i += 64) dst[i] = tile[i];
-        __syncthreads();
-    }
-    if (lane < nrow) {
-        s = sym ? (int)sym[row0 + lane] : 0;
+    if (wq == 0 && lane < nrow) {
+        const int s = sym ? (int)sym[row0 + lane] : 0;
         // numpyAc.py:111 serial float32 cumsum; keep F[s] and F[s+1] (F[0] = 0, F[k] = c[k-1])
-        float c = 0.f;
+        float c = 0.f, c_lo = 0.f, c_hi = 0.f;
         for (int j = 0; j < nsym; ++j) {
             c = __fadd_rn(c, row[j]);
             if (cdf_full) row[j] = c;
             if (j == s - 1) c_lo = c;
             if (j == s) c_hi = c;
         }
-        c_last = c;
+        const float c_last = c;
         if (lohi) {
             // :112 c / c[-1] in float32, :113 -> float64, :101-103 * 65281, rint, wrap, :106 + arange
             const double scale = (double)(65536 - nsym);
@@ -80,7 +96,7 @@ __global__ __launch_bounds__(64) void cdf_kernel(const float *__restrict__ in, i
         __syncthreads();
         const double scale = (double)(65536 - nsym);
         const int Lp = nsym + 1;
-        for (int i = lane; i < nrow * Lp; i += 64) {
+        for (int i = tid; i < nrow * Lp; i += 256) {
             const int r = i / Lp, k = i - r * Lp;
             uint32_t v = 0;
             if (k > 0) {
@@ -99,8 +115,8 @@ static int launch(bool from_logits, const float *in, int64_t ld, int64_t n, int3
     if (lohi && !sym) return SCP_EINVAL;
     const int nb = (int)cdiv64(n, ROWS);
     hipStream_t st = (hipStream_t)stream;
-    if (from_logits) hipLaunchKernelGGL(cdf_kernel<true>, dim3(nb), dim3(64), 0, st, in, ld, n, nsym, sym, pmf, lohi, cdf_full);
-    else hipLaunchKernelGGL(cdf_kernel<false>, dim3(nb), dim3(64), 0, st, in, ld, n, nsym, sym, pmf, lohi, cdf_full);
+    if (from_logits) hipLaunchKernelGGL(cdf_kernel<true>, dim3(nb), dim3(256), 0, st, in, ld, n, nsym, sym, pmf, lohi, cdf_full);
+    else hipLaunchKernelGGL(cdf_kernel<false>, dim3(nb), dim3(256), 0, st, in, ld, n, nsym, sym, pmf, lohi, cdf_full);
     LAUNCH_CHECK();
     return SCP_OK;
 }
