@@ -941,7 +941,7 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
         float *isc = (float *)aux;
         _Float16 *pl = (_Float16 *)((char *)aux + xx_bytes);
         hipLaunchKernelGGL(split2_kernel, dim3((unsigned)cdiv64(npts, 64)), dim3(256), 0, st, x, npts, C, pl, xx, isc);
-        if (ctab && knn_wg() >= 256) {
+        if (ctab && knn_wg() >= 256 && npts / 512 <= 2048) {   // the schedule kernel lists at most 2048 sequences (one per 512-row chunk at worst)
             // XCD-affine schedule of 256-query workgroups (see knn_f16x3_wg256_kernel); the table lives behind the planes
             const int nchunks = (int)(npts / 512);
             const int nspill = (int)(npts / 256);                   // every block of the launch fits

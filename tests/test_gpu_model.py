@@ -128,6 +128,28 @@ def test_knn_packed_workgroup_shapes_agree_on_ragged_windows(dev):
             base += -(-n // 512) * 512
 
 
+def test_knn_packed_many_short_windows(dev):
+    """More sequences than the XCD schedule lists (2048): the launch falls back to the 128-query kernel; and a launch of 1500 one-chunk
+    windows on the schedule (every run holds far more blocks than its even share of slots: the spill region takes them)."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(5)
+    for nwin in (1500, 2100):
+        C = 144
+        lens = torch.randint(1, 60, (nwin,), generator=g)
+        x = torch.zeros((nwin * 512, C))
+        tab = []
+        for w in range(nwin):
+            n = int(lens[w])
+            x[w * 512:w * 512 + n] = torch.randint(0, 3, (n, C), generator=g).float()
+            tab.append([w * 512, n])
+        xd, td = x.to(dev), torch.tensor(tab, dtype=torch.int32, device=dev)
+        got = native.knn_topk_packed(xd, td).cpu().long()
+        for w in (0, 1, nwin // 2, nwin - 1):
+            n = int(lens[w]); k = min(20, n)
+            want = native.knn_topk(xd[w * 512:w * 512 + n][None].contiguous(), k).cpu()[0].long() + w * 512
+            assert torch.equal(got[w * 512:w * 512 + n, :k], want), (nwin, w)
+
+
 def test_knn_matches_cpu_reference_topk_on_real_window(dev):
     from scp_amd import native
     from oracle import models_ref
