@@ -154,6 +154,9 @@ SCP_API int scp_set_knn_workgroup(int32_t shape);
 /* diagnostic: with a device buffer of (blocks * 8 * 4) u64 set, the K = 192 search of shape 256 runs its cycle-stamped build and
  * writes per wave [cycles at barrier + DMA issue, in the MFMA block, in the selection, tiles]; NULL (default) = the product kernel */
 SCP_API int scp_knn_debug_buffer(unsigned long long *dev_buf);
+/* the same for scp_mlp_split_fused: (workgroups * 8 * 8) u64, per wave [cycles at barriers, phase-1 products, GELU + split, phase-2
+ * products, epilogue, row tiles, -, -] */
+SCP_API int scp_mlp_debug_buffer(unsigned long long *dev_buf);
 /* scp_knn_topk_packed with an a-priori pruning bound per row: thr0[row] = a value of (2 x.y - |x|^2 - |y|^2) that at least 20
  * candidates of the row's sequence are known to reach (e.g. the 20th best over last layer's neighbours); same result, fewer
  * list insertions.  thr0 may be NULL. */

@@ -66,7 +66,8 @@ struct MlpArgs {
 #define MBM 128
 #define M2STAGE 49152
 #define M2HOFF (2 * M2STAGE)
-__global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
+template <bool DBG>
+__global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a, unsigned long long *__restrict__ dbg) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,6 +111,11 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     issue(tile * MBM, 0);
+    // DBG build (tools/mb_mlp_fused.py stamps): shader cycles of this wave in [barrier waits, phase-1 products, GELU + split, phase-2
+    // products, epilogue]
+    unsigned long long t_bar = 0, t_p1 = 0, t_gelu = 0, t_p2 = 0, t_epi = 0, t_prev = 0;
+    if (DBG) t_prev = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](unsigned long long &acc_t) { if (DBG) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_t += t - t_prev; t_prev = t; } };
 
     for (; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * MBM;
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
             for (int t = 0; t < 8; ++t) {
                 const int s = sc * 16 + t;
                 SCP_BARRIER_DMA(0);
+                stamp(t_bar);
                 issue(m0, s + 1);
                 const char *st = smem + (s & 1) * M2STAGE;
                 const int ow = 16384 + (wn * 32 + col) * 64, ox = (wm * 64 + col) * 64;
@@ -156,12 +163,13 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
                         for (int j = 0; j < 2; ++j) acc1[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[j], acc1[q][j], 0, 0, 0);
                     }
                 }
+                if (DBG) { float keep; asm volatile("v_mov_b32 %0, %1" : "=v"(keep) : "v"(acc1[1][1][15])); asm volatile("" :: "v"(keep)); stamp(t_p1); }
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int c = 2 * sc + q;
                 // ---------------- bias + GELU + split of chunk c -> H image (k-slab wn) ----------------
-                if (q == 1) SCP_BARRIER_DMA(0);                    // every wave is done reading chunk A's H image (the DMA in flight
+                if (q == 1) { SCP_BARRIER_DMA(0); stamp(t_bar); }  // every wave is done reading chunk A's H image (the DMA in flight
                                                                     // is re-waited at the next step; one step of prefetch is lost here)
                 {
                     char *hb = smem + M2HOFF + wn * 16384;
@@ -192,10 +200,12 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
                         }
                     }
                 }
+                stamp(t_gelu);
                 // ---------------- phase 2 of chunk c ----------------
                 for (int t = 0; t < 4; ++t) {
                     const int s = sc * 16 + 8 + 4 * q + t;
                     SCP_BARRIER_DMA(0);                             // at t = 0 this also publishes the H image
+                    stamp(t_bar);
                     if (s + 1 < 64) issue(m0, s + 1);
                     const char *st = smem + (s & 1) * M2STAGE;
                     const char *hs = smem + M2HOFF + t * 16384;
@@ -224,11 +234,13 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
 #pragma unroll
                             for (int j = 0; j < 2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc2[i][j], 0, 0, 0);
                     }
+                    if (DBG) { float keep; asm volatile("v_mov_b32 %0, %1" : "=v"(keep) : "v"(acc2[1][1][15])); asm volatile("" :: "v"(keep)); stamp(t_p2); }
                 }
             }
         }
         SCP_WAIT_DMA(0);
         __syncthreads();                                            // every wave is done with the stages and the H image
+        stamp(t_bar);
         if (tile + (int)gridDim.x < ntiles) issue((tile + gridDim.x) * MBM, 0);
 
         float *stg = (float *)(smem + M2HOFF + w * 8192);
@@ -260,8 +272,16 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a) {
                 if (m < a.M) *(mf32x4 *)(a.C + (int64_t)m * a.ldc + nb) = y;
             }
         }
+        stamp(t_epi);
+    }
+    if (DBG && dbg && lane == 0) {
+        unsigned long long *o = dbg + ((size_t)blockIdx.x * 8 + w) * 8;
+        o[0] = t_bar; o[1] = t_p1; o[2] = t_gelu; o[3] = t_p2; o[4] = t_epi; o[5] = (unsigned long long)((ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1);
     }
 }
+
+static unsigned long long *g_mlp_dbg = nullptr;   // diagnostic build only (tools/mb_mlp_fused.py): per wave [barrier, phase 1, GELU, phase 2, epilogue, tiles]
+extern "C" SCP_API int scp_mlp_debug_buffer(unsigned long long *dev_buf) { g_mlp_dbg = dev_buf; return SCP_OK; }
 
 static int g_mlp_num_cu = 0;
 
@@ -286,7 +306,8 @@ extern "C" SCP_API int scp_mlp_split_fused(const void *Xhi, const void *Xlo, int
     constexpr int LDS = 2 * M2STAGE + 65536;
     static bool configured = false;
     if (!configured) {
-        HIP_TRY(hipFuncSetAttribute((const void *)mlp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)mlp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)mlp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         configured = true;
     }
     MlpArgs a;
@@ -295,7 +316,8 @@ extern "C" SCP_API int scp_mlp_split_fused(const void *Xhi, const void *Xlo, int
     a.b1 = b1; a.b2 = b2; a.res = residual; a.ldr = ldr; a.C = C; a.ldc = ldc; a.M = M;
     const int ntiles = (M + MBM - 1) / MBM;
     const unsigned grid = (unsigned)(ntiles < g_mlp_num_cu ? ntiles : g_mlp_num_cu);
-    hipLaunchKernelGGL(mlp_fused_kernel, dim3(grid), dim3(512), LDS, (hipStream_t)stream, a);
+    if (g_mlp_dbg) hipLaunchKernelGGL(mlp_fused_kernel<true>, dim3(grid), dim3(512), LDS, (hipStream_t)stream, a, g_mlp_dbg);
+    else hipLaunchKernelGGL(mlp_fused_kernel<false>, dim3(grid), dim3(512), LDS, (hipStream_t)stream, a, (unsigned long long *)nullptr);
     LAUNCH_CHECK();
     return SCP_OK;
 }

@@ -76,6 +76,7 @@ def lib():
         "scp_layernorm_add": (C.c_int, [_vp, _vp, i64, i32, _vp, _vp, C.c_float, _vp, _vp]),
         "scp_set_knn_workgroup": (C.c_int, [i32]),
         "scp_knn_debug_buffer": (C.c_int, [_vp]),
+        "scp_mlp_debug_buffer": (C.c_int, [_vp]),
         "scp_nn_sqdist_f64": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp]),
         "scp_edge_gather_max_ld": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_embed_gather": (C.c_int, [_vp, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp]),

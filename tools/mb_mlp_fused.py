@@ -28,3 +28,13 @@ for M in ([int(a) for a in sys.argv[1:]] or [577536, 70001, 300]):
     t2, t1 = timeit(two), timeit(one)
     fl = 2.0 * M * 256 * 1024 * 2
     print(f"M={M}: fc1 + fc2 {t2:.3f} ms ({fl/t2/1e9:.0f} TFLOP/s), fused {t1:.3f} ms ({fl/t1/1e9:.0f} TFLOP/s)", flush=True)
+    if M > 100000:   # cycle stamps of the diagnostic build
+        buf = torch.zeros((256 * 8, 8), dtype=torch.int64, device=dev)
+        native.lib().scp_mlp_debug_buffer(buf.data_ptr())
+        one(); torch.cuda.synchronize()
+        native.lib().scp_mlp_debug_buffer(None)
+        b = buf[buf[:, 5] > 0].double()
+        per = b[:, :5] / b[:, 5:6]
+        names = ["barrier waits", "phase-1 products", "GELU + split", "phase-2 products", "epilogue"]
+        print("cycles per 128-row tile and wave: " + "  ".join(f"{n} {per[:, i].mean().item():.0f}" for i, n in enumerate(names)) +
+              f"  total {per.sum(1).mean().item():.0f}  (MFMA pipe time of a wave: 64 steps x 24 x 32 = 49152)", flush=True)
