@@ -52,3 +52,48 @@ def test_single_process_is_a_noop():
     from scp_amd import distributed as D
     assert D.reduce_summary([1, 2, 3, 4, 5]) == [1.0, 2.0, 3.0, 4.0, 5.0]
     assert D.shard(list("abc"), 0, 1) == [(0, "a"), (1, "b"), (2, "c")]
+
+
+def test_rank_thread_pinning_splits_the_host_cores(monkeypatch):
+    """Every rank of a node takes its own slice of the cores (launch thread, range-coder worker, reader); fewer than two cores per rank,
+    a single rank or SCP_PIN=0 leave the affinity alone."""
+    from scp_amd import distributed as D
+    calls = []
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)), raising=False)
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: calls.append(list(cpus)), raising=False)
+    monkeypatch.setattr(torch, "set_num_threads", lambda n: None)
+    assert D.pin_rank_threads(0, 8) == [0, 1] and D.pin_rank_threads(7, 8) == [14, 15] and D.pin_rank_threads(1, 2) == list(range(8, 16))
+    assert calls == [[0, 1], [14, 15], list(range(8, 16))]
+    assert D.pin_rank_threads(0, 1) is None and D.pin_rank_threads(3, 16) is None
+    monkeypatch.setenv("SCP_PIN", "0")
+    assert D.pin_rank_threads(0, 8) is None and len(calls) == 3
+
+
+def test_cli_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
+    """`encode.py --gpus N` outside torchrun starts N ranks through torch.distributed.run (as a child, before any GPU call) and exits
+    with its code; flag combinations the reference cannot execute are refused."""
+    import subprocess
+    import sys
+    from scp_amd import cli, native
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd: seen.setdefault("cmd", cmd) and 0)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["encode.py"])
+    with pytest.raises(SystemExit) as e:
+        cli.main(["--test_files", "x.bin", "--type", "kitti", "--gpus", "4", "--spher"], mullevel=False)
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--test_files", "x.bin", "--type", "kitti", "--gpus", "4"] + [] or "--spher" in cmd
+
+    class A:
+        spher_circle = False; level_wise = False; preproc_path = ""; metrics = False; type = "kitti"; spher = True; cylin = False; sequential = False
+    cli.refuse_unsupported(A, "EHEM", False)                       # a supported combination passes
+    for field, value, model, mul in (("spher_circle", True, "EHEM", False), ("level_wise", True, "OctAttention", False),
+                                     ("sequential", True, "EHEM", False), ("preproc_path", "pp/", "OctAttention", True), ("type", "obj", "EHEM", True)):
+        a = type("B", (A,), {field: value})
+        with pytest.raises(native.ScpError):
+            cli.refuse_unsupported(a, model, mul)
+    a = type("B", (A,), {"level_wise": True})
+    cli.refuse_unsupported(a, "OctAttention", True)                 # encode_mullevel.py has the fixed level-wise form

@@ -136,3 +136,48 @@ def test_training_dataset_matches_reference(tmp_path):
         d, p, lab = ds[i]
         assert np.array_equal(d, z["data"][k]) and np.array_equal(p, z["pos"][k]) and np.array_equal(lab, z["label"][k])
         assert d.dtype == np.int64 and p.dtype == np.float32 and p.shape == (3, 16)
+
+
+def test_decoder_side_info_parsing(tmp_path):
+    """decode_ehem.py:20-27 `extract_info` restated: coordinate system and (levels, bin_num, z_offset) from the file name, (min, max)
+    pairs from the `.dat`; the `.scp.json` extension round-trips; per-shell quantisation steps follow the dataset type."""
+    import torch
+    from scp_amd import decoder as D
+    f = str(tmp_path / "seq07000012_cylin_36_3279_-1.bin")
+    open(f, "wb").write(b"\x00")
+    torch.save(torch.Tensor(np.array([[0, 5], [1, 9]], np.float32)), f + ".dat")
+    spher, cylin, pos_mm, n_levels, bin_num, z = D.extract_info(f)
+    assert (spher, cylin, n_levels, bin_num, z) == (False, True, 36, 3279, -1) and pos_mm.tolist() == [[0, 5], [1, 9]]
+    g = str(tmp_path / "000001_12_0_0.bin")          # Cartesian: no .dat is read
+    open(g, "wb").write(b"\x00")
+    e = D.extract_info(g)
+    assert e[:2] == (False, False) and e[3:] == (12, 0, 0) and len(e[2]) == 0
+    assert D.read_sidecar(f) is None
+
+    class Enc:
+        data_type = "kitti"; lidar_level = 14; mullevel = True; spher = False; cylin = True
+    res = dict(n_points=120000, n_nodes=5, bin_num=3279.0, bin_nums=[3279.0, 6557.0, 13113.0], z_offset=-1.759)
+    import scp_amd.native as native
+    try:
+        side = D.write_sidecar(f, Enc, res, "EHEM")
+    except native.ScpError:
+        pytest.skip("library not built")
+    back = D.read_sidecar(f)
+    assert back == side and back["bin_nums"] == [3279.0, 6557.0, 13113.0] and back["z_offset"] == -1.759 and back["profile"].startswith("ehem/")
+    assert D.shell_qs("kitti", 16, True) == [400 / (2 ** 16 - 1), 400 / (2 ** 17 - 1), 400 / (2 ** 18 - 1)]
+    assert D.shell_qs("ford", 17, True) == [2, 1, 0.5] and D.shell_qs("kitti", 12, False) == [400 / 4095]
+
+
+def test_obj_quantisation_matches_proc_pc_defaults():
+    """`--type obj`: proc_pc's defaults (data_preprocess.py:13-70): offset = per-axis minimum, qs = 1, numpy's round half to even on the
+    float32 difference; MVUB names swap / negate axes first."""
+    import torch
+    from scp_amd.cli import obj_ints
+    rng = np.random.default_rng(2)
+    p = (rng.random((500, 3)) * 300 - 40).astype(np.float32)
+    p[:7] = np.round(p[:7]) + 0.5                                       # exact halves: round half to even
+    want = np.round(p - np.min(p, 0)).astype(np.int32)                  # the reference's arithmetic (float32 - float32, np.round)
+    assert np.array_equal(obj_ints(p, "thing_vox9.ply", torch.device("cpu")).numpy(), want)
+    r = p[:, [0, 2, 1]].copy(); r[:, 2] = -r[:, 2]
+    want_r = np.round(r - np.min(r, 0)).astype(np.int32)
+    assert np.array_equal(obj_ints(p, "data/mvub/phil9/frame0001.ply", torch.device("cpu")).numpy(), want_r)
