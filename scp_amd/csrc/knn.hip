@@ -905,12 +905,23 @@ __global__ __launch_bounds__(256) void knn_generic_kernel(const float *__restric
 
 // |x|^2 scratch + the padded / split copy of the input, grown on demand - ONE PER STREAM: two frames may run their kNN searches
 // concurrently on two streams (FrameEncoder lanes); launches of one stream are ordered, so its buffer can be reused call after call
-struct KnnScratch { void *stream; bool used; DevBuf buf; };
+struct KnnScratch { void *stream; bool used; unsigned long long last; DevBuf buf; };
 static KnnScratch g_xx_tab[8];
+static unsigned long long g_xx_clock = 0;
+// A ninth stream takes over the slot that has not been used for the longest time (streams of encoders that no longer exist, in
+// practice): its buffer is released first - hipFree waits for everything in flight, so a kernel of the old stream that may still
+// be reading the buffer finishes before the memory goes away.  Two live streams never share a buffer.
 static DevBuf *knn_scratch(hipStream_t st) {
-    for (auto &e : g_xx_tab) if (e.used && e.stream == (void *)st) return &e.buf;
-    for (auto &e : g_xx_tab) if (!e.used) { e.used = true; e.stream = (void *)st; return &e.buf; }
-    return nullptr;   // a ninth stream: refused (sharing a buffer between unordered streams would be a data race)
+    ++g_xx_clock;
+    for (auto &e : g_xx_tab) if (e.used && e.stream == (void *)st) { e.last = g_xx_clock; return &e.buf; }
+    KnnScratch *pick = nullptr;
+    for (auto &e : g_xx_tab) if (!e.used) { pick = &e; break; }
+    if (!pick) {
+        for (auto &e : g_xx_tab) if (!pick || e.last < pick->last) pick = &e;
+        pick->buf.release();
+    }
+    pick->used = true; pick->stream = (void *)st; pick->last = g_xx_clock;
+    return &pick->buf;
 }
 
 static int g_knn_mode = -1;

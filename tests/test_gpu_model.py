@@ -150,6 +150,24 @@ def test_knn_packed_many_short_windows(dev):
             assert torch.equal(got[w * 512:w * 512 + n, :k], want), (nwin, w)
 
 
+def test_knn_scratch_survives_many_streams(dev):
+    """The per-stream kNN scratch table has 8 slots: a ninth stream takes over the least recently used one (encoders come and go in a
+    long-running process); results stay those of the default stream."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn((1024, 144), generator=g).to(dev)
+    tab = torch.tensor([[0, 600], [0, 600]], dtype=torch.int32, device=dev)
+    want = native.knn_topk_packed(x, tab).cpu()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(12)]
+    torch.cuda.synchronize()
+    for rnd in range(2):
+        for st in streams:
+            with torch.cuda.stream(st):
+                got = native.knn_topk_packed(x, tab)
+            st.synchronize()
+            assert torch.equal(got.cpu()[:600], want[:600])
+
+
 def test_knn_matches_cpu_reference_topk_on_real_window(dev):
     from scp_amd import native
     from oracle import models_ref
