@@ -507,7 +507,9 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
 // block is not paced by the accumulation chain; it also reorders the fp32 sum and 1 % of the lists change); without any fragment
 // read the 36 products of a tile still take ~1,900 cycles for a wave alone on its SIMD.  What did pay: no bounds test per candidate
 // (rows beyond a sequence's length get |x|^2 = +inf by DMA: three instructions per candidate less and 16 - 100 fewer VGPRs in every
-// kernel that shares knn_select), the partner exchange by v_permlane32_swap instead of ds_bpermute: 7 - 9 % per search.
+// kernel that shares knn_select), the partner exchange by v_permlane32_swap instead of ds_bpermute: 7 - 9 % per search.  Queries dealt
+// to the waves round-robin instead of in runs of 32 (to even out the waves at the barriers): barrier time -12 %, selection +22 % (a wave
+// pays for its busiest lane, and neighbouring queries are busy together), 4 % slower overall.
 // Distance arithmetic, selection and the order of insertions per lane are those of knn_f16x3_kernel: identical neighbour lists.
 struct KnnWg { int32_t row0, n, q0, pad; };
 
