@@ -304,7 +304,7 @@ def main():
             out["roofline_kernels"] = {
                 "mlp_fused_kernel": entry(dom["mlp"], note="fc1 + GELU + fc2 + residual of a Swin block in one launch, hidden activation in LDS"),
                 "swin_attn_bf16x3_kernel": entry(dom["attn"]),
-                "knn_f16x3_kernel": entry(dom["knn_feat"], note="fused distance + top-20 selection"),
+                "knn_f16x3_wg256_kernel": entry(dom["knn_feat"], note="fused distance + top-20 selection, 256-query workgroups on the XCD-affine schedule; every phase of a wave is latency-bound (DESIGN.md 4.5), L2-miss traffic 2.0 GB per launch"),
                 "knn_mfma_kernel<2,16> (positions)": {"bound": "valu", "launches_per_frame": dom["knn_pos"]["launches"],
                                                       "avg_launch_us": dom["knn_pos"]["avg_launch_us"]}}
             out["roofline_stages"] = {
