@@ -202,6 +202,11 @@ SCP_API int scp_split_weight_f16(const float *W, int32_t N, int32_t K, int32_t N
 SCP_API int scp_linear_f16x3(const float *A, int64_t lda, const void *Whi, const void *Wlo, const float *w_inv_scale, int32_t Kpad,
                              const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, int32_t M, int32_t N,
                              int32_t K, int32_t act, float *row_scale_ws, void *stream);
+/* row scales of an activation on their own, and scp_linear_f16x3 with them given: layers that read the same rows share one pass */
+SCP_API int scp_row_scale_f16(const float *A, int64_t lda, int32_t M, int32_t K, float *scale, float *inv_scale, void *stream);
+SCP_API int scp_linear_f16x3_scaled(const float *A, int64_t lda, const void *Whi, const void *Wlo, const float *w_inv_scale, int32_t Kpad,
+                                    const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, int32_t M, int32_t N,
+                                    int32_t K, int32_t act, const float *scale, const float *inv_scale, void *stream);
 
 /* The same dense layer with the ACTIVATION pre-split too: A arrives as bf16 planes hi/lo [M][lda] (lda % 8 == 0, lda >= Kpad,
  * columns K..Kpad zero) written by the producing kernel (scp_split_rows, scp_layernorm_rows_split, the attention kernels, or this

@@ -355,14 +355,22 @@ extern "C" SCP_API int scp_split_weight_f16(const float *W, int32_t N, int32_t K
     return SCP_OK;
 }
 
-extern "C" SCP_API int scp_linear_f16x3(const float *A, int64_t lda, const void *Whi, const void *Wlo, const float *w_inv_scale,
-                                        int32_t Kpad, const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc,
-                                        int32_t M, int32_t N, int32_t K, int32_t act, float *row_scale_ws, void *stream) {
-    if (!A || !Whi || !Wlo || !w_inv_scale || !C || !row_scale_ws || M <= 0 || N <= 0 || K <= 0 || (K & 3) || (lda & 3) || Kpad < K ||
+// row scales of an activation on their own (scale [M], 1 / scale [M]): several layers reading the SAME rows (OctAttention's key / value /
+// query projections of one embedding tensor) share them through scp_linear_f16x3_scaled
+extern "C" SCP_API int scp_row_scale_f16(const float *A, int64_t lda, int32_t M, int32_t K, float *scale, float *inv_scale, void *stream) {
+    if (!A || !scale || !inv_scale || M <= 0 || K <= 0 || (K & 3) || (lda & 3) || lda < K || ((uintptr_t)A & 15)) return SCP_EINVAL;
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, A, lda, M, K, scale, inv_scale);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+static int linear_f16x3_launch(const float *A, int64_t lda, const void *Whi, const void *Wlo, const float *w_inv_scale, int32_t Kpad,
+                               const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                               int32_t act, float *sc, float *isc, bool compute_scales, void *stream) {
+    if (!A || !Whi || !Wlo || !w_inv_scale || !C || !sc || !isc || M <= 0 || N <= 0 || K <= 0 || (K & 3) || (lda & 3) || Kpad < K ||
         (Kpad % BK) || act < 0 || act > 3 || ((uintptr_t)A & 15) || lda < K || ldc < N || (residual && ldr < N))
         return SCP_EINVAL;
-    float *sc = row_scale_ws, *isc = row_scale_ws + M;      // workspace: 2 M floats
-    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, A, lda, M, K, sc, isc);
+    if (compute_scales) hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, A, lda, M, K, sc, isc);
     const dim3 grid((unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM)));
 #define GO(ACT) hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT, true>), grid, dim3(512), 0, (hipStream_t)stream, A, lda, (const __bf16 *)Whi, \
                               (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K, sc, isc, w_inv_scale)
@@ -370,6 +378,23 @@ extern "C" SCP_API int scp_linear_f16x3(const float *A, int64_t lda, const void 
 #undef GO
     LAUNCH_CHECK();
     return SCP_OK;
+}
+
+extern "C" SCP_API int scp_linear_f16x3(const float *A, int64_t lda, const void *Whi, const void *Wlo, const float *w_inv_scale,
+                                        int32_t Kpad, const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc,
+                                        int32_t M, int32_t N, int32_t K, int32_t act, float *row_scale_ws, void *stream) {
+    if (!row_scale_ws) return SCP_EINVAL;
+    return linear_f16x3_launch(A, lda, Whi, Wlo, w_inv_scale, Kpad, bias, residual, ldr, C, ldc, M, N, K, act, row_scale_ws, row_scale_ws + M, true,
+                               stream);      // workspace: 2 M floats
+}
+
+// the same with the row scales of A given (scp_row_scale_f16 on exactly these rows)
+extern "C" SCP_API int scp_linear_f16x3_scaled(const float *A, int64_t lda, const void *Whi, const void *Wlo, const float *w_inv_scale,
+                                               int32_t Kpad, const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc,
+                                               int32_t M, int32_t N, int32_t K, int32_t act, const float *scale, const float *inv_scale,
+                                               void *stream) {
+    return linear_f16x3_launch(A, lda, Whi, Wlo, w_inv_scale, Kpad, bias, residual, ldr, C, ldc, M, N, K, act, (float *)scale, (float *)inv_scale,
+                               false, stream);
 }
 
 // ================================================================================================================

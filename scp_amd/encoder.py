@@ -472,9 +472,17 @@ class OctAttnFrameEncoder:
             else:
                 d = torch.stack(full_c[b0:b1]).reshape(b1 - b0, cs, 4, 3)
                 p = torch.stack(full_p[b0:b1])
-            out = self.model(d, p)
-            for i, (r0, skip) in enumerate(dst[b0:b1]):
-                table[r0:r0 + cs - skip] = out[i, skip:]
+            out = self.model(d, p).reshape(-1, 255)
+            # consecutive full windows of one chunk cover consecutive table rows: one copy per run (the first window of a chunk
+            # starts with its cs - 1 pad rows)
+            i = 0
+            while i < b1 - b0:
+                j = i + 1
+                while j < b1 - b0 and dst[b0 + j][1] == 0 and dst[b0 + j][0] == dst[b0 + j - 1][0] + cs - dst[b0 + j - 1][1]:
+                    j += 1
+                r0, skip = dst[b0 + i]
+                table[r0:r0 + (j - i) * cs - skip] = out[i * cs + skip:j * cs]
+                i = j
 
     def encode_ints(self, q, bin_num, n_points, t0=None, sequential=False, defer=False, front=None):
         """q: integer cloud (numpy / tensor int32 [P,3]) or the list of per-shell clouds of the multi-level form."""

@@ -12,14 +12,15 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import native
+from .. import ops as _ops
 from ..ops import linear as _linear
 
 
-def linear(x, w, b=None, act=None, residual=None):
+def linear(x, w, b=None, act=None, residual=None, scales=None):
     """OctAttention scales its embeddings by sqrt(600): the bf16x3 split (16-bit operands) leaves 1.8e-3 on the logits here, above
     the 1e-3 tolerance, so its dense layers run on the f16x3 kernel (22-bit operands, row scaled: the accuracy of an fp32 chain);
     the K = 12 position layer stays on the exact fp32 kernel."""
-    return _linear(x, w, b, act=act, residual=residual, precise=True)
+    return _linear(x, w, b, act=act, residual=residual, precise=True, scales=scales)
 
 
 class _PosEnc(nn.Module):
@@ -111,9 +112,11 @@ class OctAttention(nn.Module):
         E = E + self.transformer_encoder.position_enc.pe[:c]
         for lyr in self.transformer_encoder.layers:
             a = lyr.attn
-            key = linear(E, a.mlp_key.weight, a.mlp_key.bias)
-            val = linear(E, a.mlp_value.weight, a.mlp_value.bias)
-            q_u = linear(E[1], a.mlp_query.weight, a.mlp_query.bias)
+            # the three projections read the same rows: one pass for their power-of-two row scales (the query takes the unknown stream's half)
+            rs = native.RowScales(E.reshape(-1, D)) if (E.is_contiguous() and _ops.MODE == "bf16x3") else None
+            key = linear(E, a.mlp_key.weight, a.mlp_key.bias, scales=rs)
+            val = linear(E, a.mlp_value.weight, a.mlp_value.bias, scales=rs)
+            q_u = linear(E[1], a.mlp_query.weight, a.mlp_query.bias, scales=None if rs is None else rs.rows(B * c, 2 * B * c))
             att = torch.empty_like(E)
             native.octattn_attention(q_u, key[0], key[1], val[0], val[1], self.heads, out=att[0], out_u=att[1])
             E = native.layernorm_add(att, E, lyr.norm1.weight, lyr.norm1.bias, 1e-5)          # norm(x + residual), one pass

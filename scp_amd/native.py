@@ -73,6 +73,8 @@ def lib():
         "scp_swin_attention_packed_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, i64, _vp]),
         "scp_set_attention_mode": (C.c_int, [i32]),
         "scp_set_knn_mode": (C.c_int, [i32]),
+        "scp_row_scale_f16": (C.c_int, [_vp, i64, i32, i32, _vp, _vp, _vp]),
+        "scp_linear_f16x3_scaled": (C.c_int, [_vp, i64, _vp, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp, _vp, _vp]),
         "scp_layernorm_add": (C.c_int, [_vp, _vp, i64, i32, _vp, _vp, C.c_float, _vp, _vp]),
         "scp_set_knn_workgroup": (C.c_int, [i32]),
         "scp_knn_debug_buffer": (C.c_int, [_vp]),
@@ -498,21 +500,53 @@ class SplitWeightF16:
         note_cache_fill()
 
 
-def linear_f16x3(x, sw, bias=None, act=ACT_NONE, residual=None):
-    """x [..., K] fp32 -> act(x @ W.T + bias) + residual, [..., N] fp32, on the f16x3 kernel (22-bit operands, row scaled)."""
-    K, N = sw.K, sw.N
-    lead = x.shape[:-1]
+class RowScales:
+    """Power-of-two row scales of an fp32 activation [M, K] (scale, 1 / scale) for the f16x3 layers: computed once, shared by every
+    layer that reads these rows (`rows(a, b)` = the scales of the row range [a, b))."""
+
+    __slots__ = ("sc", "isc", "x")
+
+    def __init__(self, x2=None, sc=None, isc=None):
+        if x2 is not None:
+            M, K = x2.shape
+            ws = torch.empty((2, M), dtype=torch.float32, device=x2.device)
+            _check(lib().scp_row_scale_f16(x2.data_ptr(), x2.stride(0), M, K, ws[0].data_ptr(), ws[1].data_ptr(), _stream()), "scp_row_scale_f16")
+            sc, isc = ws[0], ws[1]
+        self.sc, self.isc, self.x = sc, isc, x2
+
+    def rows(self, a, b):
+        return RowScales(None, self.sc[a:b], self.isc[a:b])
+
+
+def _rows_f16x3(x, K):
     x2 = x.reshape(-1, K)
     if x2.stride(1) != 1 or (x2.stride(0) & 3) or (x2.data_ptr() & 15):
         x2 = x2.contiguous()
+    return x2
+
+
+def linear_f16x3(x, sw, bias=None, act=ACT_NONE, residual=None, scales=None):
+    """x [..., K] fp32 -> act(x @ W.T + bias) + residual, [..., N] fp32, on the f16x3 kernel (22-bit operands, row scaled).
+    scales: RowScales of exactly these rows (else they are computed here)."""
+    K, N = sw.K, sw.N
+    lead = x.shape[:-1]
+    x2 = _rows_f16x3(x, K)
     M = x2.shape[0]
     out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    ws = torch.empty((2 * M,), dtype=torch.float32, device=x.device)
     r2 = None
     if residual is not None:
         r2 = residual.reshape(-1, N)
         if r2.stride(1) != 1:
             r2 = r2.contiguous()
+    if scales is not None:
+        if scales.sc.shape[0] != M:
+            raise ScpError("linear_f16x3: row scales of another row count")
+        rc = lib().scp_linear_f16x3_scaled(x2.data_ptr(), x2.stride(0), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.inv_scale.data_ptr(), sw.Kpad,
+                                           _opt(bias), None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0), out.data_ptr(),
+                                           out.stride(0), M, N, K, act, scales.sc.data_ptr(), scales.isc.data_ptr(), _stream())
+        _check(rc, "scp_linear_f16x3_scaled")
+        return out.reshape(*lead, N)
+    ws = torch.empty((2 * M,), dtype=torch.float32, device=x.device)
     rc = lib().scp_linear_f16x3(x2.data_ptr(), x2.stride(0), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.inv_scale.data_ptr(), sw.Kpad,
                                 _opt(bias), None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0), out.data_ptr(),
                                 out.stride(0), M, N, K, act, ws.data_ptr(), _stream())

@@ -71,13 +71,14 @@ def clear_cache():
     _cache16.clear()
 
 
-def linear(x, w, b=None, act=None, residual=None, exact=False, precise=False):
+def linear(x, w, b=None, act=None, residual=None, exact=False, precise=False, scales=None):
     """act(x @ w.T + b) + residual.  exact=True keeps plain fp32 (used where the result feeds a kNN search); precise=True uses
-    the f16x3 kernel (22-bit operands: fp32-chain accuracy at the MFMA rate; OctAttention)."""
+    the f16x3 kernel (22-bit operands: fp32-chain accuracy at the MFMA rate; OctAttention; `scales`: native.RowScales of x shared
+    between layers that read the same rows)."""
     K = w.shape[1]
     if MODE == "bf16x3" and x.is_cuda:
         if precise and not exact and K % 4 == 0 and K >= 32:
-            return native.linear_f16x3(x, _split16(w), b, _ACT[act], residual)
+            return native.linear_f16x3(x, _split16(w), b, _ACT[act], residual, scales=scales)
         if not exact and not precise and K % 4 == 0 and K >= 32:
             return native.linear_bf16x3(x, _split(w), b, _ACT[act], residual)
         # exact fp32 MFMA kernel: k-ordered FMA chains, results independent of how many rows share the launch
