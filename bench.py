@@ -146,7 +146,8 @@ def cpu_baseline(cfg, xyz, full=False):
     runs = None if full else 3
     if cfg["model"] == "EHEM":
         sd = fill_weights(EHEM(ehem_cfg()), 0).state_dict()
-        r = cpu_encode.encode_frame(xyz, sd, cfg["level"], mullevel=cfg["mullevel"], mode=cfg["mode"], full_window_runs=runs)
+        r = cpu_encode.encode_frame(xyz, sd, cfg["level"], mullevel=cfg["mullevel"], mode=cfg["mode"], full_window_runs=runs,
+                                    data_type=cfg.get("type", "kitti"))
     else:
         sd = fill_weights(OctAttention(octattn_cfg()), 0).state_dict()
         r = cpu_encode.encode_frame_octattn(xyz, sd, cfg["level"], mode=cfg["mode"], full_window_runs=runs)
@@ -165,6 +166,9 @@ CONFIGS = {
     # configs[1]: same-level level 12 (run it with --steps 16 for the batch of 16 frames)
     "ehem-L12-s": dict(model="EHEM", level=12, mullevel=False, mode="spher",
                        workload="SCP-EHEM KITTI-like synthetic 120k-pt frames, --spher lidar_level=12 (BASELINE.json configs[1])"),
+    # configs[3]: Ford-like frames (the same clouds in integer millimetres), level 17 multi-level
+    "ehem-F17-m": dict(model="EHEM", level=17, mullevel=True, mode="spher", type="ford",
+                       workload="SCP-EHEM Ford-like synthetic 120k-pt frames (integer mm), --spher --mullevel lidar_level=17 (BASELINE.json configs[3])"),
     # configs[0]'s workload on the GPU / configs[4]
     "octattn-L12-spher": dict(model="OctAttention", level=12, mullevel=False, mode="spher",
                               workload="SCP-OctAttention KITTI-like synthetic 120k-pt frames, --spher lidar_level=12 (BASELINE.json configs[0] workload)"),
@@ -205,14 +209,17 @@ def main():
     ehem = cfg["model"] == "EHEM"
     if ehem:
         model = fill_weights(EHEM(ehem_cfg()), 0).to(dev)
-        enc = FrameEncoder(model, "kitti", cfg["level"], spher=cfg["mode"] == "spher", cylin=cfg["mode"] == "cylin", mullevel=cfg["mullevel"],
-                           device=dev)
+        enc = FrameEncoder(model, cfg.get("type", "kitti"), cfg["level"], spher=cfg["mode"] == "spher", cylin=cfg["mode"] == "cylin",
+                           mullevel=cfg["mullevel"], device=dev)
     else:
         model = fill_weights(OctAttention(octattn_cfg()), 0).to(dev)
         enc = OctAttnFrameEncoder(model, "kitti", cfg["level"], spher=cfg["mode"] == "spher", cylin=cfg["mode"] == "cylin", device=dev)
 
     total = args.warmup + args.steps
     frames_host = [synth_frame(rank * 1000 + i) for i in range(total)]
+    if cfg.get("type") == "ford":
+        from scp_amd.synth import ford_like
+        frames_host = [ford_like(f) for f in frames_host]
     frames = [torch.from_numpy(f).to(dev) for f in frames_host]      # resident in HBM before the timed region
     torch.cuda.synchronize()
 
@@ -265,7 +272,9 @@ def main():
                 except Exception:
                     pass
             metric = "KITTI frames/sec encode (SCP-EHEM, level 16) + bpp match vs ref"
-            if args.config != "ehem-L16-m":
+            if args.config == "ehem-F17-m":
+                metric = "Ford-like frames/sec encode (SCP-EHEM, level 17 multi-level) + bpp match vs ref"
+            elif args.config != "ehem-L16-m":
                 metric = f"KITTI frames/sec encode (SCP-EHEM, level {cfg['level']} same-level) + bpp match vs ref"
             dtype = ("f32 (dense layers and attention as bf16x3 split on bf16 MFMA, feature kNN as f16x3 split on f16 MFMA, fp32 accumulate; "
                      "position kNN / CDF in fp32)")

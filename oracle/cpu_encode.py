@@ -27,7 +27,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def encode_frame(xyz, sd, level, mullevel=True, mode="spher", full_window_runs=None, context_size=8192):
+def encode_frame(xyz, sd, level, mullevel=True, mode="spher", full_window_runs=None, context_size=8192, data_type="kitti"):
     """One frame, every stage timed.  sd: EHEM state_dict (CPU tensors).
 
     full_window_runs=None: every window is run (a whole-frame measurement, bits are the real stream's).
@@ -39,10 +39,10 @@ def encode_frame(xyz, sd, level, mullevel=True, mode="spher", full_window_runs=N
     t = {}
     t0 = time.perf_counter()
     if mullevel:
-        shells = orc.mullevel_shells(xyz, level, mode)
+        shells = orc.mullevel_shells(xyz, level, mode, data_type)
         recs = [s["records"] for s in shells]
     else:
-        recs = [orc.proc_pc(xyz, orc.kitti_qs(level), mode)["records"]]
+        recs = [orc.proc_pc(xyz, orc.kitti_qs(level) if data_type == "kitti" else orc.ford_qs(level), mode)["records"]]
     t["quantise_octree_records"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     if mullevel:
