@@ -186,7 +186,10 @@ __global__ __launch_bounds__(256, 2) void swin_attn_kernel(const float *__restri
 // Measured and dropped (round 2): the scores of both 32-key halves as two interleaved accumulation chains with one softmax update per
 // 64 keys.  A lone dependent chain issues one v_mfma_f32_32x32x16 per 45 - 52 cycles instead of 32 (tools/src/mb_mfma_chain.cpp), so
 // the interleave helps a wave that is alone in its matrix phase - but the second score tile costs 16 VGPRs (168 -> 188) and with
-// them the third wave per SIMD: 156 us against 146 us per 128 windows.
+// them the third wave per SIMD: 156 us against 146 us per 128 windows.  The register-neutral form of the same idea - probabilities of
+// half 0 split to planes first (freeing the score registers), then the score products of half 1 issued between the output products of
+// half 0, bit-identical - needs both halves' K and V fragments live: 212 VGPRs (151 us at two waves per SIMD), 180 us when forced
+// into 168 with spills.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define LDB 72   // bf16 elements per LDS row (64 + 8): 144-byte rows -> conflict-free 16-byte fragment reads
