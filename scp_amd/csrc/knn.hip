@@ -577,6 +577,10 @@ __global__ __launch_bounds__(1024) void knn_sched_kernel(const int *__restrict__
 // (the survivors loop is data dependent: wave-state counters showed the kNN waves parked 42 % of their life); with a barrier per
 // group of G tiles the waves drift inside a group and only the sums are compared.  Ring = 2 G tiles: the group being swept and the
 // group in flight (requested right after the barrier, a whole group's sweep ahead of its use).
+// Dropped (round 2, measured): pass 1 of tile s dealt between the products of tile s + 1 (one candidate behind every second product,
+// order fenced with sched_barrier; +16 accumulator registers, no spills).  Identical lists; the fused block took 3130 cycles against
+// 2575 for the products alone, the remaining selection 1820 against 2620: 5 % fewer busy cycles per wave, but the launch went from
+// 6.31 / 7.05 ms to 6.56 / 7.46 ms (K = 144 / 192) - with two waves per SIMD the other wave already fills the pipe's idle slots.
 template <int K, int G, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void knn_f16x3_wg256_kernel(const _Float16 *__restrict__ planes, const float *__restrict__ xx,
                                                                 const float *__restrict__ inv_scale, const KnnWg *__restrict__ tab,

@@ -27,7 +27,7 @@ def timeit(f, reps=3):
     for _ in range(reps): f()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps
-shapes = (128, 256)
+shapes = tuple(int(v) for v in os.environ.get('MB_SHAPES', '128,256').split(','))
 for x, ktab in calls:
     if x.shape[1] <= 4:
         continue
