@@ -147,24 +147,25 @@ def qkv_fused(layer, cross):
     return derived(layer, "kv" if cross else "qkv", [m.weight for m in mods] + [m.bias for m in mods], build)
 
 
-def _edge_conv(conv, feat, k):
+def _edge_conv(conv, feat, k, feeds_knn=True):
     """feat [B,n,C] -> [B,n,C'] : kNN in feature space + (split 1x1 conv) + BN + LeakyReLU(0.2) + max over k."""
     Cout = conv[0].weight.shape[0]  # [C', 2C, 1, 1]
     Wuv, scale, shift = _edge_fold(conv)
     idx = native.knn_topk(feat, k)
-    uv = linear(feat, Wuv, None, exact=True)          # [B,n,2C'] plain fp32: these features feed the next kNN search
+    # [B,n,2C'] plain fp32 where the features feed the next kNN search; the last convolution's only feed dense layers: bf16x3 like those
+    uv = linear(feat, Wuv, None, exact=feeds_knn)
     u = uv[..., :Cout].contiguous()
     v = uv[..., Cout:].contiguous()
     return native.edge_gather_max(u, v, idx, scale, shift)
 
 
-def _edge_conv_packed(conv, feat, ktab):
+def _edge_conv_packed(conv, feat, ktab, feeds_knn=True):
     """packed layout: feat [T,C] (all windows back to back, padded to x512 rows), ktab int32 [T/512,2] -> [T,C']."""
     Cout = conv[0].weight.shape[0]
     Wuv, scale, shift = _edge_fold(conv)
     feat = feat.contiguous()
     idx = native.knn_topk_packed(feat, ktab)
-    uv = linear(feat, Wuv, None, exact=True)
+    uv = linear(feat, Wuv, None, exact=feeds_knn)
     return native.edge_gather_max_rows(uv[:, :Cout], uv[:, Cout:], idx, scale, shift)
 
 
@@ -181,7 +182,7 @@ def geo_feat_forward(g, ctx, pos):
     pos1 = _edge_conv(g.conv1, pos.contiguous(), k)
     pos2 = _edge_conv(g.conv2, torch.cat((pos1, x), 2), k)
     x = leaky_mlp3(g.mlp2, x, exact=True)     # feeds the third kNN search: keep plain fp32
-    pos3 = _edge_conv(g.conv3, torch.cat((pos2, x), 2), k)
+    pos3 = _edge_conv(g.conv3, torch.cat((pos2, x), 2), k, feeds_knn=False)
     x = leaky_mlp3(g.mlp3, x)
     ec = leaky_mlp3(g.edge_mlp1, torch.cat((pos1, pos2, pos3), 2))
     ec = leaky_mlp3(g.edge_mlp2, torch.cat((pos3, ec), 2))

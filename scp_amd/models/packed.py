@@ -274,7 +274,7 @@ def ehem_phase1_packed(model, ctx, pos, plan, table=None):
     pos1 = _edge_conv_packed(g.conv1, pos0, ktab)
     pos2 = _edge_conv_packed(g.conv2, torch.cat((pos1, x), 1), ktab)
     x = leaky_mlp3(g.mlp2, x, exact=True)
-    pos3 = _edge_conv_packed(g.conv3, torch.cat((pos2, x), 1), ktab)
+    pos3 = _edge_conv_packed(g.conv3, torch.cat((pos2, x), 1), ktab, feeds_knn=False)
     # dense part on the split-operand GEMM: fp32 tensors are split once, the MLP chains stay in the split format, the two
     # halves of `feat` are written straight into their column slots
     nx = g.mlp3[4].weight.shape[0]
