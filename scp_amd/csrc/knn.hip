@@ -54,35 +54,42 @@ typedef __attribute__((address_space(3))) void *knn_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *knn_glb_ptr_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// ---- sorted top-20 lists of the specialised kernels: ONE 64-bit key per entry ---------------------------------------------------
-// key = sortable(d) << 32 | (2^32 - 1 - j): the order (value desc, index asc) is a single unsigned 64-bit compare, so an insertion
-// step is v_cmp_gt_u64 + four v_cndmask instead of three compares, two scalar ops and four v_cndmask.  sortable() maps float
-// order to unsigned order (negative values: all bits flipped; others: sign bit set).  Empty slots hold KEY_EMPTY = (-inf, no index).
-typedef unsigned long long u64;
-#define KEY_EMPTY 0x007FFFFF00000000ull
-__device__ __forceinline__ unsigned knn_sortable(float d) {
-    const unsigned u = __float_as_uint(d);
-    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+// ---- sorted top-20 lists of the specialised kernels: ONE 64-bit key per entry, kept as a DOUBLE ----------------------------------
+// key = the double whose high word is the bit pattern of the float d and whose low word is the index j (d < 0) or ~j (d >= 0).
+// IEEE doubles are sign-magnitude like floats, and a float's exponent and mantissa occupy the high bits of the double's, so the
+// order of the doubles is the order the lists want (larger d = larger key; equal d: lower j = larger key) for every float d:
+// +-0, denormals (f64 denormals are never flushed) and +-inf, whose high word 0x7F800000 is a FINITE double; only a NaN d with
+// mantissa bits 0x700000 set would be a double NaN, and d is never NaN for finite inputs.  An insertion step is then
+// v_max_f64 + v_min_f64 (full rate on gfx950: 2 x 4 cycles) instead of v_cmp_gt_u64 + four v_cndmask (5 - 6 x 4 cycles): the
+// selection is VALU-bound (two waves per SIMD spend ~60 % of their cycles issuing VALU work, most of it insertions).
+// Empty slots hold KEY_EMPTY = (-inf, no index); KEY_NONE (the double -inf) is below every key, KEY_EMPTY included.
+typedef double kkey_t;
+#define KEY_EMPTY __longlong_as_double((long long)0xFF800000FFFFFFFFull)
+#define KEY_NONE __longlong_as_double((long long)0xFFF0000000000000ull)
+__device__ __forceinline__ kkey_t knn_key(float d, int j) {
+    const int hi = __float_as_int(d);
+    return __hiloint2double(hi, j ^ ~(hi >> 31));
 }
-__device__ __forceinline__ float knn_unsortable(unsigned s) {
-    return __uint_as_float((s & 0x80000000u) ? (s ^ 0x80000000u) : ~s);
+__device__ __forceinline__ float knn_key_val(kkey_t k) { return __int_as_float(__double2hiint(k)); }
+__device__ __forceinline__ int knn_key_idx(kkey_t k) {
+    const int hi = __double2hiint(k), lo = __double2loint(k);
+    return (hi == (int)0xFF800000 && lo == -1) ? INT_MAX : (lo ^ ~(hi >> 31));
 }
-__device__ __forceinline__ u64 knn_key(float d, int j) { return ((u64)knn_sortable(d) << 32) | (u64)(0xFFFFFFFFu - (unsigned)j); }
-__device__ __forceinline__ float knn_key_val(u64 k) { return knn_unsortable((unsigned)(k >> 32)); }
-__device__ __forceinline__ int knn_key_idx(u64 k) { const unsigned lo = (unsigned)k; return lo == 0u ? INT_MAX : (int)(0xFFFFFFFFu - lo); }
 
-__device__ __forceinline__ void key_insert(u64 (&key)[TK], u64 kc) {
+__device__ __forceinline__ void key_insert(kkey_t (&key)[TK], kkey_t kc) {
 #pragma unroll
     for (int t = 0; t < TK; ++t) {
-        const bool better = kc > key[t];
-        const u64 nk = better ? kc : key[t];
-        kc = better ? key[t] : kc;
-        key[t] = nk;
+        // inline asm: the compiler's fmax / fmin would canonicalise both operands first (two more instructions per step)
+        // (the maximum is written in place: separate result registers made the compiler copy 40 registers back per insertion)
+        kkey_t rest;
+        asm("v_min_f64 %0, %1, %2" : "=v"(rest) : "v"(kc), "v"(key[t]));
+        asm("v_max_f64 %0, %1, %0" : "+v"(key[t]) : "v"(kc));
+        kc = rest;
     }
 }
 
 // ---- shared tail: merge the two partial lists of every query (lane halves h = 0 / 1) and write the indices -------------------
-__device__ __forceinline__ void knn_merge_write(const u64 (&key)[TK], float *mval, int *midx, int tid, int w, int col, int h,
+__device__ __forceinline__ void knn_merge_write(const kkey_t (&key)[TK], float *mval, int *midx, int tid, int w, int col, int h,
                                                 int q0, int n, int k, size_t row0, const int *ctab, int *idx) {
     {
         const int ql = w * 32 + col;
@@ -132,7 +139,7 @@ __device__ __forceinline__ unsigned knn_xchg32(unsigned x, int h) {
 
 template <bool SCALED>
 __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, const float *sis, float usc2, float xxi, int c0, int n, int h,
-                                           u64 (&key)[TK], float thr0) {
+                                           kkey_t (&key)[TK], float thr0) {
     // Pruning bound.  The two lanes of a query (h = 0 / 1) keep separate sorted lists a, b over disjoint candidates.  a[i] and
     // b[18 - i] bound the 20th best of their union from below (i + 1 entries of a and 19 - i entries of b are at least
     // min(a[i], b[18 - i])), as do a[19] and b[19] alone; each lane evaluates four such pairs (values only: the sortable high
@@ -140,16 +147,16 @@ __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, 
     // max(a[19], b[19]) gives.  thr0 is the caller's a-priori bound (a distance that at least 20 candidates are known to beat;
     // -inf when there is none).
     static_assert(TK == 20, "pair table");
-    unsigned sb = (unsigned)(key[TK - 1] >> 32);
+    float sb = knn_key_val(key[TK - 1]);
     {
-        const unsigned p3 = knn_xchg32((unsigned)(key[3] >> 32), h), p6 = knn_xchg32((unsigned)(key[6] >> 32), h),
-                       p9 = knn_xchg32((unsigned)(key[9] >> 32), h);
-        sb = max(sb, min((unsigned)(key[15] >> 32), p3));
-        sb = max(sb, min((unsigned)(key[12] >> 32), p6));
-        sb = max(sb, min((unsigned)(key[9] >> 32), p9));
-        sb = max(sb, knn_xchg32(sb, h));
+        const float p3 = __uint_as_float(knn_xchg32(__float_as_uint(knn_key_val(key[3])), h)), p6 = __uint_as_float(knn_xchg32(__float_as_uint(knn_key_val(key[6])), h)),
+                    p9 = __uint_as_float(knn_xchg32(__float_as_uint(knn_key_val(key[9])), h));
+        sb = fmaxf(sb, fminf(knn_key_val(key[15]), p3));
+        sb = fmaxf(sb, fminf(knn_key_val(key[12]), p6));
+        sb = fmaxf(sb, fminf(knn_key_val(key[9]), p9));
+        sb = fmaxf(sb, __uint_as_float(knn_xchg32(__float_as_uint(sb), h)));
     }
-    const float thr = fmaxf(knn_unsortable(sb), thr0);
+    const float thr = fmaxf(sb, thr0);
     // cut: with m = max(|thr|, |xxi|), s = fl(thr + xxi) and cut = fl(s - 2^-21 m) satisfy cut <= thr + xxi - 2^-22 m (both
     // roundings are at most 2^-23 m).  a < cut then gives a - xxi < thr - 2^-22 |thr|, which lies below the float preceding thr,
     // so fl(a - xxi) < thr: the candidate cannot be among the 20 best.  thr = -inf (list not full yet): cut = -inf, all pass.
@@ -179,7 +186,7 @@ __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, 
         const int r = act ? 16 - __ffs(pend) : 0;
         pend &= pend - 1u;
         const int j = c0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        key_insert(key, act ? knn_key(asel - xxi, j) : 0ull);        // 0 is below every key, KEY_EMPTY included
+        key_insert(key, act ? knn_key(asel - xxi, j) : KEY_NONE);
     }
     while (__any(pend != 0u)) {   // further survivors (wave-uniform loop): recompute a of slot r, same arithmetic -> same value
         const bool act = pend != 0u;
@@ -190,7 +197,7 @@ __device__ __forceinline__ void knn_select(const f32x16 &acc, const float *sxx, 
         for (int rr = 1; rr < 16; ++rr) t = (rr == r) ? acc[rr] : t;
         const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
         const float a = SCALED ? fmaf(t * usc2, sis[cl], -sxx[cl]) : fmaf(2.f, t, -sxx[cl]);
-        key_insert(key, act ? knn_key(a - xxi, c0 + cl) : 0ull);
+        key_insert(key, act ? knn_key(a - xxi, c0 + cl) : KEY_NONE);
     }
 }
 
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
     const float xxi = (qi < n) ? xxb[qi] : 0.f;
     const float thr0v = (thr0 && qi < n) ? thr0[row0 + qi] : -INFINITY;
 
-    u64 key[TK];
+    kkey_t key[TK];
 #pragma unroll
     for (int t = 0; t < TK; ++t) key[t] = KEY_EMPTY;
 
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void knn_f16x3_kernel(const _Float16 *__res
     const float thr0v = (thr0 && qi < n) ? thr0[row0 + qi] : -INFINITY;
     const float isq = isb[qc];                      // 1 / scale of the query row (a power of two)
 
-    u64 key[TK];
+    kkey_t key[TK];
 #pragma unroll
     for (int t = 0; t < TK; ++t) key[t] = KEY_EMPTY;
 
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(512, 2) void knn_f16x3_wg256_kernel(const _Float16 
     const float thr0v = (thr0 && qi < n) ? thr0[row0 + qi] : -INFINITY;
     const float isq = isb[qc];
 
-    u64 key[TK];
+    kkey_t key[TK];
 #pragma unroll
     for (int t = 0; t < TK; ++t) key[t] = KEY_EMPTY;
 
