@@ -63,6 +63,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // v_max_f64 + v_min_f64 (full rate on gfx950: 2 x 4 cycles) instead of v_cmp_gt_u64 + four v_cndmask (5 - 6 x 4 cycles): the
 // selection is VALU-bound (two waves per SIMD spend ~60 % of their cycles issuing VALU work, most of it insertions).
 // Empty slots hold KEY_EMPTY = (-inf, no index); KEY_NONE (the double -inf) is below every key, KEY_EMPTY included.
+// Measured after this and dropped (A/B on one box, lists identical): pass 1 on v_pk_mul_f32 / v_pk_fma_f32 (two candidates per
+// instruction) +2 %, its mask built with v_addc carry-in (3 instead of 4 instructions per candidate) +0 %, the per-lane acc[r] of
+// pass 2 as a binary select tree (19 instead of 32 instructions) +6 % - fewer VALU instructions no longer buy time here.
 typedef double kkey_t;
 #define KEY_EMPTY __longlong_as_double((long long)0xFF800000FFFFFFFFull)
 #define KEY_NONE __longlong_as_double((long long)0xFFF0000000000000ull)
