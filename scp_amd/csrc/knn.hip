@@ -587,6 +587,15 @@ __global__ __launch_bounds__(1024) void knn_sched_kernel(const int *__restrict__
 // (the survivors loop is data dependent: wave-state counters showed the kNN waves parked 42 % of their life); with a barrier per
 // group of G tiles the waves drift inside a group and only the sums are compared.  Ring = 2 G tiles: the group being swept and the
 // group in flight (requested right after the barrier, a whole group's sweep ahead of its use).
+// Dropped (round 2, measured, lists identical): a producer / selector split of the 256-query workgroup - waves 0-3 (one per SIMD; waves w
+// and w + 4 share a SIMD, read back from HW_ID) only multiply, 64 queries each as two alternating accumulation chains with the candidate
+// fragments read once, and hand the 32 x 32 distance tiles to waves 4-7 through LDS, which only select, one step behind; one barrier per
+// tile, ring of three tiles.  Stamps per tile step: 72 products 3585 cycles (50 per product although the chains are independent: the
+// selecting wave's VALU stream competes for the issue port), selection of 64 queries 3746 (one wave alone is latency-bound where two
+// in step share the VALU at 812 per wave and tile), barrier waits 2200: 5.60 / 6.49 ms against 4.89 / 5.98 ms.  Interleaving the two
+// sets' selections in the selecting wave (both insertions every round) made it worse (6.57 / 7.97 ms): survivors are sparse, a round
+// usually serves one set.  Also dropped: two accumulation chains over even / odd feature chunks in this kernel (+4 %; the waves of a
+// SIMD run their product phases in step and already fill the matrix pipe between them).
 // Dropped (round 2, measured): pass 1 of tile s dealt between the products of tile s + 1 (one candidate behind every second product,
 // order fenced with sched_barrier; +16 accumulator registers, no spills).  Identical lists; the fused block took 3130 cycles against
 // 2575 for the products alone, the remaining selection 1820 against 2620: 5 % fewer busy cycles per wave, but the launch went from

@@ -49,8 +49,8 @@ native.set_knn_workgroup(256)
 for x, ktab in calls:
     if x.shape[1] != 192:
         continue
-    nb = x.shape[0] // 256 * 2 + 600
-    buf = torch.zeros((nb * 8, 4), dtype=torch.int64, device=dev)
+    nb = (x.shape[0] // 256 // 8 + 64) * 8 + x.shape[0] // 256          # blocks of the launch (knn_launch: nslots * 8 + nspill)
+    buf = torch.zeros((nb * 8 * 2, 4), dtype=torch.int64, device=dev)   # 8 u64 per wave: rows 2 j hold the stamps
     for shp in (256, 256 + 32, 256 + 32 + 64, 256 + 64):     # +32: only waves 0-3 compute (one wave per SIMD); +64: no fragment reads
         buf.zero_()
         native.set_knn_workgroup(shp)
