@@ -190,6 +190,10 @@ __global__ __launch_bounds__(256, 2) void swin_attn_kernel(const float *__restri
 // half 0 split to planes first (freeing the score registers), then the score products of half 1 issued between the output products of
 // half 0, bit-identical - needs both halves' K and V fragments live: 212 VGPRs (151 us at two waves per SIMD), 180 us when forced
 // into 168 with spills.
+// Also measured and dropped: K and V handed over as bf16 hi/lo planes written by the q|k|v projection's epilogue (q columns fp32, k|v
+// columns planes; bit-identical, staging becomes a copy and a 4 x 4 transposition of 16-bit elements).  A probe with free conversions
+// promised 7 - 13 %; the real thing gives 1326 against 1408 us (no shift) / 1325 against 1351 us (shifted) per 1152 windows - the 8-byte
+// plane loads and the 16-bit shuffles cost what the conversions did - while the projection pays 2 %: nothing per frame.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define LDB 72   // bf16 elements per LDS row (64 + 8): 144-byte rows -> conflict-free 16-byte fragment reads
