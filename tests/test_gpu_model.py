@@ -793,6 +793,52 @@ def test_split_producers_match_fp32_forms():
 
 
 @pytest.mark.gpu
+def test_position_knn_tile_skipping_keeps_the_exact_neighbours(dev):
+    """The position search skips 32-candidate tiles whose bounding box is farther from the box of a wavefront's 32 queries than every
+    lane's 20th best.  Morton-sorted clustered points (where most tiles ARE skipped), dense and packed with ragged windows: every
+    returned neighbour is at least as near as the float64 20th best (up to fp32 rounding), i.e. nothing nearer was dropped."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(3)
+
+    def morton_sorted(n, scale):
+        centres = torch.rand((16, 3), generator=g) * 100
+        p = centres[torch.randint(0, 16, (n,), generator=g)] + torch.randn((n, 3), generator=g) * scale
+        q = ((p - p.min(0)[0]) / (p.max(0)[0] - p.min(0)[0] + 1e-9) * 1023).long()
+        key = torch.zeros(n, dtype=torch.long)
+        for b in range(10):
+            for c in range(3):
+                key |= ((q[:, c] >> b) & 1) << (3 * b + c)
+        return p[torch.argsort(key)].contiguous()
+
+    def check(x, got):
+        d = ref_knn_values(x[None], x.shape[0])[0]
+        k = min(20, x.shape[0])
+        kth = torch.topk(d, k, dim=1)[0][:, -1:]
+        val = torch.gather(d, 1, got[:, :k])
+        scale = (x.double() ** 2).sum(1).max()
+        assert (val >= kth - 4e-6 * scale).all()
+        assert (torch.sort(got[:, :k], 1)[0].diff(dim=1) != 0).all()          # k distinct neighbours
+
+    for n in (8192, 5000):
+        x = morton_sorted(n, 0.8)
+        got = native.knn_topk(x[None].to(dev), 20).cpu().long()[0]
+        check(x, got)
+    lengths = [8192, 300, 4097, 8192, 31]
+    rows = sum(-(-n // 512) * 512 for n in lengths)
+    xp = torch.zeros((rows, 3))
+    tab, base = [], 0
+    for n in lengths:
+        xp[base:base + n] = morton_sorted(n, 0.5)
+        tab += [[base, n]] * (-(-n // 512))
+        base += -(-n // 512) * 512
+    out = native.knn_topk_packed(xp.to(dev), torch.tensor(tab, dtype=torch.int32, device=dev)).cpu().long()
+    base = 0
+    for n in lengths:
+        check(xp[base:base + n], out[base:base + n] - base)
+        base += -(-n // 512) * 512
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C", [144, 192])
 def test_knn_f16x3_agrees_with_exact_fp32_chain(dev, C):
     """The default 144-/192-feature search (f16x3 on f16 MFMA) against the exact fp32 MFMA chain on the same input:
