@@ -190,6 +190,13 @@ __global__ __launch_bounds__(256, 2) void swin_attn_kernel(const float *__restri
 // half 0 split to planes first (freeing the score registers), then the score products of half 1 issued between the output products of
 // half 0, bit-identical - needs both halves' K and V fragments live: 212 VGPRs (151 us at two waves per SIMD), 180 us when forced
 // into 168 with spills.
+// Cycle stamps of a diagnostic build (round 2; per 64-key tile and wave, the instrumented build holds 172 registers = two waves per SIMD):
+// barriers + staging 2 470, load issue 600, score products 1 150 (24 products of one chain: 48 cycles each), softmax 2 570, output
+// products with the split of P 1 480 - 8 270 cycles where the matrix pipe needs 1 536; a wave's phases are strictly serial and two or
+// three waves per SIMD overlap them only partly (1.85 of 2 wave slots occupied on average, HW_ID + s_memtime).  Tried on that basis,
+// bit-identical, A/B on one box against this kernel (168 registers, three waves per SIMD): two sets of staged tiles with ONE barrier per
+// tile (78 KB of LDS, two workgroups per CU), plus the scores of both halves as two alternating chains and the two output halves
+// alternating - staging 1 870, scores 1 180 per tile, but 1 335 against 1 230 us per 1 152 windows: the third wave is worth more.
 // Also measured and dropped: K and V handed over as bf16 hi/lo planes written by the q|k|v projection's epilogue (q columns fp32, k|v
 // columns planes; bit-identical, staging becomes a copy and a 4 x 4 transposition of 16-bit elements).  A probe with free conversions
 // promised 7 - 13 %; the real thing gives 1326 against 1408 us (no shift) / 1325 against 1351 us (shifted) per 1152 windows - the 8-byte
