@@ -197,10 +197,10 @@ def main(argv=None, mullevel=False):
 
     mine = D.shard(files, rank, world)
     # fast path: frames are enqueued with encode_async (stage G on a side stream, two model lanes, range coder on a worker thread)
-    # and finished two frames later - what bench.py measures.  Flows that need the frame's octree after the encode (--metrics),
+    # and finished three frames later - what bench.py measures.  Flows that need the frame's octree after the encode (--metrics),
     # come from record files, or run the one-window-per-node mode stay on the synchronous call.
     pipelined = not (args.preproc_path or args.metrics or args.sequential or obj)
-    DEPTH = 2
+    DEPTH = 3
     reader = Prefetch(mine)
     pending = []
     sums = [0.0, 0.0, 0.0, 0.0, 0.0]
