@@ -301,7 +301,7 @@ def main():
             # replaces); the kernel spends three 16-bit MFMAs per product, so its own ceiling is a third of the dense 16-bit peak.
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": dom["tflops"], "peak": peak3, "unit": "TFLOP/s", "frac": dom["tflops"] / peak3,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "peak_note": "2500 TFLOP/s dense 16-bit MFMA / 3 products; the fp32 MFMA peak this replaces is 157.3",
+                         "peak_note": "2500 TFLOP/s dense 16-bit MFMA / 3 products; the fp32 MFMA peak this replaces is 157.3.  With all 256 CUs multiplying the clock settles at 1.85 GHz (tools/src/mb_power.cpp): 1.95 PFLOP/s sustained, 650 per fp32-class product",
                          "launches_per_frame": dom["launches"], "avg_launch_us": dom["avg_launch_us"], "flops_per_launch": dom["flops_per_launch"]},
         }
 
