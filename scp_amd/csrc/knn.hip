@@ -662,6 +662,8 @@ __global__ __launch_bounds__(1024) void knn_sched_kernel(const int *__restrict__
 // sets' selections in the selecting wave (both insertions every round) made it worse (6.57 / 7.97 ms): survivors are sparse, a round
 // usually serves one set.  Also dropped: two accumulation chains over even / odd feature chunks in this kernel (+4 %; the waves of a
 // SIMD run their product phases in step and already fill the matrix pipe between them).
+// Dropped (round 2, measured, lists identical): 384-query workgroups of 12 waves - three waves per SIMD at 168 registers (the compiler
+// spills 18 / 41 registers for K = 144 / 192; schedule table in 384-query blocks): 5.41 / 8.80 ms against 4.86 / 6.03 ms.
 // Dropped (round 2, measured): pass 1 of tile s dealt between the products of tile s + 1 (one candidate behind every second product,
 // order fenced with sched_barrier; +16 accumulator registers, no spills).  Identical lists; the fused block took 3130 cycles against
 // 2575 for the products alone, the remaining selection 1820 against 2620: 5 % fewer busy cycles per wave, but the launch went from
