@@ -1023,8 +1023,9 @@ static int knn_mode() {   // 1 = f16x3 (default), 0 = exact fp32 MFMA (SCP_KNN=f
     return g_knn_mode;
 }
 extern "C" SCP_API int scp_set_knn_mode(int32_t f16x3) { g_knn_mode = f16x3 ? 1 : 0; return SCP_OK; }
-// workgroup shape of the packed f16x3 search: 256 queries on the XCD schedule with the half-step stagger (default), SCP_KNN_WG=257: the
-// same without the stagger, SCP_KNN_WG=128: the 128-query kernel in launch order (the three give identical neighbour lists)
+// workgroup shape of the packed f16x3 search: 256 = 256-query workgroups on the XCD schedule, a barrier per group of 3 / 4 tiles (default);
+// SCP_KNN_WG=257 / 258: groups of two tiles / one tile; +16: outward sweep order; 128: the 128-query kernel in launch order (all give
+// identical neighbour lists)
 static int g_knn_wg = -1;
 static int knn_wg() { if (g_knn_wg < 0) { const char *e = getenv("SCP_KNN_WG"); g_knn_wg = e ? atoi(e) : 256; } return g_knn_wg; }
 extern "C" SCP_API int scp_set_knn_workgroup(int32_t v) { g_knn_wg = v; return SCP_OK; }

@@ -94,8 +94,8 @@ def test_knn_exact_order_under_heavy_ties(dev, n, C, span):
 
 
 def test_knn_packed_workgroup_shapes_agree_on_ragged_windows(dev):
-    """The packed f16x3 search in its three workgroup shapes (256 queries on the XCD schedule with / without the stagger, 128 queries in
-    launch order) and the dense per-window entry point return the SAME lists: ragged windows (1 ... 8192 rows), heavily tied
+    """The packed f16x3 search in its workgroup shapes (256 queries on the XCD schedule with a barrier per group of 3 - 4 / 2 / 1 tiles,
+    front-to-back or outward sweep; 128 queries in launch order) and the dense per-window entry point return the SAME lists: ragged windows (1 ... 8192 rows), heavily tied
     integer features, 144 and 192 features."""
     from scp_amd import native
     lengths = [1, 7, 20, 33, 300, 513, 2049, 8192, 600, 5000]

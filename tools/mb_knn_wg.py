@@ -1,5 +1,5 @@
 """Workgroup shapes of the packed f16x3 kNN on the frame's own three searches: 128-query kernel vs 256-query XCD-scheduled kernel
-(with / without the half-step stagger).  Interleaved rounds in one process; neighbour lists must be identical."""
+(MB_SHAPES=128,256,...).  Interleaved rounds in one process; neighbour lists must be identical."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from cfgs import ehem_cfg
