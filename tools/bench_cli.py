@@ -20,6 +20,6 @@ with tempfile.TemporaryDirectory() as tmp:
 b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-baseline", "none", "--steps", str(n - 3), "--warmup", "3"], capture_output=True, text=True)
 bench = json.loads(b.stdout.strip().splitlines()[-1])
 out = dict(frames=n, cli_frames_per_s=cli_fps, cli_ms_per_frame=1e3 / cli_fps, bench_frames_per_s=bench["value"], bench_ms_per_frame=bench["ms_per_step"],
-           cli_over_bench=cli_fps / bench["value"], note="CLI: .bin files read and parsed on a reader thread, frames pipelined two deep, .bin/.dat/.scp.json written; "
-           "bench.py: frames resident in HBM, three in flight")
+           cli_over_bench=cli_fps / bench["value"], note="CLI: .bin files read and parsed on a reader thread, frames pipelined three deep, .bin/.dat/.scp.json written; "
+           "bench.py: frames resident in HBM, four in flight")
 print(json.dumps(out))
