@@ -16,7 +16,10 @@
 // residual): results are bit-identical.  LDS: 2 x 48 KiB stages + 64 KiB H image (reused as the epilogue bounce) = 160 KiB.
 // Measured and dropped: 128-hidden chunks with three 32 KiB stages two steps ahead (8 passes over the activation tile: 6 - 9 %
 // slower), GELU of the second chunk in the MFMA shadow of the first chunk's phase 2 (58 spilled registers, no gain), packed-fp32
-// GELU (no gain), nt cache policy on either stream (13 - 20 % slower).
+// GELU (no gain), nt cache policy on either stream (13 - 20 % slower).  Round 2: the compiler issues the 12 dependent packed FMAs of a
+// GELU polynomial back to back with an s_nop each (12.3 cycles per instruction and wave, tools/src/mb_valu_dep.cpp); two pairs' chains
+// alternated with volatile asm (bit-identical) take the GELU phase from 34.9 k to 32.7 k cycles per tile - and the barrier waits from
+// 49.6 k to 54.3 k: 1.958 against 1.968 ms per 577 536-row launch.  The tile is paced by its barriers, not by the waves' busy time.
 #include <stdlib.h>
 #include "scp_internal.h"
 
