@@ -208,10 +208,15 @@ SCP_API int scp_linear_f16x3_scaled(const float *A, int64_t lda, const void *Whi
                                     const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, int32_t M, int32_t N,
                                     int32_t K, int32_t act, const float *scale, const float *inv_scale, void *stream);
 
+/* weight plane [Npad][Kpad] (row-major bf16, scp_split_weight_bf16) -> tiled: 1 KiB blocks ordered [16-row group][32-element k-slab],
+ * each block the LDS image of one LDS-DMA instruction (row r at bytes 64 r, its 16-byte chunk q at position q ^ ((r >> 2) & 3)). */
+SCP_API int scp_tile_weight_bf16(const void *plane, int32_t Npad, int32_t Kpad, void *tiled, void *stream);
 /* The same dense layer with the ACTIVATION pre-split too: A arrives as bf16 planes hi/lo [M][lda] (lda % 8 == 0, lda >= Kpad,
  * columns K..Kpad zero) written by the producing kernel (scp_split_rows, scp_layernorm_rows_split, the attention kernels, or this
  * function's own split output), so operand tiles go global -> LDS by LDS-DMA with no conversion.  Outputs: C fp32 [M][ldc]
- * and/or planes Ohi/Olo [M][ldo] (columns N..round32(N) zero filled).  Weight planes must be padded to Npad % 256 == 0.
+ * and/or planes Ohi/Olo [M][ldo] (columns N..round32(N) zero filled).  Weight planes must be padded to Npad % 256 == 0 and are
+ * expected in the TILED layout of scp_tile_weight_bf16 (all scp_linear_split* entry points and scp_mlp_split_fused; the environment
+ * variable SCP_WTILE=0 switches the library to row-major [Npad][Kpad] planes, for A/B measurements).
  * cfg: 0 automatic, 1 = 256 x 256 tile, 2 = 256 x 128 tile.  Results are bit-identical to scp_linear_bf16x3 on the same values.
  *   scp_split_rows: fp32 rows -> planes, optionally gathered: out[r] = split(src[idx ? idx[r] : r]); idx == n_src -> zero row */
 SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,

@@ -80,6 +80,7 @@ struct GemmSplitArgs {
     int M, N;
     int vec_ok;                                  // fp32 rows of C / residual are 16-byte aligned
     int ncols_out;                               // split output: columns written (N rounded up to 32, <= ldo): zero filled beyond N
+    int wtiled;                                  // weight planes in the tiled layout (default) / row-major [Npad][Kpad] (SCP_WTILE=0)
 };
 
 // EXT: the epilogue extensions (gathered residual before the activation, scattered output rows) are compiled only into the
@@ -136,7 +137,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int cr = w + NW * j;
-            const int64_t off = (int64_t)(n0 + 16 * cr + d_row) * a.Kpad + k0;
+            // weight planes are TILED (native._tile_planes): block (16-row group, 32-element k-slab) = the 1 KiB LDS image of one DMA
+            // instruction, consecutive in memory, blocks ordered [row group][k-slab]
+            const int64_t off = a.wtiled ? ((int64_t)((n0 >> 4) + cr) * (a.Kpad >> 5) + kt) * 512 + lane * 8 : (int64_t)(n0 + 16 * cr + d_row) * a.Kpad + k0;
             dma16(a.Whi + off, base + OFF_BH + cr * 1024);
             dma16(a.Wlo + off, base + OFF_BL + cr * 1024);
         }
@@ -366,6 +369,31 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
     *(bf16x4 *)(lo + r * ldo + 4 * c) = vl;
 }
 
+// weight plane [Npad][Kpad] (row-major, bf16) -> the TILED layout the LDS-DMA loops stream: blocks of 1 KiB ordered [16-row group][32-element
+// k-slab], each block the LDS image of one DMA instruction - row r of the group at bytes 64 r, its logical 16-byte chunk q at position
+// q ^ ((r >> 2) & 3) (the read swizzle of the fragment loads).  One DMA instruction then reads eight whole cache lines instead of sixteen
+// half lines: with every CU streaming, 48 KiB land in 1 190 instead of 2 020 cycles (tools/src/mb_lds_fill.cpp).
+__global__ __launch_bounds__(256) void tile_weight_kernel(const uint4 *__restrict__ src, int Npad, int Kpad, uint4 *__restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // destination chunk (16 bytes = 8 elements)
+    const int64_t total = (int64_t)Npad * Kpad / 8;
+    if (i >= total) return;
+    const int p = (int)(i & 3), r = (int)((i >> 2) & 15);
+    const int64_t blk = i >> 6;
+    const int nks = Kpad >> 5;
+    const int ks = (int)(blk % nks);
+    const int64_t rb = blk / nks;
+    const int q = p ^ ((r >> 2) & 3);
+    dst[i] = src[((rb * 16 + r) * (int64_t)Kpad + 32 * ks + 8 * q) >> 3];
+}
+
+extern "C" SCP_API int scp_tile_weight_bf16(const void *plane, int32_t Npad, int32_t Kpad, void *tiled, void *stream) {
+    if (!plane || !tiled || Npad <= 0 || Kpad <= 0 || (Npad & 15) || (Kpad & 31) || (((uintptr_t)plane | (uintptr_t)tiled) & 15)) return SCP_EINVAL;
+    const int64_t total = (int64_t)Npad * Kpad / 8;
+    hipLaunchKernelGGL(tile_weight_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)plane, Npad, Kpad, (uint4 *)tiled);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
 extern "C" SCP_API int scp_split_rows(const float *src, int64_t ld_src, int64_t n_src, const int64_t *idx, int32_t C, void *hi, void *lo,
                                       int64_t ldo, int64_t rows, void *stream) {
     if (!src || !hi || !lo || rows < 0 || C <= 0 || (C & 3) || (ld_src & 3) || (ldo & 7) || ldo < C || (((uintptr_t)src) & 15) ||
@@ -433,6 +461,7 @@ static int linear_split_impl(const void *Ahi, const void *Alo, int64_t lda, cons
     int nco = (N + 31) & ~31;
     if (nco > ldo) nco = (N + 3) & ~3;
     ga.ncols_out = nco;
+    { static int wt = -1; if (wt < 0) { const char *e = getenv("SCP_WTILE"); wt = (e && e[0] == '0') ? 0 : 1; } ga.wtiled = wt; }
     if (cfg & ~0xff) {
         // timing probes of tools/mb_gemm_split.py (RESULTS ARE WRONG with them): 0x10000 = every activation row reads row 0 (operands
         // cache resident), 0x20000 = no output traffic.  Only honoured when SCP_GEMM_PROBE is set; an error otherwise.

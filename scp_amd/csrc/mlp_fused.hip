@@ -64,6 +64,7 @@ struct MlpArgs {
     const float *res; int64_t ldr;               // fp32 [M][ldr] or null
     float *C; int64_t ldc;
     int M;
+    int wtiled;                                  // W planes tiled (default) / row-major (SCP_WTILE=0)
 };
 
 #define MBM 128
@@ -94,17 +95,20 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const MlpArgs a, unsi
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int cr = w + 8 * j;                          // 16-row chunk of the 256 hidden rows
-                const int64_t wo = (int64_t)(sc * 256 + 16 * cr + d_row) * 256 + k0;
+                // W1 planes are TILED (scp_tile_weight_bf16): block (16-row group, 32-element k-slab) = the 1 KiB LDS image of one DMA
+                // instruction, consecutive in memory - eight whole cache lines per instruction instead of sixteen half lines
+                const int64_t wo = a.wtiled ? ((int64_t)(sc * 16 + cr) * 8 + t) * 512 + lane * 8 : (int64_t)(sc * 256 + 16 * cr + d_row) * 256 + k0;
                 mlp_dma16(a.W1hi + wo, base + 16384 + cr * 1024);
                 mlp_dma16(a.W1lo + wo, base + 32768 + cr * 1024);
             }
         } else {
             const int c = 2 * sc + ((t - 8) >> 2);
-            const int k0 = c * 128 + ((t - 8) & 3) * 32 + 8 * d_q;
+            const int k0s = c * 128 + ((t - 8) & 3) * 32;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int cr = w + 8 * j;
-                const int64_t wo = (int64_t)(16 * cr + d_row) * 1024 + k0;
+                const int64_t wo = a.wtiled ? ((int64_t)cr * 32 + (k0s >> 5)) * 512 + lane * 8      // tiled W2 planes: [16 row groups][32 k-slabs][1 KiB]
+                                            : (int64_t)(16 * cr + d_row) * 1024 + k0s + 8 * d_q;
                 mlp_dma16(a.W2hi + wo, base + cr * 1024);
                 mlp_dma16(a.W2lo + wo, base + 16384 + cr * 1024);
             }
@@ -317,6 +321,7 @@ extern "C" SCP_API int scp_mlp_split_fused(const void *Xhi, const void *Xlo, int
     a.Xhi = (const __bf16 *)Xhi; a.Xlo = (const __bf16 *)Xlo; a.ldx = ldx;
     a.W1hi = (const __bf16 *)W1hi; a.W1lo = (const __bf16 *)W1lo; a.W2hi = (const __bf16 *)W2hi; a.W2lo = (const __bf16 *)W2lo;
     a.b1 = b1; a.b2 = b2; a.res = residual; a.ldr = ldr; a.C = C; a.ldc = ldc; a.M = M;
+    { static int wt = -1; if (wt < 0) { const char *e = getenv("SCP_WTILE"); wt = (e && e[0] == '0') ? 0 : 1; } a.wtiled = wt; }
     const int ntiles = (M + MBM - 1) / MBM;
     const unsigned grid = (unsigned)(ntiles < g_mlp_num_cu ? ntiles : g_mlp_num_cu);
     if (g_mlp_dbg) hipLaunchKernelGGL(mlp_fused_kernel<true>, dim3(grid), dim3(512), LDS, (hipStream_t)stream, a, g_mlp_dbg);

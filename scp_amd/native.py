@@ -95,6 +95,7 @@ def lib():
         "scp_linear_f16x3": (C.c_int, [_vp, i64, _vp, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp, _vp]),
         "scp_linear_split": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_mlp_split_fused": (C.c_int, [_vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp, i64, i32, _vp]),
+        "scp_tile_weight_bf16": (C.c_int, [_vp, i32, i32, _vp, _vp]),
         "scp_split_rows": (C.c_int, [_vp, i64, i64, _vp, i32, _vp, _vp, i64, i64, _vp]),
         "scp_linear_split_scatter": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_linear_split_gather": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
@@ -456,7 +457,19 @@ class SplitWeight:
         wc = w.detach().contiguous().float()
         _check(lib().scp_split_weight_bf16(_dev(wc), N, K, self.Npad, self.Kpad, _dev(self.hi), _dev(self.lo), _stream()),
                "scp_split_weight_bf16")
+        self._tiled = None
         note_cache_fill()
+
+    def tiled(self):
+        """(hi, lo) in the tiled layout of _tile_planes (built once): what the LDS-DMA kernels stream (SCP_WTILE=0: row-major)."""
+        if os.environ.get("SCP_WTILE", "1")[:1] == "0":
+            return (self.hi, self.lo)
+        if self._tiled is None:
+            th, tl = torch.empty_like(self.hi), torch.empty_like(self.lo)
+            for src, dst in ((self.hi, th), (self.lo, tl)):
+                _check(lib().scp_tile_weight_bf16(src.data_ptr(), self.Npad, self.Kpad, dst.data_ptr(), _stream()), "scp_tile_weight_bf16")
+            self._tiled = (th, tl)
+        return self._tiled
 
 
 def linear_bf16x3(x, sw, bias=None, act=ACT_NONE, residual=None, out=None):
@@ -482,6 +495,18 @@ def linear_bf16x3(x, sw, bias=None, act=ACT_NONE, residual=None, out=None):
                                  o2.stride(0), M, N, K, act, _stream())
     _check(rc, "scp_linear_bf16x3")
     return out.reshape(*lead, N) if out.dim() == 2 and len(lead) != 1 else out
+
+
+def _tile_planes(t):
+    """bf16 plane [Npad, Kpad] -> the tiled layout the LDS-DMA kernels read: block (16-row group rb, 32-element k-slab ks) = 1 KiB =
+    the LDS image of one DMA instruction, [r][p][8] with the logical 16-byte chunk p ^ ((r >> 2) & 3) of row r at position p (the
+    read swizzle of csrc/gemm_split.hip), blocks ordered [rb][ks]."""
+    N, K = t.shape
+    v = t.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 1, 3, 4)                    # [rb, ks, r, q, e]
+    r = torch.arange(16, device=t.device)
+    q = (torch.arange(4, device=t.device)[None, :] ^ ((r[:, None] >> 2) & 3))        # [r, p] -> source chunk
+    idx = q[None, None, :, :, None].expand(N // 16, K // 32, 16, 4, 8)
+    return torch.gather(v, 3, idx).contiguous()
 
 
 class SplitWeightF16:
@@ -597,7 +622,7 @@ def linear_split_scatter(a, sw, bias, out_map, table, act=ACT_NONE, cfg=0):
                 note_cache_fill()
             bias = pb[1]
         N = Np
-    _check(lib().scp_linear_split_scatter(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.Npad, sw.Kpad,
+    _check(lib().scp_linear_split_scatter(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw.tiled()[0].data_ptr(), sw.tiled()[1].data_ptr(), sw.Npad, sw.Kpad,
                                           _opt(bias), _dev(out_map, torch.int64), table.data_ptr(), table.stride(0), a.M, N, sw.K, act, cfg,
                                           _stream()), "scp_linear_split_scatter")
 
@@ -631,7 +656,7 @@ def linear_split(a, sw, bias=None, act=ACT_NONE, residual=None, out=None, out_sp
     r2 = residual
     if res_map is not None or res_first:
         # out[m] = act(a[m] . W^T + bias + residual[res_map[m]]): gathered residual, added before the activation
-        rc = lib().scp_linear_split_gather(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.Npad, sw.Kpad,
+        rc = lib().scp_linear_split_gather(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw.tiled()[0].data_ptr(), sw.tiled()[1].data_ptr(), sw.Npad, sw.Kpad,
                                            _opt(bias), None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0),
                                            None if res_map is None else _dev(res_map, torch.int64),
                                            None if c is None else c.data_ptr(), 0 if c is None else c.stride(0),
@@ -639,7 +664,7 @@ def linear_split(a, sw, bias=None, act=ACT_NONE, residual=None, out=None, out_sp
                                            0 if o is None else o.t.stride(1), M, N, K, act, cfg, _stream())
         _check(rc, "scp_linear_split_gather")
         return c if want == "f32" else (o if want == "split" else (c, o))
-    rc = lib().scp_linear_split(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.Npad, sw.Kpad, _opt(bias),
+    rc = lib().scp_linear_split(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw.tiled()[0].data_ptr(), sw.tiled()[1].data_ptr(), sw.Npad, sw.Kpad, _opt(bias),
                                 None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0),
                                 None if c is None else c.data_ptr(), 0 if c is None else c.stride(0),
                                 None if o is None else o.t[0].data_ptr(), None if o is None else o.t[1].data_ptr(),
@@ -654,8 +679,9 @@ def mlp_split_fused(a, sw1, b1, sw2, b2, residual=None):
         raise ScpError("mlp_split_fused: 256 -> 1024 -> 256 only")
     t = a.t
     c = torch.empty((a.M, 256), dtype=torch.float32, device=t.device)
-    rc = lib().scp_mlp_split_fused(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), sw1.hi.data_ptr(), sw1.lo.data_ptr(), sw2.hi.data_ptr(),
-                                   sw2.lo.data_ptr(), _dev(b1), _dev(b2), None if residual is None else residual.data_ptr(),
+    t1, t2 = sw1.tiled(), sw2.tiled()
+    rc = lib().scp_mlp_split_fused(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), t1[0].data_ptr(), t1[1].data_ptr(), t2[0].data_ptr(),
+                                   t2[1].data_ptr(), _dev(b1), _dev(b2), None if residual is None else residual.data_ptr(),
                                    0 if residual is None else residual.stride(0), c.data_ptr(), c.stride(0), a.M, _stream())
     _check(rc, "scp_mlp_split_fused")
     return c

@@ -793,6 +793,31 @@ def test_split_producers_match_fp32_forms():
 
 
 @pytest.mark.gpu
+def test_tiled_weight_planes(dev):
+    """scp_tile_weight_bf16 against the layout written out in Python (native._tile_planes), and the split-operand layers / the fused MLP on
+    tiled planes (default) against a process with SCP_WTILE=0 (row-major planes): identical bits."""
+    import subprocess, sys
+    from scp_amd import native
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn((300, 600), generator=g).to(dev)
+    sw = native.SplitWeight(w)
+    th, tl = sw.tiled()
+    assert torch.equal(th.view(-1), native._tile_planes(sw.hi).view(-1)) and torch.equal(tl.view(-1), native._tile_planes(sw.lo).view(-1))
+    code = ("import torch, hashlib, sys; sys.path.insert(0, %r); from scp_amd import native; dev = torch.device('cuda:0'); g = torch.Generator().manual_seed(9);"
+            "x = torch.randn((1000, 256), generator=g).to(dev); w1 = (torch.randn((1024, 256), generator=g) / 16).to(dev); b1 = torch.randn(1024, generator=g).to(dev);"
+            "w2 = (torch.randn((256, 1024), generator=g) / 32).to(dev); b2 = torch.randn(256, generator=g).to(dev); a = native.split_rows(x);"
+            "s1, s2 = native.SplitWeight(w1), native.SplitWeight(w2);"
+            "c = native.mlp_split_fused(a, s1, b1, s2, b2, residual=x); d = native.linear_split(a, s1, b1, act=native.ACT_LEAKY);"
+            "print(hashlib.sha256(c.cpu().numpy().tobytes() + d.cpu().numpy().tobytes()).hexdigest())") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for wt in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SCP_WTILE=wt))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(outs[0]) == 64
+
+
+@pytest.mark.gpu
 def test_position_knn_tile_skipping_keeps_the_exact_neighbours(dev):
     """The position search skips 32-candidate tiles whose bounding box is farther from the box of a wavefront's 32 queries than every
     lane's 20th best.  Morton-sorted clustered points (where most tiles ARE skipped), dense and packed with ragged windows: every

@@ -9,6 +9,67 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ROWS variant: the access pattern of mlp_fused.hip / gemm_split.hip - one DMA instruction reads 16 rows x 64 B (a 32-element k-slab
+// of 16 rows of a [N][256] bf16 plane: row stride 512 B) instead of 1 KiB of consecutive bytes
+template <int STEP_KB>
+__global__ __launch_bounds__(512, 2) void fill_rows_kernel(const char *__restrict__ src, size_t src_bytes, int steps, unsigned long long *cyc, float *sink, int desync) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int STEP = STEP_KB * 1024;
+    constexpr int PER_WAVE = STEP / 8 / 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float acc = 0.f;
+    // the "matrix": rows of 512 B; a step = k-slab ks (64 B of every row) of 16 * 8 * PER_WAVE rows; slabs 0..7 then the next row block
+    const int rows_per_step = 16 * 8 * PER_WAVE;
+    const size_t nrows = src_bytes / 512;
+    const int phase = desync ? (int)((blockIdx.x * 37u) % 61u) : 0;       // workgroups at different positions of the weight stream
+    auto issue = [&](int s) {
+        const int sp = s + phase;
+        const int ks = sp & 7;
+        const size_t row0 = ((size_t)(sp >> 3) * rows_per_step) % (nrows - rows_per_step);
+        char *l = smem + (s & 1) * STEP;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int piece = w * PER_WAVE + j;
+            const size_t row = row0 + piece * 16 + (lane >> 2);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + row * 512 + ks * 64 + (lane & 3) * 16), (lds_ptr_t)(l + piece * 1024), 16, 0, 0);
+        }
+    };
+    issue(0);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int s = 0; s < steps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue(s + 1);
+        acc += *(const float *)(smem + (s & 1) * STEP + tid * 4);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (lane == 0) cyc[blockIdx.x * 8 + w] = t1 - t0;
+    if (acc == 123.456f) sink[0] = acc;
+}
+
+template <int STEP_KB>
+static void run_rows(const char *src, size_t bytes, int blocks, unsigned long long *cyc, float *sink, int desync) {
+    const int steps = 400;
+    const int lds = 2 * STEP_KB * 1024;
+    (void)hipFuncSetAttribute((const void *)fill_rows_kernel<STEP_KB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((fill_rows_kernel<STEP_KB>), dim3(blocks), dim3(512), lds, 0, src, bytes, steps, cyc, sink, desync);
+        (void)hipEventRecord(e1);
+        (void)hipDeviceSynchronize();
+    }
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    static unsigned long long h[256 * 8];
+    (void)hipMemcpy(h, cyc, sizeof(unsigned long long) * blocks * 8, hipMemcpyDeviceToHost);
+    double m = 0; for (int i = 0; i < blocks * 8; ++i) m += (double)h[i];
+    m /= blocks * 8;
+    const double bytes_per_cu = (double)steps * STEP_KB * 1024;
+    printf("rows 16x64B%s step %2d KiB, %3d workgroups: %7.0f cycles per step, %6.1f GB/s per CU by wall clock, %6.2f TB/s aggregate\n", desync ? " desync" : "       ",
+           STEP_KB, blocks, m / steps, bytes_per_cu / (ms * 1e-3) / 1e9, bytes_per_cu * blocks / (ms * 1e-3) / 1e12);
+}
+
 template <int STEP_KB, bool DMA>
 __global__ __launch_bounds__(512, 2) void fill_kernel(const char *__restrict__ src, size_t src_bytes, int steps, unsigned long long *cyc, float *sink) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -77,6 +138,8 @@ int main() {
     const size_t bytes = 2u << 20;                      // 2 MiB: resident in every XCD's L2 after the first pass
     char *src; unsigned long long *cyc; float *sink;
     hipMalloc(&src, bytes); hipMemset(src, 1, bytes); hipMalloc(&cyc, 8 * 256 * 8); hipMalloc(&sink, 4);
+    for (int d : {0, 1}) { run_rows<32>(src, bytes, 256, cyc, sink, d); run_rows<48>(src, bytes, 256, cyc, sink, d); }
+    run_rows<48>(src, bytes, 1, cyc, sink, 0);
     for (int blocks : {256, 1}) {
         run<16, true>(src, bytes, blocks, cyc, sink);  run<16, false>(src, bytes, blocks, cyc, sink);
         run<32, true>(src, bytes, blocks, cyc, sink);  run<32, false>(src, bytes, blocks, cyc, sink);
