@@ -183,7 +183,8 @@ SCP_API int scp_swin_attention(const float *q, const float *k, const float *v, c
 /* Dense layer C = epilogue(A . W^T) on bf16 MFMA with fp32-class accuracy ("bf16x3": x = hi + lo, three products, fp32
  * accumulate; replaces the nn.Linear calls of models/ehem.py / swin_transformer.py:448-452,511,559,571).
  *   scp_split_weight_bf16: W fp32 [N][K] -> bf16 planes hi/lo [Npad][Kpad] (Npad % 256 == 0, Kpad % 32 == 0, zero padded)
- *   scp_linear_bf16x3    : A fp32 [M][lda] (K % 4 == 0), planes from above, optional bias[N], residual[M][ldr];
+ *   scp_linear_bf16x3    : A fp32 [M][lda] (K % 4 == 0), the planes from above passed through scp_tile_weight_bf16 (every dense entry point
+ *                          of this library streams TILED weight planes; SCP_WTILE=0: row-major), optional bias[N], residual[M][ldr];
  *                          act: 0 none, 1 LeakyReLU(0.01), 2 GELU(erf), 3 ReLU;  C fp32 [M][ldc]                        */
 SCP_API int scp_split_weight_bf16(const float *W, int32_t N, int32_t K, int32_t Npad, int32_t Kpad, void *hi, void *lo, void *stream);
 SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void *Whi, const void *Wlo, int32_t Kpad, const float *bias,

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__rest
                                                             const __bf16 *__restrict__ Wlo, int Kpad, const float *__restrict__ bias,
                                                             const float *__restrict__ res, int64_t ldr, float *__restrict__ C, int64_t ldc,
                                                             int M, int N, int K, const float *__restrict__ asc,
-                                                            const float *__restrict__ iasc, const float *__restrict__ iwsc) {
+                                                            const float *__restrict__ iasc, const float *__restrict__ iwsc, int wtiled) {
     // two LDS stages x four 16-bit planes (A hi, A lo, B hi, B lo) = 2 x 40 KiB: exactly two workgroups per CU
     __shared__ __attribute__((aligned(16))) __bf16 lds[2][4][BM * LDP];
 
@@ -112,7 +112,11 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__rest
                                                                                   // here would make the wave wait for the load at once
         }
         {
-            const int64_t off = (int64_t)(n0 + b_r) * Kpad + k0 + 8 * b_c;   // planes are padded: always in range
+            // planes are padded: always in range.  wtiled: the tiled planes of scp_tile_weight_bf16 (1 KiB blocks [16-row group][k-slab], chunk
+            // q of row r at position q ^ ((r >> 2) & 3)): a wavefront's 64 loads then cover whole cache lines
+            const int wr = n0 + b_r;
+            const int64_t off = wtiled ? (((int64_t)(wr >> 4) * (Kpad >> 5) + kt) * 64 + (wr & 15) * 4 + (b_c ^ ((wr >> 2) & 3))) * 8
+                                       : (int64_t)wr * Kpad + k0 + 8 * b_c;
             pbh[0] = *(const bf16x8 *)(Whi + off);
             pbl[0] = *(const bf16x8 *)(Wlo + off);
         }
@@ -254,6 +258,8 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_kernel(const float *__rest
     }
 }
 
+static int gemm_wtiled() { static int wt = -1; if (wt < 0) { const char *e = getenv("SCP_WTILE"); wt = (e && e[0] == '0') ? 0 : 1; } return wt; }
+
 // split an fp32 weight [N][K] into zero-padded bf16 planes [Npad][Kpad]
 __global__ void split_weight_kernel(const float *__restrict__ W, int N, int K, int Npad, int Kpad, __bf16 *__restrict__ hi,
                                     __bf16 *__restrict__ lo) {
@@ -283,7 +289,7 @@ extern "C" SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void
         return SCP_EINVAL;
     const dim3 grid((unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM)));
 #define GO(ACT) hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT, false>), grid, dim3(512), 0, (hipStream_t)stream, A, lda, (const __bf16 *)Whi, \
-                              (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K, nullptr, nullptr, nullptr)
+                              (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K, nullptr, nullptr, nullptr, gemm_wtiled())
     switch (act) { case ACT_LEAKY: GO(ACT_LEAKY); break; case ACT_GELU: GO(ACT_GELU); break; case ACT_RELU: GO(ACT_RELU); break; default: GO(ACT_NONE); }
 #undef GO
     LAUNCH_CHECK();
@@ -373,7 +379,7 @@ static int linear_f16x3_launch(const float *A, int64_t lda, const void *Whi, con
     if (compute_scales) hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, A, lda, M, K, sc, isc);
     const dim3 grid((unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM)));
 #define GO(ACT) hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT, true>), grid, dim3(512), 0, (hipStream_t)stream, A, lda, (const __bf16 *)Whi, \
-                              (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K, sc, isc, w_inv_scale)
+                              (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K, sc, isc, w_inv_scale, gemm_wtiled())
     switch (act) { case ACT_LEAKY: GO(ACT_LEAKY); break; case ACT_GELU: GO(ACT_GELU); break; case ACT_RELU: GO(ACT_RELU); break; default: GO(ACT_NONE); }
 #undef GO
     LAUNCH_CHECK();

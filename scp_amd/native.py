@@ -461,15 +461,8 @@ class SplitWeight:
         note_cache_fill()
 
     def tiled(self):
-        """(hi, lo) in the tiled layout of _tile_planes (built once): what the LDS-DMA kernels stream (SCP_WTILE=0: row-major)."""
-        if os.environ.get("SCP_WTILE", "1")[:1] == "0":
-            return (self.hi, self.lo)
-        if self._tiled is None:
-            th, tl = torch.empty_like(self.hi), torch.empty_like(self.lo)
-            for src, dst in ((self.hi, th), (self.lo, tl)):
-                _check(lib().scp_tile_weight_bf16(src.data_ptr(), self.Npad, self.Kpad, dst.data_ptr(), _stream()), "scp_tile_weight_bf16")
-            self._tiled = (th, tl)
-        return self._tiled
+        """(hi, lo) in the tiled layout of _tile_planes (built once): what the dense kernels stream (SCP_WTILE=0: row-major)."""
+        return _tiled_pair(self)
 
 
 def linear_bf16x3(x, sw, bias=None, act=ACT_NONE, residual=None, out=None):
@@ -490,11 +483,23 @@ def linear_bf16x3(x, sw, bias=None, act=ACT_NONE, residual=None, out=None):
     r2 = None
     if residual is not None:
         r2 = residual.reshape(-1, N) if residual.is_contiguous() else residual.contiguous().reshape(-1, N)
-    rc = lib().scp_linear_bf16x3(x2.data_ptr(), x2.stride(0), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.Kpad, _opt(bias),
+    wt = _tiled_pair(sw)
+    rc = lib().scp_linear_bf16x3(x2.data_ptr(), x2.stride(0), wt[0].data_ptr(), wt[1].data_ptr(), sw.Kpad, _opt(bias),
                                  None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0), o2.data_ptr(),
                                  o2.stride(0), M, N, K, act, _stream())
     _check(rc, "scp_linear_bf16x3")
     return out.reshape(*lead, N) if out.dim() == 2 and len(lead) != 1 else out
+
+
+def _tiled_pair(sw):
+    if os.environ.get("SCP_WTILE", "1")[:1] == "0":
+        return (sw.hi, sw.lo)
+    if getattr(sw, "_tiled", None) is None:
+        th, tl = torch.empty_like(sw.hi), torch.empty_like(sw.lo)
+        for src, dst in ((sw.hi, th), (sw.lo, tl)):
+            _check(lib().scp_tile_weight_bf16(src.data_ptr(), sw.Npad, sw.Kpad, dst.data_ptr(), _stream()), "scp_tile_weight_bf16")
+        sw._tiled = (th, tl)
+    return sw._tiled
 
 
 def _tile_planes(t):
@@ -566,13 +571,13 @@ def linear_f16x3(x, sw, bias=None, act=ACT_NONE, residual=None, scales=None):
     if scales is not None:
         if scales.sc.shape[0] != M:
             raise ScpError("linear_f16x3: row scales of another row count")
-        rc = lib().scp_linear_f16x3_scaled(x2.data_ptr(), x2.stride(0), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.inv_scale.data_ptr(), sw.Kpad,
+        rc = lib().scp_linear_f16x3_scaled(x2.data_ptr(), x2.stride(0), _tiled_pair(sw)[0].data_ptr(), _tiled_pair(sw)[1].data_ptr(), sw.inv_scale.data_ptr(), sw.Kpad,
                                            _opt(bias), None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0), out.data_ptr(),
                                            out.stride(0), M, N, K, act, scales.sc.data_ptr(), scales.isc.data_ptr(), _stream())
         _check(rc, "scp_linear_f16x3_scaled")
         return out.reshape(*lead, N)
     ws = torch.empty((2 * M,), dtype=torch.float32, device=x.device)
-    rc = lib().scp_linear_f16x3(x2.data_ptr(), x2.stride(0), sw.hi.data_ptr(), sw.lo.data_ptr(), sw.inv_scale.data_ptr(), sw.Kpad,
+    rc = lib().scp_linear_f16x3(x2.data_ptr(), x2.stride(0), _tiled_pair(sw)[0].data_ptr(), _tiled_pair(sw)[1].data_ptr(), sw.inv_scale.data_ptr(), sw.Kpad,
                                 _opt(bias), None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0), out.data_ptr(),
                                 out.stride(0), M, N, K, act, ws.data_ptr(), _stream())
     _check(rc, "scp_linear_f16x3")
