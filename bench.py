@@ -2,7 +2,9 @@
 """Headline benchmark: KITTI-like frames/s encode, SCP-EHEM, lidar_level 16 --spher --mullevel (BASELINE.json configs[2]).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...            (starts N ranks itself: a child `python -m torch.distributed.run`, before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --all-configs            (the five BASELINE.json configurations, one JSON line each, into profiles/ with --out-dir)
 
 One step = one synthetic 120 000-point frame through the whole hot path on one GPU: quantiser (3 shells) -> octree
 serialisation -> context tables -> EHEM over every <= 8192-node window -> softmax/integer CDF -> range coder.  The frame
@@ -38,7 +40,42 @@ def parse():
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=4, help="frames in flight (encode_async handles not yet finished); 4 measured 1.2 % above 3, 5 no better")
+    ap.add_argument("--host-transform", action="store_true", help="strict-identity mode: numpy float32 transform + quantiser on the host (inside the timed region)")
+    ap.add_argument("--all-configs", action="store_true", help="run every configuration of CONFIGS in turn (child processes), one JSON line each")
+    ap.add_argument("--out-dir", default=None, help="with --all-configs: also write <out-dir>/<tag>_bench_<config>.json")
+    ap.add_argument("--tag", default="r3", help="file-name prefix used with --out-dir")
     return ap.parse_args()
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` outside a torchrun environment: N ranks (one per GPU) as a CHILD `python -m torch.distributed.run`,
+    started before this process has touched the GPU; its exit code is ours and rank 0's JSON line passes through on stdout."""
+    from scp_amd.cli import spawn_ranks as _spawn
+    return _spawn(n, os.path.abspath(__file__), argv)
+
+
+def run_all_configs(args, argv):
+    """One child process per configuration (a fresh process per run keeps lanes, caches and allocator state apart)."""
+    import subprocess
+    rest = [a for a in argv if a != "--all-configs"]
+    for drop in ("--config", "--out-dir", "--tag"):
+        while drop in rest:
+            i = rest.index(drop)
+            del rest[i:i + 2]
+    rc = 0
+    for name in ("ehem-L16-m", "ehem-L12-s", "ehem-F17-m", "octattn-L12-spher", "octattn-L14-cylin"):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name] + rest, stdout=subprocess.PIPE, text=True)
+        rc = rc or r.returncode
+        line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
+        if line is None:
+            print(json.dumps({"config": name, "error": f"exit code {r.returncode}"}), flush=True)
+            continue
+        print(line, flush=True)
+        if args.out_dir:
+            os.makedirs(args.out_dir, exist_ok=True)
+            with open(os.path.join(args.out_dir, f"{args.tag}_bench_{name.replace('-', '_')}.json"), "w") as f:
+                f.write(line + "\n")
+    return rc
 
 
 def measure_dominant_kernel(enc, xyz_dev):
@@ -179,6 +216,10 @@ CONFIGS = {
 
 def main():
     args = parse()
+    if args.all_configs:
+        raise SystemExit(run_all_configs(args, sys.argv[1:]))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))       # nothing has touched the GPU yet
     cfg = CONFIGS[args.config]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,15 +251,16 @@ def main():
     if ehem:
         model = fill_weights(EHEM(ehem_cfg()), 0).to(dev)
         enc = FrameEncoder(model, cfg.get("type", "kitti"), cfg["level"], spher=cfg["mode"] == "spher", cylin=cfg["mode"] == "cylin",
-                           mullevel=cfg["mullevel"], device=dev)
+                           mullevel=cfg["mullevel"], device=dev, host_transform=True if args.host_transform else None)
     else:
         model = fill_weights(OctAttention(octattn_cfg()), 0).to(dev)
-        enc = OctAttnFrameEncoder(model, "kitti", cfg["level"], spher=cfg["mode"] == "spher", cylin=cfg["mode"] == "cylin", device=dev)
+        enc = OctAttnFrameEncoder(model, "kitti", cfg["level"], spher=cfg["mode"] == "spher", cylin=cfg["mode"] == "cylin", device=dev,
+                                  host_transform=True if args.host_transform else None)
 
     total = args.warmup + args.steps
     frames_host = [synth_frame(rank * 1000 + i) for i in range(total)]
+    from scp_amd.synth import ford_like
     if cfg.get("type") == "ford":
-        from scp_amd.synth import ford_like
         frames_host = [ford_like(f) for f in frames_host]
     frames = [torch.from_numpy(f).to(dev) for f in frames_host]      # resident in HBM before the timed region
     torch.cuda.synchronize()
@@ -231,6 +273,7 @@ def main():
     for i in range(args.warmup):
         enc.finish(enc.encode_async(frames[i]))
     barrier()
+    cpu0 = time.process_time()                      # CPU seconds of this rank, all threads (launch thread, coder worker, reader)
     t0 = time.perf_counter()
     # frame i is range-coded on a worker thread while frames i+1 .. i+depth run on the GPU; a handle pins its ~590 MB logits table,
     # so at most `depth` frames are in flight (memory stays O(depth), not O(steps))
@@ -240,12 +283,24 @@ def main():
         if len(pending) > args.depth:
             results.append(enc.finish(pending.pop(0)))
     results += [enc.finish(h) for h in pending]
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0               # this rank's own time for its frames (before the barrier)
+    cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps
     barrier()
     dt = time.perf_counter() - t0
+    rank_stats = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # per-rank view for the scaling curve: is the limiter on the host side?  Every rank also encodes ONE shared frame (outside
+        # the timed region): the streams must be byte-identical on every GPU.
+        import hashlib
+        shared = enc.finish(enc.encode_async(torch.from_numpy(synth_frame(0) if cfg.get("type") != "ford" else ford_like(synth_frame(0))).to(dev)))
+        mine = dict(rank=rank, device=torch.cuda.current_device(), fps=args.steps / dt_own, host_cpu_ms_per_frame=cpu_ms,
+                    shared_frame_sha256=hashlib.sha256(shared["bytes"]).hexdigest())
+        rank_stats = [None] * world
+        dist.all_gather_object(rank_stats, mine)
 
     # end-of-run summary reduction (encode.py:293-305): [sum bpp, sum psnr, sum chamfer, sum time, count] over all ranks
     summ = torch.tensor([sum(r["bpp"] for r in results), 0.0, 0.0, dt, len(results)], dtype=torch.float64, device=red_dev)
@@ -293,8 +348,10 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": cfg["workload"] + ", seeded random weights", "nodes_per_frame": int(n_nodes), "windows_per_frame": windows,
-                       "frames_per_gpu": args.steps, "frames_in_flight": args.depth, "parallelism": f"frame-sharded x{world}",
+                       "frames_per_gpu": args.steps, "frames_in_flight": args.depth, "transform": "host-numpy (strict identity)" if enc.host_transform else "device", "parallelism": f"frame-sharded x{world}",
                        "rank_cores": len(pinned) if pinned else None},
+            "rccl_world": dist.get_world_size() if world > 1 else 1, "dist_backend": backend if world > 1 else None,
+            "host_cpu_ms_per_frame": cpu_ms,
             "bpp_mean": float(summ[0] / summ[4]),
             "stage_ms": {k: round(1e3 * v, 3) for k, v in st.items()},
             # dominant kernel: the x3-split dense layer.  `achieved` counts ALGORITHMIC flops (2*M*N*K of the fp32 product it
@@ -323,6 +380,11 @@ def main():
                       "frac": bytes_C / st["cdf"] / 1e9 / HBM_PEAK_GBS, "bytes": bytes_C, "note": "includes the 4 B/node D2H copy"}}
         else:
             out["roofline_kernels"] = {"oa_attn_f16x3_kernel": entry(dom["attn"], note="dual-stream causal attention, non-causal flop count (SURVEY.md 8d)")}
+        if rank_stats:
+            fps = [r["fps"] for r in rank_stats]
+            cpu = [r["host_cpu_ms_per_frame"] for r in rank_stats]
+            out["ranks"] = {"fps_min": min(fps), "fps_max": max(fps), "host_cpu_ms_per_frame_min": min(cpu), "host_cpu_ms_per_frame_max": max(cpu),
+                            "shared_frame_streams_identical": len({r["shared_frame_sha256"] for r in rank_stats}) == 1, "per_rank": rank_stats}
         mode = "none" if args.no_cpu_baseline else args.cpu_baseline
         if world == 1 and mode != "none":
             try:

@@ -72,6 +72,10 @@ def get_args(argv=None, mullevel=False):
     p.add_argument("--random_weights", type=int, default=None)
     p.add_argument("--out_dir", type=str, default=None)
     p.add_argument("--metrics", action="store_true", help="chamfer distance + D1 PSNR per frame (computed on the device)")
+    p.add_argument("--host_transform", action="store_true",
+                   help="strict identity with the reference from the frame on: the coordinate transform + quantiser run in numpy float32 on the "
+                        "host exactly as data_preprocess.py:42-70 does (the device transform is more accurate, hence not bit-identical); "
+                        "also SCP_XFORM=numpy")
     return p.parse_args(argv)
 
 
@@ -134,19 +138,25 @@ def spawn_ranks(n, argv0, argv):
 
 
 class Prefetch:
-    """File reads (and the ascii PLY parse) one frame ahead on a reader thread, so the launch thread only enqueues GPU work."""
+    """File reads (and the ascii PLY parse) one frame ahead on a reader thread, so the launch thread only enqueues GPU work.
+    `post` (strict-identity mode: the host transform + quantiser) runs on the reader thread too; get() then returns (xyz, post(xyz))."""
 
-    def __init__(self, files, depth=2):
+    def __init__(self, files, depth=2, post=None):
         from concurrent.futures import ThreadPoolExecutor
         self.files = files
         self.pool = ThreadPoolExecutor(max_workers=1)
         self.depth = depth
         self.futs = {}
         self.next = 0
+        self.post = post
+
+    def _read(self, path):
+        xyz = pointCloud.ptread(path)
+        return xyz if self.post is None else (xyz, self.post(xyz))
 
     def get(self, k):
         while self.next < len(self.files) and self.next <= k + self.depth:
-            self.futs[self.next] = self.pool.submit(pointCloud.ptread, self.files[self.next][1])
+            self.futs[self.next] = self.pool.submit(self._read, self.files[self.next][1])
             self.next += 1
         return self.futs.pop(k).result()
 
@@ -191,9 +201,11 @@ def main(argv=None, mullevel=False):
     if name == "OctAttention":
         mul = mullevel and args.spher and not obj       # encode_dataset_mullevel.py:76: the three-shell form exists for --spher
         enc = OctAttnFrameEncoder(model, args.type, args.lidar_level, spher=args.spher and not obj, cylin=args.cylin and not obj, device=dev,
-                                  mullevel=mul, level_wise=args.level_wise and mullevel, named=mullevel)
+                                  mullevel=mul, level_wise=args.level_wise and mullevel, named=mullevel,
+                                  host_transform=True if args.host_transform else None)
     else:
-        enc = FrameEncoder(model, args.type, args.lidar_level, spher=args.spher, cylin=args.cylin, mullevel=mullevel, device=dev)
+        enc = FrameEncoder(model, args.type, args.lidar_level, spher=args.spher, cylin=args.cylin, mullevel=mullevel, device=dev,
+                           host_transform=True if args.host_transform else None)
 
     mine = D.shard(files, rank, world)
     # fast path: frames are enqueued with encode_async (stage G on a side stream, two model lanes, range coder on a worker thread)
@@ -201,7 +213,8 @@ def main(argv=None, mullevel=False):
     # come from record files, or run the one-window-per-node mode stay on the synchronous call.
     pipelined = not (args.preproc_path or args.metrics or args.sequential or obj)
     DEPTH = 3
-    reader = Prefetch(mine)
+    host_ints = enc.host_ints if (pipelined and name != "OctAttention" and enc.host_transform) else None
+    reader = Prefetch(mine, post=host_ints)
     pending = []
     sums = [0.0, 0.0, 0.0, 0.0, 0.0]
     last_done = [time.time()]
@@ -238,9 +251,12 @@ def main(argv=None, mullevel=False):
     for k, (i, cur) in enumerate(mine):
         print("Encoding ", cur, i, "/", len(files))
         xyz = reader.get(k)
+        ints = None
+        if host_ints is not None:
+            xyz, ints = xyz
         t0 = time.time()
         if pipelined:
-            pending.append((cur, enc.encode_async(xyz), t0))
+            pending.append((cur, enc.encode_async(xyz, ints) if ints is not None else enc.encode_async(xyz), t0))
             if len(pending) > DEPTH:
                 c0, h0, ts = pending.pop(0)
                 report(c0, enc.finish(h0), ts)
@@ -296,12 +312,33 @@ def get_decode_args(argv=None):
     return p.parse_args(argv)
 
 
+def find_stream(out_root, ori):
+    """The stream the encode CLIs wrote for the original file `ori`: `<stem>[_spher|_cylin]_<levels>_<bin_num>_<z_offset>.bin` with
+    stem = `<sequence dir><frame>` for KITTI EHEM runs (encode.py:140-144 via the dataset's file name) or the plain file stem.  The
+    reference takes the first name that merely CONTAINS the frame number (decode_ehem.py:206-214), which picks the wrong sequence's
+    stream as soon as two sequences hold the same frame number; here the name must match exactly, and 0 or several candidates are
+    an error.  Returns the file name."""
+    import re
+    p = Path(ori)
+    names = [f for f in os.listdir(out_root) if f.endswith(".bin")]
+    tried = []
+    for stem in ([p.parent.name + p.stem] if p.parent.name else []) + [p.stem]:
+        pat = re.compile("^" + re.escape(stem) + r"((_spher|_cylin)?_\d+_-?\d+_-?\d+)?\.bin$")
+        c = sorted(f for f in names if pat.match(f))
+        if len(c) == 1:
+            return c[0]
+        if len(c) > 1:
+            raise native.ScpError(f"{len(c)} streams match {ori} in {out_root}: {c}")
+        tried.append(stem)
+    raise native.ScpError(f"no stream for {ori} in {out_root} (looked for {tried})")
+
+
 def decode_main(argv=None, mullevel=False):
     """Drop-in for decode_ehem.py:191-255 / decode_ehem_mullevel.py:209-277: for every original file, find its stream in the
-    test_output directory (the `.bin` whose name contains the file's stem), decode it with the side info of `extract_info`,
+    test_output directory (`find_stream`: the exact name the encoder wrote, sequence included), decode it with the side info of `extract_info`,
     check the occupancy codes against the `--preproc_path` record files when they exist (the reference asserts this window by
     window, decode_ehem.py:184), rebuild the points (DeOctree -> de-quantise -> spher2cart / cylin2cart) and write
-    `<test_output>/<stem>.ply`."""
+    `<test_output>/<stream stem>.ply` (KITTI: `<sequence><frame>.ply`, so two sequences never overwrite each other)."""
     args = get_decode_args(argv)
     if not torch.cuda.is_available():
         raise native.ScpError("decode needs an MI355X: the SCP hot path has no CPU fallback")
@@ -330,11 +367,11 @@ def decode_main(argv=None, mullevel=False):
     elapsed, results = 0.0, []
     for i, ori in enumerate(files):
         print(f"{i}/{len(files)}")
-        stem = Path(ori).stem
-        cands = sorted(f for f in os.listdir(out_root) if stem in f and f.endswith(".bin"))
-        if not cands:
-            raise native.ScpError(f"no stream for {ori} in {out_root}")
-        binfile = out_root + cands[0]
+        name = find_stream(out_root, ori)
+        stem = name[:-4].split("_spher_")[0].split("_cylin_")[0]
+        if stem == name[:-4] and stem.count("_") >= 3:
+            stem = stem.rsplit("_", 3)[0]                      # Cartesian streams: <stem>_<levels>_<bin_num>_<z_offset>
+        binfile = out_root + name
         t0 = time.time()
         out = decode_file(binfile, model, args.lidar_level, args.type, mullevel, dev)
         torch.cuda.synchronize()

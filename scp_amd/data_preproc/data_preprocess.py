@@ -37,6 +37,46 @@ def cylin2cart(points):
     return np.vstack((rho * np.cos(phi), rho * np.sin(phi), z)).transpose(1, 0)
 
 
+def cart2cylin(points):
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    rho = np.sqrt(x ** 2 + y ** 2)
+    phi = np.arctan2(y, x + 1e-9)
+    phi[np.where(phi < 0)[0]] += 2 * math.pi
+    return np.vstack((rho, phi, z)).transpose(1, 0)
+
+
+class HostQuantInfo:
+    """What scp_quantize reports in its scp_quant_info, for integers produced on the host."""
+
+    def __init__(self, bin_num, qs, offset):
+        self.bin_num = float(bin_num)
+        self.qs = [float(v) for v in np.broadcast_to(np.asarray(qs, np.float64).reshape(-1), (3,))]
+        self.offset = [float(v) for v in np.broadcast_to(np.asarray(offset, np.float64).reshape(-1), (3,))]
+
+
+def host_quantize(xyz, mode, qs, cart_offset=-200.0):
+    """The reference's own float -> integer step, on the host, in numpy (data_preprocess.py:40-70 / :107-138; cart2spher :200-207,
+    cart2cylin :171-177): float32 sqrt / arctan2 / arccos as numpy evaluates them, `bin_num = round(rho.max() / qs) + 1`, the float64
+    divide `(points - offset) / qs_vec` and round-half-even.  This is the STRICT-IDENTITY path: the device transform
+    (csrc/geom.hip: transform_kernel) evaluates atan2 / acos in float64 and rounds once, which is more accurate than numpy's float32
+    routines and therefore not the same integers for a few points per frame.  Returns (int32 [P,3], HostQuantInfo)."""
+    pts = np.ascontiguousarray(xyz[:, :3], np.float32)
+    if mode == native.CYLIN:
+        tr = cart2cylin(pts)
+        bin_num = np.round(tr[:, 0].max() / qs) + 1
+        qsv = np.array([qs, 2 * math.pi / (bin_num - 1), qs])[True]
+        off = np.array([0.0, 0.0, min(tr[:, 2])])[True]
+    elif mode == native.SPHER:
+        tr = cart2spher(pts)
+        bin_num = np.round(tr[:, 0].max() / qs) + 1
+        qsv = np.array([qs, 2 * math.pi / (bin_num - 1), math.pi / (bin_num - 1)])[True]
+        off = 0
+    else:
+        tr, bin_num, qsv, off = pts, 0.0, qs, cart_offset
+    q = np.round((tr - off) / qsv)
+    return q.astype(np.int32), HostQuantInfo(bin_num, qsv, off)
+
+
 def _mode(cylin, spher):
     return native.CYLIN if cylin else (native.SPHER if spher else native.CART)
 

@@ -29,18 +29,90 @@ def init(backend=None):
     return rank, world, local
 
 
-def pin_rank_threads(local, local_world):
-    """Give every rank its own slice of the host cores (launch thread, range-coder worker, file reader): with 8 ranks the host
-    side is the expected limiter, and threads of different ranks migrating over each other's cores is the first
-    thing that hurts.  A rank needs ~3 cores; with fewer than 2 per rank the affinity is left alone.  SCP_PIN=0 disables."""
+def _parse_cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def _core_groups(cpus):
+    """The logical CPUs of `cpus` grouped by physical core (SMT siblings together), in core order; every CPU its own group when the
+    topology files are not readable."""
+    seen, groups = set(), []
+    for c in sorted(cpus):
+        if c in seen:
+            continue
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                sib = [x for x in _parse_cpulist(f.read()) if x in cpus]
+        except (OSError, ValueError):
+            sib = [c]
+        sib = [x for x in (sib or [c]) if x not in seen] or [c]
+        seen.update(sib)
+        groups.append(sorted(sib))
+    return groups
+
+
+def _gpu_numa_node(index):
+    """NUMA node of HIP device `index` (PCI address -> sysfs), or None.  Needs the device properties, i.e. an initialised GPU."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            n = int(f.read())
+        return n if n >= 0 else None
+    except Exception:
+        return None
+
+
+def _node_cpus(node):
+    try:
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            return set(_parse_cpulist(f.read()))
+    except (OSError, ValueError):
+        return None
+
+
+def _set_affinity_all_threads(cpus):
+    """sched_setaffinity(0) moves only the calling thread (new threads inherit it); the HIP runtime and OpenMP threads that already
+    exist are moved one by one."""
+    os.sched_setaffinity(0, cpus)
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), cpus)
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        pass
+
+
+def pin_rank_threads(local, local_world, numa=True):
+    """Give every rank of a node its own PHYSICAL cores (launch thread, range-coder worker, file reader: ~3 busy threads), taken
+    from the NUMA node its GPU hangs on when sysfs tells (ranks whose GPUs share a node split that node's cores; SMT siblings stay
+    with one rank).  Threads that already exist are moved too.  Nothing is changed for a single rank, with fewer than two cores per
+    rank, or with SCP_PIN=0.  Returns the CPU list of this rank or None."""
     if os.environ.get("SCP_PIN", "1") == "0" or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
-    cpus = sorted(os.sched_getaffinity(0))
-    per = len(cpus) // local_world
+    allowed = set(os.sched_getaffinity(0))
+    peers, slot, pool = local_world, local, allowed
+    if numa:
+        nodes = [_gpu_numa_node(i) for i in range(local_world)]
+        mine_node = nodes[local] if local < len(nodes) else None
+        node_cpus = _node_cpus(mine_node) if mine_node is not None else None
+        if node_cpus and (node_cpus & allowed):
+            same = [i for i, n in enumerate(nodes) if n == mine_node]
+            peers, slot, pool = len(same), same.index(local), node_cpus & allowed
+    cores = _core_groups(pool)
+    per = len(cores) // peers
     if per < 2:
         return None
-    mine = cpus[local * per:(local + 1) * per]
-    os.sched_setaffinity(0, mine)
+    mine = sorted(c for g in cores[slot * per:(slot + 1) * per] for c in g)
+    _set_affinity_all_threads(mine)
     torch.set_num_threads(max(1, min(per, 4)))
     return mine
 

@@ -77,8 +77,13 @@ class EncodePlan:
 
 class FrameEncoder:
     def __init__(self, model, data_type=KITTI, lidar_level=12, spher=True, cylin=False, mullevel=False, max_batch=8,
-                 device=None, packed=True, max_tokens=1_000_000):
+                 device=None, packed=True, max_tokens=1_000_000, host_transform=None):
         self.model = model
+        # strict-identity switch (CLI --host_transform, SCP_XFORM=numpy): the float -> integer step of the reference on the host
+        # (numpy float32 arctan2 / arccos, data_preprocess.py:42-70) instead of the device transform, whose float64 atan2 / acos is
+        # more accurate and therefore gives other integers for a few points per frame.  Everything after the
+        # integers is bit-exact on the device either way.
+        self.host_transform = (os.environ.get("SCP_XFORM", "") == "numpy") if host_transform is None else bool(host_transform)
         self.packed = packed            # one packed forward for all windows (default) vs one forward per group of equal windows
         self.max_tokens = max_tokens
         self.data_type = data_type
@@ -100,8 +105,21 @@ class FrameEncoder:
         L = self.lidar_level
         return [([0, 0], L), ([0, 1], L + 1), ([1], L + 2)] if self.mullevel else [(None, L)]
 
-    def quantize(self, xyz_dev):
+    def host_ints(self, xyz):
+        """The strict-identity front end: numpy [P,>=3] float32 -> (per-shell int32 arrays, infos) exactly as the reference computes
+        them (scp_amd/data_preproc/data_preprocess.py: host_quantize).  Runs on the host; the CLI calls it on its reader thread."""
+        from .data_preproc.data_preprocess import host_quantize
+        xyz = np.ascontiguousarray(xyz.cpu().numpy() if isinstance(xyz, torch.Tensor) else xyz, np.float32)
+        out = [host_quantize(xyz, self.mode, level_qs(self.data_type, lv), 0.0 if self.mullevel else self.cart_offset) for _, lv in self.shells()]
+        return [q for q, _ in out], [i for _, i in out]
+
+    def quantize(self, xyz_dev, ints=None):
         """xyz -> list of per-shell integer clouds (device int32 [P,3]) + (bin_num, z_offset)."""
+        if self.host_transform or ints is not None:
+            hq, infos = ints if ints is not None else self.host_ints(xyz_dev)
+            self._infos = infos
+            qs = [torch.from_numpy(q).to(self.device, non_blocking=True) for q in hq]
+            return qs, infos[0].bin_num, (infos[0].offset[2] if self.cylin else 0.0)
         qs, infos = [], []
         for path, lv in self.shells():
             q, qi, _ = native.quantize(xyz_dev, self.mode, level_qs(self.data_type, lv),
@@ -122,8 +140,8 @@ class FrameEncoder:
                                           f32=not self.mullevel).double())
         return metrics.chamfer_psnr(xyz_dev, torch.cat(pts), metrics.PEAK.get(self.data_type, 1.0))
 
-    def preprocess(self, xyz_dev):
-        qs, bin_num, z_off = self.quantize(xyz_dev)
+    def preprocess(self, xyz_dev, ints=None):
+        qs, bin_num, z_off = self.quantize(xyz_dev, ints)
         pre = self.preprocess_ints(qs, bin_num, z_off, xyz_dev.shape[0])
         pre["bin_nums"] = [float(i.bin_num) for i in self._infos]      # every shell's own (the file name carries the first)
         return pre
@@ -233,8 +251,9 @@ class FrameEncoder:
         t0 = time.perf_counter()
         if isinstance(xyz, np.ndarray):
             xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
+        ints = self.host_ints(xyz) if self.host_transform else None        # from the caller's copy (no D2H of a frame just uploaded)
         xyz_dev = xyz.to(self.device, non_blocking=True)
-        return self._encode_pre(self.preprocess(xyz_dev), t0, timing)
+        return self._encode_pre(self.preprocess(xyz_dev, ints), t0, timing)
 
     def encode_ints(self, qs, bin_num, z_offset, n_points, timing=False):
         """Encode from already-quantised integer coordinates (list of per-shell int32 [P_s,3] arrays / tensors)."""
@@ -244,13 +263,16 @@ class FrameEncoder:
         return self._encode_pre(self.preprocess_ints(dq, bin_num, z_offset, n_points), t0, timing)
 
     # ------------------------------------------------------------------------------------------ pipelined variant
-    def encode_async(self, xyz):
+    def encode_async(self, xyz, ints=None):
         """Like encode(), but the D2H copy of the (c_low, c_high) pairs and the serial host range coder run on a worker
         thread (ctypes releases the GIL) behind an event on a side stream, so the caller can enqueue the next frame while this
-        one is being coded.  Returns a handle; `finish(handle)` blocks and returns the usual result dict."""
+        one is being coded.  Returns a handle; `finish(handle)` blocks and returns the usual result dict.
+        ints: the result of `host_ints(xyz)` when the caller has already computed it (strict-identity mode, CLI reader thread)."""
         t0 = time.perf_counter()
         if isinstance(xyz, np.ndarray):
             xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
+        if self.host_transform and ints is None:
+            ints = self.host_ints(xyz)
         if not hasattr(self, "_pool"):
             self._pool = ThreadPoolExecutor(max_workers=2)
             self._copy_stream = torch.cuda.Stream(device=self.device)
@@ -260,7 +282,7 @@ class FrameEncoder:
             # co-run).  SCP_LANES=1 keeps every frame on the caller's stream.
             self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(os.environ.get("SCP_LANES", "2"))))]
             self._lane_i = 0
-        # Front part on its own stream: stage G (with its small D2H syncs) and the ~600 tiny index-map kernels of the window plans
+        # Front part on its own stream: stage G (with its small D2H syncs) and the window plans (one plan_kernel launch per chunk)
         # are launch-bound; on a side stream they run under the previous frame's model kernels instead of in front of this
         # frame's.  Everything allocated here stays referenced by the handle until finish(), i.e. past its last use on the
         # main stream, so the caching allocator cannot hand it out again early.
@@ -274,7 +296,7 @@ class FrameEncoder:
         fills0 = native.CACHE_FILLS
         with torch.cuda.stream(self._front_stream):
             self._front_stream.wait_stream(caller)
-            pre = self.preprocess(xyz.to(self.device, non_blocking=True))
+            pre = self.preprocess(xyz.to(self.device, non_blocking=True), ints)
             plan = EncodePlan(pre["level_sizes"], self.context_size)
             if self.packed:
                 pre["packed_plans"] = self.packed_plans(plan)
@@ -357,8 +379,9 @@ class OctAttnFrameEncoder:
     (`probabilities[:-1023]`) and coded as one stream.  File name `<base>[_spher]_<chunks>_<bin_num>_0.bin`."""
 
     def __init__(self, model, data_type=KITTI, lidar_level=12, spher=True, cylin=False, max_batch=128, device=None, mullevel=False,
-                 level_wise=False, named=False):
+                 level_wise=False, named=False, host_transform=None):
         self.model = model
+        self.host_transform = (os.environ.get("SCP_XFORM", "") == "numpy") if host_transform is None else bool(host_transform)   # see FrameEncoder
         self.data_type = data_type
         self.lidar_level = lidar_level
         self.mode = native.CYLIN if cylin else (native.SPHER if spher else native.CART)
@@ -380,6 +403,11 @@ class OctAttnFrameEncoder:
         return [([0, 0], L), ([0, 1], L + 1), ([1], L + 2)] if self.mullevel else [(None, L)]
 
     def quantize(self, xyz_dev):
+        if self.host_transform:
+            from .data_preproc.data_preprocess import host_quantize
+            xyz = np.ascontiguousarray(xyz_dev.cpu().numpy(), np.float32)
+            out = [host_quantize(xyz, self.mode, level_qs(self.data_type, lv), 0.0 if self.mullevel else self.cart_offset) for _, lv in self.shells()]
+            return [torch.from_numpy(q).to(self.device) for q, _ in out], out[0][1].bin_num
         qs, bin_num = [], None
         for path, lv in self.shells():
             q, qi, _ = native.quantize(xyz_dev, self.mode, level_qs(self.data_type, lv), 0.0 if self.mullevel else self.cart_offset)

@@ -62,11 +62,22 @@ def test_rank_thread_pinning_splits_the_host_cores(monkeypatch):
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)), raising=False)
     monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: calls.append(list(cpus)), raising=False)
     monkeypatch.setattr(torch, "set_num_threads", lambda n: None)
+    monkeypatch.setattr(D, "_core_groups", lambda cpus: [[c] for c in sorted(cpus)])
+    monkeypatch.setattr(D, "_gpu_numa_node", lambda i: None)
+    monkeypatch.setattr(D, "_set_affinity_all_threads", lambda cpus: os.sched_setaffinity(0, cpus))
     assert D.pin_rank_threads(0, 8) == [0, 1] and D.pin_rank_threads(7, 8) == [14, 15] and D.pin_rank_threads(1, 2) == list(range(8, 16))
     assert calls == [[0, 1], [14, 15], list(range(8, 16))]
     assert D.pin_rank_threads(0, 1) is None and D.pin_rank_threads(3, 16) is None
+    # SMT siblings stay with one rank; ranks whose GPUs hang on one NUMA node split THAT node's cores
+    monkeypatch.setattr(D, "_core_groups", lambda cpus: [[c, c + 8] for c in sorted(cpus) if c < 8 and c + 8 in cpus] or [[c] for c in sorted(cpus)])
+    assert D.pin_rank_threads(1, 4) == [2, 3, 10, 11]
+    monkeypatch.setattr(D, "_core_groups", lambda cpus: [[c] for c in sorted(cpus)])
+    monkeypatch.setattr(D, "_gpu_numa_node", lambda i: i // 2)                  # GPUs 0,1 on node 0; 2,3 on node 1
+    monkeypatch.setattr(D, "_node_cpus", lambda n: set(range(8 * n, 8 * n + 8)))
+    assert D.pin_rank_threads(2, 4) == [8, 9, 10, 11] and D.pin_rank_threads(1, 4) == [4, 5, 6, 7]
+    n_calls = len(calls)
     monkeypatch.setenv("SCP_PIN", "0")
-    assert D.pin_rank_threads(0, 8) is None and len(calls) == 3
+    assert D.pin_rank_threads(0, 8) is None and len(calls) == n_calls
 
 
 def test_cli_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
@@ -85,7 +96,7 @@ def test_cli_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
     assert e.value.code == 0
     cmd = seen["cmd"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
-    assert cmd[-6:] == ["--test_files", "x.bin", "--type", "kitti", "--gpus", "4"] + [] or "--spher" in cmd
+    assert cmd[-7:] == ["--test_files", "x.bin", "--type", "kitti", "--gpus", "4", "--spher"]       # the caller's own arguments, unchanged
 
     class A:
         spher_circle = False; level_wise = False; preproc_path = ""; metrics = False; type = "kitti"; spher = True; cylin = False; sequential = False
@@ -97,3 +108,27 @@ def test_cli_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
             cli.refuse_unsupported(a, model, mul)
     a = type("B", (A,), {"level_wise": True})
     cli.refuse_unsupported(a, "OctAttention", True)                 # encode_mullevel.py has the fixed level-wise form
+
+
+def test_bench_gpus_flag_spawns_ranks_before_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` outside torchrun starts N ranks itself (child torch.distributed.run, 127.0.0.1) and exits with the
+    child's code; inside a torchrun environment (RANK set) it does not spawn again."""
+    import importlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd: seen.setdefault("cmd", cmd) and 7)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "4", "--warmup", "1"])
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: (_ for _ in ()).throw(AssertionError("GPU touched before the spawn")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-7:] == [os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1"]

@@ -1,0 +1,47 @@
+"""bench.py as the driver runs it: the N-rank line produced by `bench.py --gpus N` itself, on a one-GPU box."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=1500):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` (no torchrun around it) starts two ranks as a child launcher before touching the GPU; here both
+    ranks share the box's one GPU (SCP_FORCE_DEVICE=0) and reduce over gloo.  The line says n_gpus 2, the whole-job rate counts both
+    ranks' frames, and the frame every rank encodes with the shared seed gives byte-identical streams."""
+    out = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--config", "ehem-L12-s"],
+               {"SCP_FORCE_DEVICE": "0", "SCP_DIST_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["rccl_world"] == 2 and out["scaling"] == "weak"
+    assert out["steps"] == 4 and abs(out["value"] - 2 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"]
+    r = out["ranks"]
+    assert len(r["per_rank"]) == 2 and {x["rank"] for x in r["per_rank"]} == {0, 1}
+    assert r["shared_frame_streams_identical"]
+    assert r["fps_min"] > 0 and r["host_cpu_ms_per_frame_max"] > 0
+    assert "roofline" in out and out["roofline"]["frac"] > 0
+
+
+def test_bench_single_rank_line_has_the_contract_fields():
+    out = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--config", "ehem-L12-s"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline"):
+        assert k in out
+    assert out["n_gpus"] == 1 and out["rccl_world"] == 1 and "ranks" not in out
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])

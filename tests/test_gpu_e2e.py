@@ -333,7 +333,7 @@ def test_cli_encode_then_decode_files(tmp_path, orc, mullevel, mode):
     r = _run_cli(dec_script, ["--test_files", f, "--random_weights", "0", "--out_dir", str(out), "--preproc_path", str(pp)], tmp_path)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "checked against" in r.stdout and "decode succeeded" in r.stdout
-    got = ptread(str(out / "000002.ply"))
+    got = ptread(str(out / "seq05000002.ply"))          # KITTI streams carry the sequence: so does the decoded cloud
     # oracle: same device integers -> octree -> code list -> DeOctree -> de-quantise
     dev = torch.device("cuda:0")
     want = []
@@ -683,3 +683,86 @@ def test_unsupported_configurations_fail_loudly(enc_parts):
     enc = FrameEncoder(model, "kitti", 12, spher=True, mullevel=True, device=dev)
     with pytest.raises(native.ScpError):
         enc.encode(np.array([[10.0, 3.0, -1.0]], np.float32))                                       # two of the three shells are empty
+
+
+@pytest.mark.parametrize("cfg", ["L12-s", "L16-m"])
+def test_host_transform_gives_the_reference_occupancy_stream_from_the_bin(enc_parts, tmp_path, cfg):
+    """Strict-identity switch (`--host_transform`, FrameEncoder(host_transform=True), SCP_XFORM=numpy): the 120 000-point `.bin`
+    frame through the drop-in CLI gives, from the FLOATS on, the occupancy stream of the reference: 0 points whose integers differ
+    from the reference quantiser's (tests/golden/frame_ints.npz), the octree's occupancy bytes hash to frame_facts.json `codes_sha`,
+    and the byte stream the CLI writes is the one `encode_ints` produces from the reference's own integers."""
+    import hashlib
+    import json
+    from conftest import GOLDEN, parity_record
+    from scp_amd import native
+    from scp_amd.encoder import FrameEncoder
+    from scp_amd.synth import synth_frame, write_kitti_bin
+    model, dev = enc_parts
+    mul = cfg == "L16-m"
+    L = 16 if mul else 12
+    facts = json.load(open(os.path.join(GOLDEN, "frame_facts.json")))[cfg]
+    ints = golden("frame_ints")
+    xyz = synth_frame(0)
+    ref_q = [np.ascontiguousarray(ints[f"q_spher_L{L + k}"]) for k in range(3 if mul else 1)]
+    enc = FrameEncoder(model, "kitti", L, spher=True, mullevel=mul, device=dev, host_transform=True)
+    hq, infos = enc.host_ints(xyz)
+    ndiff = sum(int((a != b).any(1).sum()) for a, b in zip(hq, ref_q))
+    parity_record(f"host_transform/{cfg}", points=len(xyz), points_differing_from_reference_ints=ndiff)
+    assert ndiff == 0
+    res = enc.encode(xyz)
+    # the octree the encoder just built, shell by shell, against what the reference's builders produced
+    occ = enc.geom.nodes(("occ",))["occ"].cpu().numpy()
+    for k, f in enumerate(facts if mul else [facts]):
+        i = enc.geom.info[k]
+        assert hashlib.sha256(occ[i.node_base:i.node_base + i.n_nodes].tobytes()).hexdigest() == f["codes_sha"], (cfg, k)
+    want = FrameEncoder(model, "kitti", L, spher=True, mullevel=mul, device=dev).encode_ints(ref_q, infos[0].bin_num, 0.0, len(xyz))
+    assert res["bytes"] == want["bytes"] and res["n_nodes"] == want["n_nodes"]
+    assert np.array_equal(res["_debug"]["sym_coded"].cpu().numpy(), want["_debug"]["sym_coded"].cpu().numpy())
+    # ... and through the command line, from the file
+    seq = tmp_path / "seq00"
+    seq.mkdir()
+    f = str(seq / "000000.bin")
+    write_kitti_bin(f, xyz)
+    out = tmp_path / "out"
+    r = _run_cli("encode_mullevel.py" if mul else "encode.py", ["--test_files", f, "--type", "kitti", "--lidar_level", str(L), "--spher",
+                                                                 "--random_weights", "0", "--out_dir", str(out), "--host_transform"], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bins = [p for p in out.iterdir() if p.name.endswith(".bin")]
+    assert len(bins) == 1 and bins[0].read_bytes() == want["bytes"]
+    # without the switch the device transform runs: its integers differ for a few points at L12 (DESIGN.md 2.1) - still a valid stream
+    if not mul:
+        plain = FrameEncoder(model, "kitti", L, spher=True, mullevel=False, device=dev).encode(xyz)
+        assert plain["n_nodes"] != want["n_nodes"] or plain["bytes"] != want["bytes"]
+
+
+def test_cli_decode_picks_the_stream_of_the_right_sequence(tmp_path, orc):
+    """Two KITTI sequences holding a frame with the same number: every stream decodes to ITS OWN cloud (`<sequence><frame>.ply`); a stem
+    that matches several streams, or none, is an error - never a silent first match."""
+    from scp_amd.cli import decode_main, find_stream
+    from scp_amd import native
+    from scp_amd.data_preproc.pt import ptread
+    from scp_amd.synth import synth_frame, write_kitti_bin
+    files = []
+    for seq, seed in (("11", 3), ("12", 4)):
+        d = tmp_path / seq
+        d.mkdir()
+        f = str(d / "000001.bin")
+        write_kitti_bin(f, synth_frame(seed)[::60].copy())
+        files.append(f)
+    out = tmp_path / "out"
+    r = _run_cli("encode.py", ["--test_files"] + files + ["--type", "kitti", "--lidar_level", "10", "--spher", "--random_weights", "0", "--out_dir", str(out)],
+                 tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = sorted(p.name for p in out.iterdir() if p.name.endswith(".bin"))
+    assert len(names) == 2 and names[0].startswith("11000001_") and names[1].startswith("12000001_")
+    assert find_stream(str(out) + "/", files[0]) == names[0] and find_stream(str(out) + "/", files[1]) == names[1]
+    r = _run_cli("decode_ehem.py", ["--test_files"] + files + ["--random_weights", "0", "--out_dir", str(out)], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = ptread(str(out / "11000001.ply")), ptread(str(out / "12000001.ply"))
+    assert a.shape != b.shape or not np.array_equal(a, b)
+    (out / (names[0][:-4] + "_copy.bin")).write_bytes(b"x")               # an ambiguous directory is refused
+    (out / "11000001_spher_9_9_9.bin").write_bytes(b"x")
+    with pytest.raises(native.ScpError):
+        find_stream(str(out) + "/", files[0])
+    with pytest.raises(native.ScpError):
+        find_stream(str(out) + "/", str(tmp_path / "13" / "000001.bin"))

@@ -181,3 +181,46 @@ def test_obj_quantisation_matches_proc_pc_defaults():
     r = p[:, [0, 2, 1]].copy(); r[:, 2] = -r[:, 2]
     want_r = np.round(r - np.min(r, 0)).astype(np.int32)
     assert np.array_equal(obj_ints(p, "data/mvub/phil9/frame0001.ply", torch.device("cpu")).numpy(), want_r)
+
+
+def test_host_quantize_equals_the_reference_integers_on_full_frames():
+    """Strict-identity switch (--host_transform / SCP_XFORM=numpy): scp_amd.data_preproc.data_preprocess.host_quantize is the
+    reference's float -> integer step (data_preprocess.py:40-70) in numpy.  On the 120 000-point frame its integers equal the ones the
+    reference itself produced in the build container (tests/golden/frame_ints.npz) for every configuration: 0 differing points."""
+    from scp_amd import native
+    from scp_amd.data_preproc.data_preprocess import host_quantize
+    from scp_amd.synth import synth_frame
+    from conftest import GOLDEN
+    ints = np.load(os.path.join(GOLDEN, "frame_ints.npz"))
+    xyz = synth_frame(0)
+    for key, mode, L, off in (("q_spher_L12", native.SPHER, 12, -200.0), ("q_spher_L16", native.SPHER, 16, 0.0), ("q_spher_L17", native.SPHER, 17, 0.0),
+                              ("q_spher_L18", native.SPHER, 18, 0.0), ("q_cylin_L14", native.CYLIN, 14, -200.0), ("q_cart_L12", native.CART, 12, -200.0)):
+        q, info = host_quantize(xyz, mode, 400 / (2 ** L - 1), off)
+        assert q.dtype == np.int32 and int((q != ints[key]).any(1).sum()) == 0, key
+    q, info = host_quantize(xyz, native.SPHER, 400 / (2 ** 12 - 1))
+    assert info.bin_num == 820.0 and info.offset == [0.0, 0.0, 0.0] and abs(info.qs[1] - 2 * np.pi / 819) < 1e-9      # float32 step: numpy >= 2 keeps bin_num float32
+    q, info = host_quantize(xyz, native.CYLIN, 400 / (2 ** 14 - 1))
+    assert info.bin_num == 3279.0 and abs(info.offset[2] - (-1.75919378)) < 1e-6
+
+
+def test_decode_cli_finds_exactly_the_stream_the_encoder_wrote(tmp_path):
+    """decode_ehem*.py stream lookup: exact `<sequence><frame>` / `<stem>` names as the encoder writes them; substring matches of other
+    sequences (`11000001` vs `000001`) and ambiguous directories are errors, not a silent first match."""
+    from scp_amd import native
+    from scp_amd.cli import find_stream
+    out = tmp_path / "out"
+    out.mkdir()
+    for n in ("11000001_spher_10_820_0.bin", "12000001_spher_10_821_0.bin", "00000010_spher_10_800_0.bin", "frame7_cylin_12_3279_-1.bin",
+              "cart3_12_0_-200.bin", "thing_vox6.bin", "11000001_spher_10_820_0.bin.dat"):
+        (out / n).write_bytes(b"")
+    root = str(out) + "/"
+    assert find_stream(root, "/data/kitti/11/000001.bin") == "11000001_spher_10_820_0.bin"
+    assert find_stream(root, "/data/kitti/12/000001.bin") == "12000001_spher_10_821_0.bin"
+    assert find_stream(root, "/data/kitti/00/000010.bin") == "00000010_spher_10_800_0.bin"
+    assert find_stream(root, "ford/frame7.ply") == "frame7_cylin_12_3279_-1.bin"
+    assert find_stream(root, "x/cart3.bin") == "cart3_12_0_-200.bin" and find_stream(root, "thing_vox6.ply") == "thing_vox6.bin"
+    with pytest.raises(native.ScpError):
+        find_stream(root, "/data/kitti/13/000001.bin")          # `000001` is a substring of three names, a match of none
+    (out / "11000001_spher_10_999_0.bin").write_bytes(b"")
+    with pytest.raises(native.ScpError):
+        find_stream(root, "/data/kitti/11/000001.bin")
