@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libscp_hip.so")
 SOURCES = ["api.cpp", "geom.hip", "sort_u64.hip", "cdf.hip", "rangecoder.cpp", "legacy_octree.cpp",
-           "knn.hip", "edge.hip", "attn.hip", "octattn.hip", "octattn_f16.hip", "gemm.hip", "gemm_split.hip", "mlp_fused.hip", "fused.hip", "metrics.hip", "plan.hip"]
+           "knn.hip", "edge.hip", "attn.hip", "octattn.hip", "octattn_f16.hip", "gemm.hip", "gemm_split.hip", "mlp_fused.hip", "rowchain.hip", "fused.hip", "metrics.hip", "plan.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fvisibility=hidden", "-x", "hip"]

@@ -58,15 +58,11 @@ extern "C" void *genOctreeInterface(void *v, const double *xyz, int n) {
         scp_segment_info info;
         if (scp_geom_build(g, dq, n, &seg, 1, &info, nullptr) != SCP_OK) break;
         const size_t N = (size_t)info.n_nodes;
-        if (hipMalloc((void **)&docc, N * (3 + 4 + 12)) != hipSuccess) break;
-        uint8_t *dlevel = docc + N, *doct = docc + 2 * N;
-        int32_t *dpar = (int32_t *)(docc + ((3 * N + 15) / 16) * 16);
-        (void)dlevel;
-        // simpler: separate, aligned allocations for the int tables
-        int32_t *dparent = nullptr, *dpos = nullptr;
+        if (hipMalloc((void **)&docc, 2 * N) != hipSuccess) break;      // occupancy bytes, then octants
+        uint8_t *doct = docc + N;
+        int32_t *dparent = nullptr, *dpos = nullptr;                    // the int tables: separate (aligned) allocations
         if (hipMalloc((void **)&dparent, N * 4) != hipSuccess) break;
         if (hipMalloc((void **)&dpos, N * 12) != hipSuccess) { (void)hipFree(dparent); break; }
-        (void)dpar;
         int rc = scp_geom_emit_nodes(g, docc, nullptr, doct, dparent, dpos, nullptr);
         std::vector<uint8_t> occ(N), oct(N);
         std::vector<int32_t> parent(N), pos(3 * N);

@@ -96,6 +96,7 @@ def lib():
         "scp_linear_split": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_mlp_split_fused": (C.c_int, [_vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp, i64, i32, _vp]),
         "scp_tile_weight_bf16": (C.c_int, [_vp, i32, i32, _vp, _vp]),
+        "scp_swin_ln_linear": (C.c_int, [_vp, i64, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, i32, _vp]),
         "scp_split_rows": (C.c_int, [_vp, i64, i64, _vp, i32, _vp, _vp, i64, i64, _vp]),
         "scp_linear_split_scatter": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_linear_split_gather": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
@@ -690,6 +691,34 @@ def mlp_split_fused(a, sw1, b1, sw2, b2, residual=None):
                                    0 if residual is None else residual.stride(0), c.data_ptr(), c.stride(0), a.M, _stream())
     _check(rc, "scp_mlp_split_fused")
     return c
+
+
+class LnFoldedWeight:
+    """A Linear that follows a LayerNorm, with the LayerNorm's affine folded in (built once per weight):
+    LN(x) . W^T + b = n(x) . (W diag(gamma))^T + (b + W beta), n = the normalised row.  `sw` = split + tiled planes of W diag(gamma),
+    `wbeta` = W beta (kept apart from b: rows a window pads AFTER LayerNorm get b alone, swin_transformer.py:638-641)."""
+
+    def __init__(self, w, gamma, beta):
+        w64 = w.detach().double()
+        self.sw = SplitWeight((w64 * gamma.detach().double()[None, :]).float())
+        self.wbeta = (w64 @ beta.detach().double()).float().contiguous()
+        self.N, self.K = self.sw.N, self.sw.K
+        note_cache_fill()
+
+
+def swin_ln_linear(x, fw, bias, eps=1e-5, valid=None, out=None):
+    """out = valid * LayerNorm(x) . W^T + bias in one launch (csrc/rowchain.hip): x fp32 [M, 256] rows (unit channel stride),
+    fw = LnFoldedWeight, valid fp32 [M] / [M, 1] or None.  -> fp32 [M, N]."""
+    M = x.shape[0]
+    if x.shape[1] != 256 or fw.K != 256 or x.stride(1) != 1:
+        raise ScpError("swin_ln_linear: 256-channel rows expected")
+    if out is None:
+        out = torch.empty((M, fw.N), dtype=torch.float32, device=x.device)
+    t = fw.sw.tiled()
+    rc = lib().scp_swin_ln_linear(x.data_ptr(), x.stride(0), None if valid is None else _dev(valid, torch.float32), t[0].data_ptr(), t[1].data_ptr(),
+                                  _opt(bias), _dev(fw.wbeta), float(eps), out.data_ptr(), out.stride(0), M, fw.N, _stream())
+    _check(rc, "scp_swin_ln_linear")
+    return out
 
 
 def layernorm_rows(x, gamma, beta, eps=1e-5, valid=None, ia=None, ib=None, out=None, split=False):
