@@ -49,16 +49,27 @@ __device__ __forceinline__ void rc_dma16(const void *g, char *l) {
     __builtin_amdgcn_global_load_lds((rc_glb_ptr_t)g, (rc_lds_ptr_t)l, 16, 0, 0);
 }
 
-// hi/lo split of an fp32 value (the same arithmetic as every other producer of split operands: hi = bf16(x), lo = bf16(x - hi))
+// hi/lo split of fp32 values (the arithmetic of every producer of split operands: hi = bf16(x), lo = bf16(x - hi)), two at a time:
+// v_cvt_pk_bf16_f32 packs the pair, so a fragment is assembled from four 32-bit words - element-wise conversion made the compiler
+// hold every 16-bit half in a register of its own until a v_perm_b32 packed it (hundreds of spills in the LayerNorm section).
+typedef float rf32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 rbf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned ru32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned rc_pack2(float a, float b) {
+    const rf32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rbf16x2));
+}
+__device__ __forceinline__ void rc_split2(float a, float b, unsigned &hi, unsigned &lo) {
+    asm volatile("" : "+v"(a), "+v"(b));        // the rounded fp32 values (no FMA contraction into the subtractions below)
+    hi = rc_pack2(a, b);
+    lo = rc_pack2(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u));
+}
 __device__ __forceinline__ void rc_split8(const float *f, rbf16x8 &hi, rbf16x8 &lo) {
+    ru32x4 h, l;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float v = f[i];
-        asm volatile("" : "+v"(v));            // the rounded fp32 value (no FMA contraction into the subtraction below)
-        const __bf16 hh = (__bf16)v;
-        hi[i] = hh;
-        lo[i] = (__bf16)(v - (float)hh);
-    }
+    for (int i = 0; i < 4; ++i) { unsigned a, b; rc_split2(f[2 * i], f[2 * i + 1], a, b); h[i] = a; l[i] = b; }
+    hi = __builtin_bit_cast(rbf16x8, h);
+    lo = __builtin_bit_cast(rbf16x8, l);
 }
 
 // A fragment of weight row (lane & 31) of a 32-row slot block, k-step s (16 k): the tiled image of scp_tile_weight_bf16
@@ -235,13 +246,13 @@ __device__ __forceinline__ void rc_ll_step(const RcLane &L, const RcLnLinArgs &a
                 if (gap == 2) RC_DS_READ(A[nb][2], ra, RC_SLOT + (ns >> 1) * 1024);
                 if (gap == 3) RC_DS_READ(A[nb][3], ra, RC_SLOT + 16384 + (ns >> 1) * 1024);
             }
-            if (s < 8 && (s & 3) == L.w && gap < 4 && !(PROBE & 2)) {   // 2 of the next step's LDS-DMA pieces: slot s >> 2, block w + 4 gap
-                // buffer form: per-lane offset (16 lane) in one VGPR for all pieces, the piece's offset in an SGPR - the global form
-                // spends two 64-bit VALU adds per piece on its address (32 of the ~48 cycles a piece then costs the wave)
-                const int slot = s >> 2, pb = L.w + 4 * gap;
+            if (s < 8 && (gap == 1 || gap == 3) && !(PROBE & 2)) {   // one of the next step's 16 LDS-DMA pieces: slot s >> 2, block w + 4 (s & 3)
+                // (buffer form: the per-lane offset 16 lane in one VGPR for all pieces, the piece's offset in an SGPR; no wave-dependent
+                // branch, so the step is one basic block - see rc_dma_piece)
+                const int slot = s >> 2, pb = L.w + 4 * (s & 3), plane = gap >> 1;
                 const int soff = ((g_next + slot) * 16 + pb) * 1024;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr_hi, (rc_lds_ptr_t)(nxt + slot * RC_SLOT + pb * 1024), 16, L.lane * 16, soff, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr_lo, (rc_lds_ptr_t)(nxt + slot * RC_SLOT + 16384 + pb * 1024), 16, L.lane * 16, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(plane ? wr_lo : wr_hi, (rc_lds_ptr_t)(nxt + slot * RC_SLOT + plane * 16384 + pb * 1024), 16,
+                                                         L.lane * 16, soff, 0, 0);
             }
             if ((s == 8 || s == 11) && gap < 4 && !(PROBE & 8)) { // previous results -> bounce buffer, one 32-channel block at a time
                 const rf32x16 &pp = (s == 8) ? p0 : p1;
@@ -272,6 +283,7 @@ __device__ __forceinline__ void rc_ll_step(const RcLane &L, const RcLnLinArgs &a
             RC_SB;
         }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the next step's first fragments: waited for before any block boundary
     if (st) { const unsigned long long t = __builtin_amdgcn_s_memtime(); st[4] += t - ts0; }
 }
 
@@ -400,6 +412,390 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
     SCP_WAIT_DMA(0);                                                // the slots requested for a tile that does not exist
 }
 
+// =================================================================================================================================
+// scp_swin_post_attn: everything of a Swin block behind the attention, one launch (see the head of this file).
+//
+// Per 128-row tile, per wave (32 rows), 37 steps of 96 MFMAs, each step fed by one ring half (two 32 KiB weight slots):
+//   steps 0 - 3   phase 0   Y[2j], Y[2j+1] += Wp[64 j .. 64 j + 63][:] . O^T          (B = the attention output rows, read as planes)
+//   then          Y += x + bp  (x1 = the new residual stream), LayerNorm statistics, normalised rows -> hi/lo B fragments IN PLACE of O
+//   step 4        P1(0), P1(1)   acc1[c] = W1'[32 c .. 32 c + 31][:] . X^T              (hidden chunk c = 32 hidden units)
+//   steps 5 - 36  body(c), c = 0 .. 31: per slice one k-step of P1(c + 2) (chain acc1[c & 1]) and one of P2(c): Y[blk] += W2[32 blk ..]
+//                 [hidden chunk c] . H(c)^T (chain Y[blk], blk = slice >> 1), and in the gaps GELU(c + 1): acc1[(c + 1) & 1] + b1' ->
+//                 exact-erf GELU -> hi/lo split -> the B fragments of P2(c + 1).  The accumulator layout IS the fragment layout (lane =
+//                 row, 8 consecutive registers = one k-step) up to a fixed permutation of each 16 channels (rc_perm16), which the caller
+//                 applies to the K axis of W1' and to the hidden axis of W2 when it tiles them.
+//   then          Y + b2 -> fp32 rows out (bounce buffer, whole 128-byte lines).
+// The next tile's attention rows are requested into the fragment registers when the last P1 is done (body 30), its residual rows at
+// the start of the tile; they are older than the LDS-DMA pieces requested after them, so the step barriers (vmcnt(0)) cover them.
+struct RcPostArgs {
+    const __bf16 *Ohi, *Olo; int64_t ldo_in;    // attention output planes [M][ldo_in] (256 columns)
+    const float *x; int64_t ldx;                // residual stream in, fp32 [M][ldx]
+    const void *W;                              // ONE buffer: tiled planes proj hi | fc1 hi | fc2 hi | proj lo | fc1 lo | fc2 lo (RC_W_*):
+                                                //   proj [256][256]; fc1 = (W1 diag(gamma))[:, perm16] [1024][256]; fc2 = W2[:, perm16] [256][1024]
+    const float *bp, *b1, *b2;                  // [256], [1024] (= b1 + W1 beta), [256]
+    float *out; int64_t ldc;                    // residual stream out, fp32 [M][ldc] (may be x)
+    int M;
+    float eps;
+    unsigned long long *dbg;
+    int dbg_mode;                               // SCP_RC_DUMP: 1 = write the normalised rows instead of the result, 2 = mean / rstd in columns 0, 1
+};
+
+#define RC_W_PROJ 0
+#define RC_W_FC1 (256 * 512)
+#define RC_W_FC2 (RC_W_FC1 + 1024 * 512)
+#define RC_W_PLANE (RC_W_FC2 + 256 * 2048)      // bytes of the three hi planes; the lo planes follow in the same order
+// LDS-DMA piece pb (1 KiB) of a slot: byte offset base + pb * stride into the weight buffer (lo plane: + RC_W_PLANE).  One buffer
+// resource for every weight of the block: nothing selects between descriptors at run time, and four SGPRs hold it instead of 24.
+struct RcSlotSrc { int base, stride; };
+
+// The 16 LDS-DMA pieces a wave requests per step: piece pb = w + 4 (s & 3) of slot s >> 2, slices s = 0 .. 7, its hi plane in gap 1 and
+// its lo plane in gap 3.  No wave-dependent branch: a step stays ONE basic block, so the compiler has no place to put a copy (or a
+// spill) of a fragment register between the inline-asm read that fills it and the hand-placed wait - it would copy stale bytes.
+__device__ __forceinline__ void rc_dma_piece(const RcLane &L, __amdgpu_buffer_rsrc_t wr, const RcSlotSrc &src, char *slot_lds, int s, int plane) {
+    const int pb = L.w + 4 * (s & 3);
+    const int soff = src.base + pb * src.stride + plane * RC_W_PLANE;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (rc_lds_ptr_t)(slot_lds + plane * 16384 + pb * 1024), 16, L.lane * 16, soff, 0, 0);
+}
+
+// lane addresses of the fragment reads in a ring half: row-chunk slots (k-chunk 0 / 1) and k-chunk slots (t = 0 / 1)
+struct RcFragAddr { unsigned r0, r1, k0, k1; };
+__device__ __forceinline__ RcFragAddr rc_frag_addr(const RcLane &L, char *half_base) {
+    RcFragAddr f;
+    const unsigned b = (unsigned)(uintptr_t)(rc_lds_ptr_t)half_base;
+    f.r0 = b + L.rg * 8192 + L.frag; f.r1 = b + L.rg * 8192 + (L.frag ^ 32);
+    f.k0 = b + L.rg * 1024 + L.frag; f.k1 = b + L.rg * 1024 + (L.frag ^ 32);
+    return f;
+}
+
+// GEMM step: two row-chunk slots, two chains (c0: slot 0, c1: slot 1) over the 16 k-steps of the resident B fragments.  Used for
+// phase 0 (B = attention rows, chains = Y blocks) and for P1(0), P1(1).  NEXT_BODY: the step after this one is a body step (its first
+// fragments are a row-chunk and a k-chunk fragment) - they are read in slice 15, after the barrier that publishes the next ring half.
+template <bool NEXT_BODY>
+__device__ __forceinline__ void rc_gemm_step(const RcLane &L, char *smem, int half, rf32x16 &c0, rf32x16 &c1, const rbf16x8 (&Bh)[16],
+                                             const rbf16x8 (&Bl)[16], rbf16x8 (&A)[2][4], __amdgpu_buffer_rsrc_t wr, const RcSlotSrc &n0,
+                                             const RcSlotSrc &n1) {
+    const RcFragAddr f = rc_frag_addr(L, smem + half * (2 * RC_SLOT)), fn = rc_frag_addr(L, smem + (half ^ 1) * (2 * RC_SLOT));
+    char *nxt = smem + (half ^ 1) * (2 * RC_SLOT);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (s == 15) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        RC_SB;
+        const int nb = (s + 1) & 1, ns = (s + 1) & 15;
+#pragma unroll
+        for (int gap = 0; gap < 6; ++gap) {
+            if (gap == 0) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][1], Bh[s], c0, 0, 0, 0);
+            if (gap == 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][3], Bh[s], c1, 0, 0, 0);
+            if (gap == 2) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0], Bl[s], c0, 0, 0, 0);
+            if (gap == 3) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][2], Bl[s], c1, 0, 0, 0);
+            if (gap == 4) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0], Bh[s], c0, 0, 0, 0);
+            if (gap == 5) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][2], Bh[s], c1, 0, 0, 0);
+            RC_SB;
+            if (s < 15) {
+                const unsigned ra = (ns & 1) ? f.r1 : f.r0;
+                if (gap == 0) RC_DS_READ(A[nb][0], ra, (ns >> 1) * 1024);
+                if (gap == 1) RC_DS_READ(A[nb][1], ra, 16384 + (ns >> 1) * 1024);
+                if (gap == 2) RC_DS_READ(A[nb][2], ra, RC_SLOT + (ns >> 1) * 1024);
+                if (gap == 3) RC_DS_READ(A[nb][3], ra, RC_SLOT + 16384 + (ns >> 1) * 1024);
+            } else {   // first fragments of the next step, from the other ring half
+                if (gap == 0) RC_DS_READ(A[0][0], fn.r0, 0);
+                if (gap == 1) RC_DS_READ(A[0][1], fn.r0, 16384);
+                if (gap == 2) { if (NEXT_BODY) RC_DS_READ(A[0][2], fn.k0, RC_SLOT); else RC_DS_READ(A[0][2], fn.r0, RC_SLOT); }
+                if (gap == 3) { if (NEXT_BODY) RC_DS_READ(A[0][3], fn.k0, RC_SLOT + 16384); else RC_DS_READ(A[0][3], fn.r0, RC_SLOT + 16384); }
+            }
+            if (s < 8 && (gap == 1 || gap == 3)) rc_dma_piece(L, wr, (s >> 2) ? n1 : n0, nxt + (s >> 2) * RC_SLOT, s, gap >> 1);
+            RC_SB;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the next step's first fragments: waited for before any block boundary
+}
+
+// exact-erf GELU of gemm_split.hip (same polynomial), two elements at a time, cut into 12 stages of 4 VALU instructions: one stage per
+// MFMA gap, so the 48 instructions of a pair ride in the gaps of two slices.  st = (slice & 1) * 6 + gap.
+struct RcGelu { float ya, yb, za, zb, ca, cb, ua, ub, pa, pb, ga, gb; unsigned hw; };
+__device__ __forceinline__ void rc_gelu_stage(int st, RcGelu &g, float acc_a, float acc_b, float bias_a, float bias_b, unsigned &wh, unsigned &wl) {
+    switch (st) {
+    case 0: g.ya = acc_a + bias_a; g.yb = acc_b + bias_b; g.za = g.ya * 0.70710678118654752f; g.zb = g.yb * 0.70710678118654752f; break;
+    case 1: g.ca = fminf(fabsf(g.za), 3.5f); g.cb = fminf(fabsf(g.zb), 3.5f); g.ua = g.ca * g.ca; g.ub = g.cb * g.cb; break;
+    case 2: g.ua = fmaf(g.ua, 2.0f / 12.25f, -1.0f); g.ub = fmaf(g.ub, 2.0f / 12.25f, -1.0f);
+            g.pa = fmaf(1.480935152e-03f, g.ua, -3.987360327e-03f); g.pb = fmaf(1.480935152e-03f, g.ub, -3.987360327e-03f); break;
+    case 3: g.pa = fmaf(g.pa, g.ua, 4.474287011e-03f); g.pb = fmaf(g.pb, g.ub, 4.474287011e-03f);
+            g.pa = fmaf(g.pa, g.ua, -7.227925849e-03f); g.pb = fmaf(g.pb, g.ub, -7.227925849e-03f); break;
+    case 4: g.pa = fmaf(g.pa, g.ua, 1.704961757e-02f); g.pb = fmaf(g.pb, g.ub, 1.704961757e-02f);
+            g.pa = fmaf(g.pa, g.ua, -3.003174999e-02f); g.pb = fmaf(g.pb, g.ub, -3.003174999e-02f); break;
+    case 5: g.pa = fmaf(g.pa, g.ua, 4.501544287e-02f); g.pb = fmaf(g.pb, g.ub, 4.501544287e-02f);
+            g.pa = fmaf(g.pa, g.ua, -6.477065166e-02f); g.pb = fmaf(g.pb, g.ub, -6.477065166e-02f); break;
+    case 6: g.pa = fmaf(g.pa, g.ua, 8.840217622e-02f); g.pb = fmaf(g.pb, g.ub, 8.840217622e-02f);
+            g.pa = fmaf(g.pa, g.ua, -1.146127499e-01f); g.pb = fmaf(g.pb, g.ub, -1.146127499e-01f); break;
+    case 7: g.pa = fmaf(g.pa, g.ua, 1.467501802e-01f); g.pb = fmaf(g.pb, g.ub, 1.467501802e-01f);
+            g.pa = fmaf(g.pa, g.ua, -2.007010379e-01f); g.pb = fmaf(g.pb, g.ub, -2.007010379e-01f); break;
+    case 8: g.pa = fmaf(g.pa, g.ua, 4.038729840e-01f); g.pb = fmaf(g.pb, g.ub, 4.038729840e-01f); g.pa *= g.ca; g.pb *= g.cb; break;
+    case 9: g.pa = copysignf(g.pa, g.za); g.pb = copysignf(g.pb, g.zb); g.ya *= 0.5f; g.yb *= 0.5f; break;
+    case 10: g.ga = fmaf(g.ya, g.pa, g.ya); g.gb = fmaf(g.yb, g.pb, g.yb); g.hw = rc_pack2(g.ga, g.gb); wh = g.hw; break;
+    default: wl = rc_pack2(g.ga - __builtin_bit_cast(float, g.hw << 16), g.gb - __builtin_bit_cast(float, g.hw & 0xffff0000u)); break;
+    }
+}
+
+// Body step c: slot 0 = W1' rows [32 (c + 2), +32) (row chunk), slot 1 = W2 hidden slab c (k chunk).
+//   HAS_P1: P1(c + 2) -> a1n (false for the last two bodies);  GELU of a1g (= P1(c + 1)) + bias bg -> Hn (fragments of P2(c + 1));
+//   P2(c): Y[blk] += W2 . Hc.   NEXT: 0 = next step is a body, 1 = next step is a GEMM step (phase 0 of the next tile).
+template <bool HAS_P1, bool HAS_GELU, int NEXT>
+__device__ __forceinline__ void rc_body_step(const RcLane &L, char *smem, int half, rf32x16 (&Y)[8], rf32x16 &a1n, const rf32x16 &a1g,
+                                             const rf32x4 (&bg)[4], const ru32x4 (&Hch)[2], const ru32x4 (&Hcl)[2], ru32x4 (&Hnh)[2],
+                                             ru32x4 (&Hnl)[2], const rbf16x8 (&Xh)[16], const rbf16x8 (&Xl)[16], rbf16x8 (&A)[2][4],
+                                             __amdgpu_buffer_rsrc_t wr, const RcSlotSrc &n0, const RcSlotSrc &n1) {
+    const RcFragAddr f = rc_frag_addr(L, smem + half * (2 * RC_SLOT)), fn = rc_frag_addr(L, smem + (half ^ 1) * (2 * RC_SLOT));
+    char *nxt = smem + (half ^ 1) * (2 * RC_SLOT);
+    RcGelu g;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (s == 15) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        RC_SB;
+        const int nb = (s + 1) & 1, ns = (s + 1) & 15;
+        const int blk = s >> 1, t = s & 1;
+#pragma unroll
+        for (int gap = 0; gap < 6; ++gap) {
+            // P1 k-step s on chain a1n (fragments A[.][0] hi, A[.][1] lo) and P2 (blk, t) on chain Y[blk] (A[.][2] hi, A[.][3] lo), alternating
+            if (gap == 0 && HAS_P1) a1n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][1], Xh[s], a1n, 0, 0, 0);
+            if (gap == 1) Y[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][3], __builtin_bit_cast(rbf16x8, Hch[t]), Y[blk], 0, 0, 0);
+            if (gap == 2 && HAS_P1) a1n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0], Xl[s], a1n, 0, 0, 0);
+            if (gap == 3) Y[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][2], __builtin_bit_cast(rbf16x8, Hcl[t]), Y[blk], 0, 0, 0);
+            if (gap == 4 && HAS_P1) a1n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0], Xh[s], a1n, 0, 0, 0);
+            if (gap == 5) Y[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][2], __builtin_bit_cast(rbf16x8, Hch[t]), Y[blk], 0, 0, 0);
+            RC_SB;
+            if (s < 15) {
+                if (gap == 0 && HAS_P1) RC_DS_READ(A[nb][0], (ns & 1) ? f.r1 : f.r0, (ns >> 1) * 1024);
+                if (gap == 1 && HAS_P1) RC_DS_READ(A[nb][1], (ns & 1) ? f.r1 : f.r0, 16384 + (ns >> 1) * 1024);
+                if (gap == 2) RC_DS_READ(A[nb][2], (ns & 1) ? f.k1 : f.k0, RC_SLOT + (ns >> 1) * 2048);
+                if (gap == 3) RC_DS_READ(A[nb][3], (ns & 1) ? f.k1 : f.k0, RC_SLOT + 16384 + (ns >> 1) * 2048);
+            } else {   // first fragments of the next step, from the other ring half
+                if (gap == 0) RC_DS_READ(A[0][0], fn.r0, 0);
+                if (gap == 1) RC_DS_READ(A[0][1], fn.r0, 16384);
+                if (gap == 2) { if (NEXT == 0) RC_DS_READ(A[0][2], fn.k0, RC_SLOT); else RC_DS_READ(A[0][2], fn.r0, RC_SLOT); }
+                if (gap == 3) { if (NEXT == 0) RC_DS_READ(A[0][3], fn.k0, RC_SLOT + 16384); else RC_DS_READ(A[0][3], fn.r0, RC_SLOT + 16384); }
+            }
+            if (s < 8 && (gap == 1 || gap == 3)) rc_dma_piece(L, wr, (s >> 2) ? n1 : n0, nxt + (s >> 2) * RC_SLOT, s, gap >> 1);
+            if (HAS_GELU) {   // element pair (2 k, 2 k + 1) of the finished P1 chain, k = s >> 1: registers 2 k, 2 k + 1 = fragment (k >> 2), elements 2 (k & 3), + 1
+                const int k = s >> 1, st = (s & 1) * 6 + gap;
+                unsigned wh = 0, wl = 0;
+                rc_gelu_stage(st, g, a1g[2 * k], a1g[2 * k + 1], bg[k >> 1][(2 * k) & 3], bg[k >> 1][(2 * k + 1) & 3], wh, wl);
+                if (st == 10) Hnh[k >> 2][k & 3] = wh;
+                if (st == 11) Hnl[k >> 2][k & 3] = wl;
+            }
+            RC_SB;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the next step's first fragments: waited for before any block boundary
+}
+
+__global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const RcLane L = rc_lane();
+    const int ntiles = (a.M + RC_ROWS - 1) / RC_ROWS;
+    float *sbp = (float *)(smem + RC_OFF_BIAS), *sb2 = sbp + 256, *sb1 = sbp + 512;      // bp[256], b2[256], b1'[1024]
+    for (int i = threadIdx.x; i < 256; i += 256) { sbp[i] = a.bp[i]; sb2[i] = a.b2[i]; }
+    for (int i = threadIdx.x; i < 1024; i += 256) sb1[i] = a.b1[i];
+    __syncthreads();
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    char *bounce = smem + RC_OFF_BOUNCE + L.w * RC_BOUNCE;
+
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.W, 0, 2 * RC_W_PLANE, 0x00020000);
+    auto src_p = [&](int g) { RcSlotSrc r = {RC_W_PROJ + g * 16384, 1024}; return r; };             // proj rows [32 g, +32): 16 consecutive KiB
+    auto src_1 = [&](int c) { RcSlotSrc r = {RC_W_FC1 + c * 16384, 1024}; return r; };              // fc1 rows [32 c, +32)
+    auto src_2 = [&](int c) { RcSlotSrc r = {RC_W_FC2 + c * 1024, 32 * 1024}; return r; };          // fc2 hidden slab c (32 columns) of the 16 row groups
+
+    unsigned long long t_p0 = 0, t_ln = 0, t_mlp = 0, t_epi = 0, t_prev = 0, n_tiles = 0;
+    const bool DBG = a.dbg != nullptr;
+    if (DBG) t_prev = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](unsigned long long &acc_t) { if (DBG) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_t += t - t_prev; t_prev = t; } };
+
+    // first step's slots (proj rows 0 .. 63) and the first tile's attention rows (B fragments: k = 16 s + 8 h + i, natural order)
+    {
+        const RcSlotSrc s0 = src_p(0), s1 = src_p(1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) { rc_dma_piece(L, wr, s0, smem, q, plane); rc_dma_piece(L, wr, s1, smem + RC_SLOT, q, plane); }
+    }
+    rbf16x8 Bh[16], Bl[16];                                         // attention rows during phase 0, normalised rows afterwards
+    auto orow = [&](int t) {
+        const int r = t * RC_ROWS + 32 * L.w + L.col;
+        return (int64_t)(r < a.M ? r : a.M - 1) * a.ldo_in + 8 * L.h;
+    };
+    {
+        const int64_t o = orow(tile);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { Bh[s] = *(const rbf16x8 *)(a.Ohi + o + 16 * s); Bl[s] = *(const rbf16x8 *)(a.Olo + o + 16 * s); }
+    }
+    rbf16x8 A[2][4];
+    {
+        SCP_BARRIER_DMA(0);
+        const RcFragAddr f = rc_frag_addr(L, smem);
+        RC_DS_READ(A[0][0], f.r0, 0); RC_DS_READ(A[0][1], f.r0, 16384); RC_DS_READ(A[0][2], f.r0, RC_SLOT); RC_DS_READ(A[0][3], f.r0, RC_SLOT + 16384);
+    }
+    int gstep = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * RC_ROWS;
+        const int row = m0 + 32 * L.w + L.col;
+        const int rowc = row < a.M ? row : a.M - 1;
+        const bool more = tile + (int)gridDim.x < ntiles;
+        rf32x16 Y[8];
+        // ---- phase 0: x1 = x + bp + proj(attention rows): four steps of two 32-channel blocks (one copy of the step's code).  The residual
+        // rows of a step's 64 channels (accumulator layout: channel 32 b + 8 q + 4 h + u) are requested in front of the step - older than
+        // its LDS-DMA pieces, so the step's barrier covers them - and added behind it.
+        const float *xsrc = a.x + (int64_t)rowc * a.ldx + 4 * L.h;
+        for (int j = 0; j < 4; ++j) {
+            rf32x4 xr[2][4];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xr[b][q] = *(const rf32x4 *)(xsrc + 64 * j + 32 * b + 8 * q);
+            rf32x16 c0, c1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+            rc_gemm_step<false>(L, smem, gstep & 1, c0, c1, Bh, Bl, A, wr, j < 3 ? src_p(2 * j + 2) : src_1(0), j < 3 ? src_p(2 * j + 3) : src_1(1));
+            ++gstep;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const rf32x4 b0 = *(const rf32x4 *)(sbp + 64 * j + 8 * q + 4 * L.h), b1 = *(const rf32x4 *)(sbp + 64 * j + 32 + 8 * q + 4 * L.h);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { c0[4 * q + u] += xr[0][q][u] + b0[u]; c1[4 * q + u] += xr[1][q][u] + b1[u]; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            switch (j) {
+            case 0: Y[0] = c0; Y[1] = c1; break;
+            case 1: Y[2] = c0; Y[3] = c1; break;
+            case 2: Y[4] = c0; Y[5] = c1; break;
+            default: Y[6] = c0; Y[7] = c1; break;
+            }
+        }
+        stamp(t_p0);
+        // ---- LayerNorm statistics of x1 over the row (this lane's 128 channels + lane ^ 32's) -------------------------------------------------
+        float sum = 0.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) sum += (Y[b][r] + Y[b][r + 1]) + (Y[b][r + 2] + Y[b][r + 3]);
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / 256.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = Y[b][r] - mean; sq += d * d; }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq * (1.0f / 256.0f) + a.eps);
+        // normalised rows -> B fragments of fc1 (k-step 2 b + t = registers 8 t .. 8 t + 7 of block b); Y += b2 (the MLP output bias)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float fr[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fr[i] = (Y[b][8 * t + i] - mean) * rstd;
+                rc_split8(fr, Bh[2 * b + t], Bl[2 * b + t]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const rf32x4 bb = *(const rf32x4 *)(sb2 + 32 * b + 8 * q + 4 * L.h);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Y[b][4 * q + u] += bb[u];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(t_ln);
+        if (a.dbg_mode) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = r >> 3, i = r & 7;
+                    Y[b][r] = (a.dbg_mode == 1) ? (float)Bh[2 * b + t][i] + (float)Bl[2 * b + t][i] : (r == 0 ? mean : rstd);
+                }
+        }
+        // ---- P1(0), P1(1) -----------------------------------------------------------------------------------------------------------
+        rf32x16 a1[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a1[0][r] = 0.f; a1[1][r] = 0.f; }
+        if (!a.dbg_mode) {
+        rc_gemm_step<true>(L, smem, gstep & 1, a1[0], a1[1], Bh, Bl, A, wr, src_1(2), src_2(0)); ++gstep;
+        // ---- GELU(0) (nothing to hide it behind yet) -----------------------------------------------------------------------------------
+        ru32x4 Hh[1][2], Hl[1][2];                                     // H(c): hi / lo fragments (bf16 pairs) of the two k-steps of a hidden chunk
+        rf32x4 bg[4];
+        auto load_bias = [&](int c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bg[q] = *(const rf32x4 *)(sb1 + 32 * c + 8 * q + 4 * L.h);
+        };
+        load_bias(0);
+        {
+            RcGelu g;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int st = 0; st < 12; ++st)
+                {
+                    unsigned wh = 0, wl = 0;
+                    rc_gelu_stage(st, g, a1[0][2 * k], a1[0][2 * k + 1], bg[k >> 1][(2 * k) & 3], bg[k >> 1][(2 * k + 1) & 3], wh, wl);
+                    if (st == 10) Hh[0][k >> 2][k & 3] = wh;
+                    if (st == 11) Hl[0][k >> 2][k & 3] = wl;
+                }
+        }
+        // ---- bodies: H(c) in (Hch, Hcl), P1(c + 1) in a1g; body c leaves H(c + 1) in (Hnh, Hnl) and P1(c + 2) in a1n; then they swap -----
+        ru32x4 Hnh[2], Hnl[2];
+        for (int c = 0; c < 30; ++c) {
+            load_bias(c + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            rf32x16 a1n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1n[r] = 0.f;
+            rc_body_step<true, true, 0>(L, smem, gstep & 1, Y, a1n, a1[1], bg, Hh[0], Hl[0], Hnh, Hnl, Bh, Bl, A, wr,
+                                        c + 3 < 32 ? src_1(c + 3) : src_2(c + 1), src_2(c + 1));
+            ++gstep;
+            a1[1] = a1n;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { Hh[0][t] = Hnh[t]; Hl[0][t] = Hnl[t]; }
+        }
+        // body 30: no P1 left; GELU(31).  The fragment registers are free: the next tile's attention rows are requested here
+        load_bias(31);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+            const int64_t o = orow(more ? tile + (int)gridDim.x : tile);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { Bh[s] = *(const rbf16x8 *)(a.Ohi + o + 16 * s); Bl[s] = *(const rbf16x8 *)(a.Olo + o + 16 * s); }
+        }
+        rc_body_step<false, true, 0>(L, smem, gstep & 1, Y, a1[0], a1[1], bg, Hh[0], Hl[0], Hnh, Hnl, Bh, Bl, A, wr, src_2(31), src_2(31));
+        ++gstep;
+        // body 31: P2 only; the step after it is phase 0 of the next tile
+        rc_body_step<false, false, 1>(L, smem, gstep & 1, Y, a1[0], a1[1], bg, Hnh, Hnl, Hh[0], Hl[0], Bh, Bl, A, wr, src_p(0), src_p(1));
+        ++gstep;
+        }
+        stamp(t_mlp);
+        // ---- x2 = Y -> fp32 rows -------------------------------------------------------------------------------------------------------
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t rows_left = (int64_t)a.M - m0;
+        const int64_t span = (rows_left < RC_ROWS ? rows_left : RC_ROWS) * a.ldc * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)m0 * a.ldc, 0, (int)span, 0x00020000);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            rf32x4 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[q][u] = Y[b][4 * q + u];
+            rc_store_block(L, bounce, o, rs, a.ldc * 4, 32 * L.w, 32 * b);
+        }
+        stamp(t_epi);
+        ++n_tiles;
+    }
+    if (DBG && L.lane == 0) {
+        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 4 + L.w) * 8;
+        o[0] = t_p0; o[1] = t_mlp; o[2] = t_ln; o[3] = t_epi; o[4] = n_tiles;
+    }
+    SCP_WAIT_DMA(0);
+}
+
 static unsigned long long *g_rc_dbg = nullptr;   // diagnostic only (tools/mb_rowchain_probe.py): [workgroup][wave][8] cycle sums
 extern "C" SCP_API int scp_rc_debug_buffer(unsigned long long *dev_buf) { g_rc_dbg = dev_buf; return SCP_OK; }
 
@@ -446,3 +842,35 @@ extern "C" SCP_API int scp_swin_ln_linear(const float *x, int64_t ldx, const flo
     LAUNCH_CHECK();
     return SCP_OK;
 }
+
+// x2 = x1 + fc2(GELU(fc1(LayerNorm(x1)))) with x1 = x + proj(o): the whole Swin block behind the attention (swin_transformer.py:503-571,
+// 662-706) for M rows.  o: attention output as bf16 hi/lo planes [M][ldo_in]; x: fp32 [M][ldx]; out: fp32 [M][ldc] (may be x).
+// W: ONE device buffer of scp_swin_post_attn_weight_bytes() bytes holding the tiled planes (scp_split_weight_bf16 + scp_tile_weight_bf16)
+// proj hi | fc1 hi | fc2 hi | proj lo | fc1 lo | fc2 lo with proj [256][256]; fc1 = (W1 diag(gamma))[:, rc_perm16] [1024][256]; fc2 =
+// W2[:, rc_perm16] [256][1024]; rc_perm16: inside every group of 16 columns, columns 4 - 7 and 8 - 11 change places.  b1 = the fc1 bias
+// + W1 beta (the LayerNorm affine folded in).
+extern "C" SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int64_t ldo_in, const float *x, int64_t ldx, const void *W, const float *bp,
+                                          const float *b1, const float *b2, float eps, float *out, int64_t ldc, int32_t M, void *stream) {
+    if (!Ohi || !Olo || !x || !W || !bp || !b1 || !b2 || !out || M <= 0 || ldo_in < 256 || (ldo_in & 7) || ldx < 256 || (ldx & 3) || ldc < 256 ||
+        (ldc & 3) || (((uintptr_t)Ohi | (uintptr_t)Olo | (uintptr_t)x | (uintptr_t)out | (uintptr_t)W) & 15) ||
+        (int64_t)RC_ROWS * ldc * 4 > 0x7fffffffLL)
+        return SCP_EINVAL;
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void *)rc_post_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
+        configured = true;
+    }
+    RcPostArgs a;
+    a.Ohi = (const __bf16 *)Ohi; a.Olo = (const __bf16 *)Olo; a.ldo_in = ldo_in; a.x = x; a.ldx = ldx; a.W = W;
+    a.bp = bp; a.b1 = b1; a.b2 = b2; a.out = out; a.ldc = ldc; a.M = M; a.eps = eps;
+    a.dbg = g_rc_dbg;
+    { const char *e = getenv("SCP_RC_DUMP"); a.dbg_mode = e ? atoi(e) : 0; }
+    const int ntiles = (M + RC_ROWS - 1) / RC_ROWS;
+    const int ncu = rc_num_cu();
+    hipLaunchKernelGGL(rc_post_attn_kernel, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+// size in bytes of the weight buffer of scp_swin_post_attn (six tiled planes, see RcPostArgs.W)
+extern "C" SCP_API int64_t scp_swin_post_attn_weight_bytes(void) { return 2 * (int64_t)RC_W_PLANE; }

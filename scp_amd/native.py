@@ -97,6 +97,8 @@ def lib():
         "scp_mlp_split_fused": (C.c_int, [_vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp, i64, i32, _vp]),
         "scp_tile_weight_bf16": (C.c_int, [_vp, i32, i32, _vp, _vp]),
         "scp_swin_ln_linear": (C.c_int, [_vp, i64, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, i32, _vp]),
+        "scp_swin_post_attn": (C.c_int, [_vp, _vp, i64, _vp, i64, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, _vp]),
+        "scp_swin_post_attn_weight_bytes": (C.c_int64, []),
         "scp_split_rows": (C.c_int, [_vp, i64, i64, _vp, i32, _vp, _vp, i64, i64, _vp]),
         "scp_linear_split_scatter": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_linear_split_gather": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
@@ -503,6 +505,14 @@ def _tiled_pair(sw):
     return sw._tiled
 
 
+def _tiled_planes_always(sw):
+    """(hi, lo) of a SplitWeight in the tiled layout whatever SCP_WTILE says (the row-chain kernels have no row-major mode)."""
+    th, tl = torch.empty_like(sw.hi), torch.empty_like(sw.lo)
+    for src, dst in ((sw.hi, th), (sw.lo, tl)):
+        _check(lib().scp_tile_weight_bf16(src.data_ptr(), sw.Npad, sw.Kpad, dst.data_ptr(), _stream()), "scp_tile_weight_bf16")
+    return th, tl
+
+
 def _tile_planes(t):
     """bf16 plane [Npad, Kpad] -> the tiled layout the LDS-DMA kernels read: block (16-row group rb, 32-element k-slab ks) = 1 KiB =
     the LDS image of one DMA instruction, [r][p][8] with the logical 16-byte chunk p ^ ((r >> 2) & 3) of row r at position p (the
@@ -701,6 +711,7 @@ class LnFoldedWeight:
     def __init__(self, w, gamma, beta):
         w64 = w.detach().double()
         self.sw = SplitWeight((w64 * gamma.detach().double()[None, :]).float())
+        self.planes = _tiled_planes_always(self.sw)
         self.wbeta = (w64 @ beta.detach().double()).float().contiguous()
         self.N, self.K = self.sw.N, self.sw.K
         note_cache_fill()
@@ -714,10 +725,56 @@ def swin_ln_linear(x, fw, bias, eps=1e-5, valid=None, out=None):
         raise ScpError("swin_ln_linear: 256-channel rows expected")
     if out is None:
         out = torch.empty((M, fw.N), dtype=torch.float32, device=x.device)
-    t = fw.sw.tiled()
+    t = fw.planes
     rc = lib().scp_swin_ln_linear(x.data_ptr(), x.stride(0), None if valid is None else _dev(valid, torch.float32), t[0].data_ptr(), t[1].data_ptr(),
                                   _opt(bias), _dev(fw.wbeta), float(eps), out.data_ptr(), out.stride(0), M, fw.N, _stream())
     _check(rc, "scp_swin_ln_linear")
+    return out
+
+
+def rc_perm16(n, device):
+    """Column permutation of the row-chain kernels' chained operands (csrc/rowchain.hip): inside every group of 16, columns 4-7 and
+    8-11 change places - the order in which an MFMA accumulator holds a row's channels, read as the next product's B fragment."""
+    p = torch.arange(n, device=device)
+    q = p & 15
+    return (p & ~15) | (q & 3) | ((q & 4) << 1) | ((q & 8) >> 1)
+
+
+class PostAttnWeights:
+    """Weights of a Swin block's post-attention half in the form scp_swin_post_attn streams (built once per block): proj as it is;
+    fc1 with layernorm_after's affine folded in (W1 diag(gamma), b1 + W1 beta) and its K axis in accumulator order; fc2 with its
+    hidden axis in accumulator order."""
+
+    def __init__(self, wp, bp, gamma, beta, w1, b1, w2, b2):
+        dev = wp.device
+        perm_k, perm_h = rc_perm16(256, dev), rc_perm16(w1.shape[0], dev)
+        w1d = w1.detach().double()
+        swp = SplitWeight(wp.detach().float().contiguous())
+        sw1 = SplitWeight((w1d * gamma.detach().double()[None, :]).float()[:, perm_k].contiguous())
+        sw2 = SplitWeight(w2.detach().float()[:, perm_h].contiguous())
+        # one buffer for the kernel's single buffer resource: the tiled planes proj hi | fc1 hi | fc2 hi | proj lo | fc1 lo | fc2 lo
+        tiles = [_tiled_planes_always(w) for w in (swp, sw1, sw2)]
+        self.packed = torch.cat([t[0].reshape(-1) for t in tiles] + [t[1].reshape(-1) for t in tiles]).contiguous()
+        if self.packed.numel() * 2 != lib().scp_swin_post_attn_weight_bytes():
+            raise ScpError("swin_post_attn: 256 -> 1024 -> 256 blocks only")
+        self.bp = bp.detach().float().contiguous()
+        self.b1 = (b1.detach().double() + w1d @ beta.detach().double()).float().contiguous()
+        self.b2 = b2.detach().float().contiguous()
+        note_cache_fill()
+
+
+def swin_post_attn(o, x, pw, eps=1e-5, out=None):
+    """x + proj(o) -> LayerNorm -> fc1 -> GELU -> fc2 -> + residual, one launch (csrc/rowchain.hip).  o: SplitAct [M, 256] (the attention
+    output planes), x: fp32 [M, 256] residual stream, pw: PostAttnWeights.  -> fp32 [M, 256] (`out` may be x itself)."""
+    M = x.shape[0]
+    if o.K != 256 or o.M != M or x.shape[1] != 256 or x.stride(1) != 1:
+        raise ScpError("swin_post_attn: [M, 256] operands expected")
+    if out is None:
+        out = torch.empty((M, 256), dtype=torch.float32, device=x.device)
+    t = o.t
+    rc = lib().scp_swin_post_attn(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), x.data_ptr(), x.stride(0), pw.packed.data_ptr(), _dev(pw.bp),
+                                  _dev(pw.b1), _dev(pw.b2), float(eps), out.data_ptr(), out.stride(0), M, _stream())
+    _check(rc, "scp_swin_post_attn")
     return out
 
 

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""scp_swin_post_attn (csrc/rowchain.hip) against the three launches it replaces (projection + residual, LayerNorm, fused MLP):
+correctness against float64 and time.    python tools/mb_postattn.py [rows]"""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from scp_amd import native
+from scp_amd.ops import linear_s, _split
+
+
+def timeit(f, n=5):
+    f(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        f()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+def main():
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else 590848
+    dev = torch.device("cuda:0"); native.lib()
+    g = torch.Generator().manual_seed(1)
+    rn = lambda *sh, s=1.0: (torch.randn(sh, generator=g) * s).to(dev)
+    x, ofull = rn(M, 256), rn(M, 256)
+    wp, bp = rn(256, 256, s=0.05), rn(256, s=0.1)
+    gamma, beta = 1 + rn(256, s=0.1), rn(256, s=0.1)
+    w1, b1, w2, b2 = rn(1024, 256, s=0.05), rn(1024, s=0.1), rn(256, 1024, s=0.03), rn(256, s=0.1)
+    o = native.split_rows(ofull)
+    pw = native.PostAttnWeights(wp, bp, gamma, beta, w1, b1, w2, b2)
+    y = native.swin_post_attn(o, x, pw)
+    torch.cuda.synchronize()
+    idx = torch.cat((torch.arange(0, min(M, 300)), torch.randint(0, M, (1500,), generator=g), torch.arange(max(0, M - 300), M))).to(dev)
+    xs, os_ = x[idx].double(), ofull[idx].double()
+    x1 = xs + os_ @ wp.double().T + bp.double()
+    h = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x1, (256,), gamma.double(), beta.double(), 1e-5) @ w1.double().T + b1.double())
+    ref = x1 + h @ w2.double().T + b2.double()
+    err = (y[idx].double() - ref).abs().max().item()
+
+    def old():
+        x1_ = linear_s(o, wp, bp, residual=x)
+        h2 = native.layernorm_rows(x1_, gamma, beta, 1e-5, split=True)
+        return native.mlp_split_fused(h2, _split(w1), b1, _split(w2), b2, residual=x1_)
+    y2 = old()
+    err_old = (y2[idx].double() - ref).abs().max().item()
+    print(f"M={M}: max err vs float64: rowchain {err:.2e}, three launches {err_old:.2e}   (|ref| max {ref.abs().max().item():.1f})", flush=True)
+    t_new, t_old = timeit(lambda: native.swin_post_attn(o, x, pw, out=y)), timeit(old)
+    fl = 2.0 * M * (256 * 256 + 2 * 256 * 1024)
+    print(f"rowchain {t_new:.3f} ms ({fl / t_new / 1e9:.0f} TF/s alg)   |   proj + LN + fused MLP {t_old:.3f} ms ({fl / t_old / 1e9:.0f} TF/s alg)", flush=True)
+    for Mr in (1, 33, 128, 129, 1000):
+        yr = native.swin_post_attn(native.split_rows(ofull[:Mr].contiguous()), x[:Mr].contiguous(), pw)
+        ok = torch.equal(yr, y[:Mr])
+        print(f"M={Mr}: rows equal the big launch's bit for bit: {ok}")
+    if os.environ.get("RC_STAMPS"):
+        import ctypes
+        L = native.lib(); L.scp_rc_debug_buffer.argtypes = [ctypes.c_void_p]
+        buf = torch.zeros((256 * 4 * 8,), dtype=torch.int64, device=dev)
+        L.scp_rc_debug_buffer(buf.data_ptr()); native.swin_post_attn(o, x, pw, out=y); torch.cuda.synchronize(); L.scp_rc_debug_buffer(None)
+        b = buf.cpu().view(256, 4, 8).double(); tiles = b[:, :, 4].clamp(min=1)
+        print("cycles per tile and wave: phase 0 / MLP (P1 prologue + 32 bodies) / LayerNorm / epilogue: " + " / ".join(f"{(b[:, :, i] / tiles).mean():.0f}" for i in (0, 1, 2, 3)))
+
+
+if __name__ == "__main__":
+    main()
