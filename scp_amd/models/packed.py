@@ -140,9 +140,56 @@ class PackedPlan:
 FUSED_MLP = __import__('os').environ.get('SCP_MLP', 'fused') != 'split'   # SCP_MLP=split: fc1 and fc2 as two launches
 
 
+# SCP_SWIN=split: the Swin blocks as the separate launches of rounds 1 - 2 (LayerNorm, q|k|v GEMM, attention, projection GEMM, LayerNorm,
+# fused MLP); default: the row-chain kernels of csrc/rowchain.hip - LayerNorm + q|k|v in one launch, everything behind the attention in
+# another (11 KB of HBM traffic per row and block instead of 17 + 3.6 of re-reads)
+ROWCHAIN = __import__('os').environ.get('SCP_SWIN', 'rowchain') != 'split'
+
+
+def _rowchain_weights(layer, cross):
+    """Derived weights of a block for the row-chain kernels (rebuilt when a parameter changes): LayerNorm-folded q|k|v (or k|v and q for a
+    cross layer) and the packed post-attention buffer."""
+    att = layer.attention.self
+    lnb, lna = layer.layernorm_before, layer.layernorm_after
+    W, b = qkv_fused(layer, cross)
+    fc1, fc2, proj = layer.intermediate.dense, layer.output.dense, layer.attention.output.dense
+    srcs = [W, b, lnb.weight, lnb.bias, lna.weight, lna.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, proj.weight, proj.bias]
+    if cross:
+        srcs += [att.query.weight, att.query.bias]
+
+    def build():
+        out = dict(kv=native.LnFoldedWeight(W, lnb.weight, lnb.bias), b=b,
+                   post=native.PostAttnWeights(proj.weight, proj.bias, lna.weight, lna.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias))
+        if cross:
+            out["q"] = native.LnFoldedWeight(att.query.weight, lnb.weight, lnb.bias)
+        return out
+    return derived(layer, "rowchain+" if cross else "rowchain", srcs, build)
+
+
+def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None):
+    """The same block on two row-chain launches around the attention kernel."""
+    att = layer.attention.self
+    cross = query is not None
+    w = _rowchain_weights(layer, cross)
+    lnb = layer.layernorm_before
+    v1 = None if valid is None else valid.reshape(-1)
+    if not cross:
+        qkv = native.swin_ln_linear(x, w["kv"], w["b"], lnb.eps, v1)
+        q, k, v = qkv[:, :256], qkv[:, 256:512], qkv[:, 512:]
+    else:
+        q = native.swin_ln_linear(query, w["q"], att.query.bias, lnb.eps, v1)
+        kv = native.swin_ln_linear(x, w["kv"], w["b"], lnb.eps, v1)
+        k, v = kv[:, :256], kv[:, 256:]
+    o = native.swin_attention_packed(q, k, v, att.relative_position_bias_table, wtab, shift, split=True)
+    return native.swin_post_attn(o, x, w["post"], layer.layernorm_after.eps)
+
+
 def _swin_layer(layer, x, valid, wtab, shift, query=None):
     """swin_transformer.py:654-706 on a packed layout (rows beyond a window's length are don't-care, except that the
     LayerNorm output is zeroed there - the reference zero-pads AFTER LayerNorm)."""
+    fc1, fc2 = layer.intermediate.dense, layer.output.dense
+    if ROWCHAIN and x.shape[1] == 256 and fc1.weight.shape == (1024, 256) and fc2.weight.shape == (256, 1024):
+        return _swin_layer_rowchain(layer, x, valid, wtab, shift, query)
     att = layer.attention.self
     cross = query is not None
     W, b = qkv_fused(layer, cross)

@@ -395,7 +395,8 @@ def numeric_profile(model_name):
     from .models import packed
     if model_name == "OctAttention":
         return f"octattn/1:gemm={ops.MODE},attn={OCTATTN_MODE}"
-    return f"ehem/1:gemm={ops.MODE},knn={_MODES['knn']},attn={_MODES['attn']},concat={'hier' if packed.HIER else 'direct'}"
+    return (f"ehem/2:gemm={ops.MODE},knn={_MODES['knn']},attn={_MODES['attn']},concat={'hier' if packed.HIER else 'direct'},"
+            f"swin={'rowchain' if packed.ROWCHAIN else 'split'}")
 
 
 def edge_gather_max(u, v, idx, scale, shift, out=None):
