@@ -121,6 +121,15 @@ __device__ __forceinline__ rbf16x8 rc_frag_kchunk(const RcLane &L, const char *s
     return *(const rbf16x8 *)(slot + plane * 16384 + (2 * b + L.rg) * 1024 + (L.frag ^ (t << 5)));
 }
 
+// The first fragments of the NEXT step are read behind the last MFMA of a step, all four and their wait in ONE asm statement: the
+// compiler treats an asm output as valid the moment the statement ends, and across a step boundary it does move these registers (a
+// v_accvgpr_write right behind the read that fills them copied stale bytes: errors of one lo plane, 1e-4, that came and went with
+// unrelated edits).  Inside a step - one basic block - nothing may touch a fragment between its read and the counted wait:
+// tests/test_rowchain_isa.py scans the generated code for exactly that.
+#define RC_DS_READ4_WAIT(d0, a0, o0, d1, a1, o1, d2, a2, o2, d3, a3, o3)                                                              \
+    asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%9\n\tds_read_b128 %2, %6 offset:%10\n\t"                   \
+                 "ds_read_b128 %3, %7 offset:%11\n\ts_waitcnt lgkmcnt(0)"                                                              \
+                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(o0), "n"(o1), "n"(o2), "n"(o3) : "memory")
 #define RC_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 
 // bf16x3 product step on two alternating chains (same order of the three partial products as gemm_split.hip: lo.hi, hi.lo, hi.hi)
@@ -200,6 +209,11 @@ struct RcLnLinArgs {
 // All LDS traffic of the loop is inline asm with hand-counted waits: the compiler's wait insertion cannot see across asm, and what it
 // inserts for its own LDS reads drains the read-ahead.
 #define RC_SB __builtin_amdgcn_sched_barrier(0)
+#ifdef RC_WAIT0
+#define RC_FRAG_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define RC_FRAG_WAIT() asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory")
+#endif
 #ifndef RC_STORE_AUX
 #define RC_STORE_AUX 0              // cache policy of the output stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
@@ -219,8 +233,8 @@ __device__ __forceinline__ void rc_ll_step(const RcLane &L, const RcLnLinArgs &a
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         if (st && (s == 1 || s == 8 || s == 15)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); st[s == 1 ? 0 : s == 8 ? 1 : 2] += t - ts0; ts0 = t; }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the fragments of this k-step (requested a slice ago)
-        if (s == 15) {                                              // next step's slots landed; every wave is done reading this half's
+        if (s == 15) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              // next step's slots landed; every wave is done reading this half's
             if (PROBE) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             else if (LOADX) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
@@ -228,10 +242,13 @@ __device__ __forceinline__ void rc_ll_step(const RcLane &L, const RcLnLinArgs &a
         }
         RC_SB;
         const int nb = (s + 1) & 1, ns = (s + 1) & 15;
-        const unsigned ra = (s == 15) ? an0 : ((ns & 1) ? ad1 : ad0);
+        const unsigned ra = (ns & 1) ? ad1 : ad0;
 #pragma unroll
         for (int gap = 0; gap < 6; ++gap) {
-            // ---- the MFMA of this gap (product order lo.hi, hi.lo, hi.hi on both chains, as everywhere) -------------------------------
+            // ---- the MFMA of this gap (product order lo.hi, hi.lo, hi.hi on both chains, as everywhere).  The four fragments of this
+            // k-step were requested one per gap of the slice before, in the order their first MFMA needs them: before each of the first
+            // four MFMAs the oldest outstanding read is the one it needs - a whole slice old - and the three younger ones stay in flight
+            if (gap < 4) { RC_FRAG_WAIT(); RC_SB; }
             if (gap == 0) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][1], Xh[s], c0, 0, 0, 0);
             if (gap == 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][3], Xh[s], c1, 0, 0, 0);
             if (gap == 2) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0], Xl[s], c0, 0, 0, 0);
@@ -240,11 +257,11 @@ __device__ __forceinline__ void rc_ll_step(const RcLane &L, const RcLnLinArgs &a
             if (gap == 5) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][2], Xh[s], c1, 0, 0, 0);
             RC_SB;
             // ---- what rides in the gap behind it ----------------------------------------------------------------------------------------
-            if (gap < 4) {                                          // fragment gap of the next k-step: (slot gap >> 1, plane gap & 1)
-                if (gap == 0) RC_DS_READ(A[nb][0], ra, (ns >> 1) * 1024);
-                if (gap == 1) RC_DS_READ(A[nb][1], ra, 16384 + (ns >> 1) * 1024);
-                if (gap == 2) RC_DS_READ(A[nb][2], ra, RC_SLOT + (ns >> 1) * 1024);
-                if (gap == 3) RC_DS_READ(A[nb][3], ra, RC_SLOT + 16384 + (ns >> 1) * 1024);
+            if (gap < 4 && s < 15) {                                // a fragment of the next k-step, in the order of use: lo 0, lo 1, hi 0, hi 1
+                if (gap == 0) RC_DS_READ(A[nb][1], ra, 16384 + (ns >> 1) * 1024);
+                if (gap == 1) RC_DS_READ(A[nb][3], ra, RC_SLOT + 16384 + (ns >> 1) * 1024);
+                if (gap == 2) RC_DS_READ(A[nb][0], ra, (ns >> 1) * 1024);
+                if (gap == 3) RC_DS_READ(A[nb][2], ra, RC_SLOT + (ns >> 1) * 1024);
             }
             if (s < 8 && (gap == 1 || gap == 3) && !(PROBE & 2)) {   // one of the next step's 16 LDS-DMA pieces: slot s >> 2, block w + 4 (s & 3)
                 // (buffer form: the per-lane offset 16 lane in one VGPR for all pieces, the piece's offset in an SGPR; no wave-dependent
@@ -283,7 +300,7 @@ __device__ __forceinline__ void rc_ll_step(const RcLane &L, const RcLnLinArgs &a
             RC_SB;
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the next step's first fragments: waited for before any block boundary
+    RC_DS_READ4_WAIT(A[0][1], an0, 16384, A[0][3], an0, RC_SLOT + 16384, A[0][0], an0, 0, A[0][2], an0, RC_SLOT);   // next step, k-step 0
     if (st) { const unsigned long long t = __builtin_amdgcn_s_memtime(); st[4] += t - ts0; }
 }
 
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
     {
         SCP_BARRIER_DMA(0);                                         // (also drains the row loads: once per launch)
         const unsigned ad0 = (unsigned)(uintptr_t)(rc_lds_ptr_t)(smem) + L.rg * 8192 + L.frag;
-        RC_DS_READ(A[0][0], ad0, 0); RC_DS_READ(A[0][1], ad0, 16384); RC_DS_READ(A[0][2], ad0, RC_SLOT); RC_DS_READ(A[0][3], ad0, RC_SLOT + 16384);
+        RC_DS_READ4_WAIT(A[0][1], ad0, 16384, A[0][3], ad0, RC_SLOT + 16384, A[0][0], ad0, 0, A[0][2], ad0, RC_SLOT);
     }
     int gstep = 0;
     for (; tile < ntiles; tile += gridDim.x) {
@@ -467,6 +484,16 @@ __device__ __forceinline__ RcFragAddr rc_frag_addr(const RcLane &L, char *half_b
     return f;
 }
 
+// Measured and dropped: the MFMAs as inline asm with every operand's register file pinned (accumulators and half of the resident B
+// fragments in AGPRs, everything the VALU touches in VGPRs).  gfx950 gives a wave 256 + 256 registers and only MFMA operands may sit in
+// the second half; the compiler keeps the two live chains in a[0:31] and parks everything else in the other AGPRs through
+// v_accvgpr moves (about 2.7 per MFMA gap).  With asm MFMAs it no longer inserts the wait states between a VALU write of a register
+// (its own v_accvgpr copies for the "a" constraints, the zeroing of an accumulator) and the MFMA that reads it: wrong results that
+// come and go with timing, and the build that added the nops by hand was slower (186 k against 171 k cycles per tile for the MLP).
+#define RC_MFMA_AVA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0)
+#define RC_MFMA_AVV(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(rbf16x8, b), acc, 0, 0, 0)
+#define RC_MFMA_DRAIN() do { } while (0)
+
 // GEMM step: two row-chunk slots, two chains (c0: slot 0, c1: slot 1) over the 16 k-steps of the resident B fragments.  Used for
 // phase 0 (B = attention rows, chains = Y blocks) and for P1(0), P1(1).  NEXT_BODY: the step after this one is a body step (its first
 // fragments are a row-chunk and a k-chunk fragment) - they are read in slice 15, after the barrier that publishes the next ring half.
@@ -478,36 +505,33 @@ __device__ __forceinline__ void rc_gemm_step(const RcLane &L, char *smem, int ha
     char *nxt = smem + (half ^ 1) * (2 * RC_SLOT);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (s == 15) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s == 15) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         RC_SB;
         const int nb = (s + 1) & 1, ns = (s + 1) & 15;
 #pragma unroll
         for (int gap = 0; gap < 6; ++gap) {
-            if (gap == 0) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][1], Bh[s], c0, 0, 0, 0);
-            if (gap == 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][3], Bh[s], c1, 0, 0, 0);
-            if (gap == 2) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0], Bl[s], c0, 0, 0, 0);
-            if (gap == 3) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][2], Bl[s], c1, 0, 0, 0);
-            if (gap == 4) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0], Bh[s], c0, 0, 0, 0);
-            if (gap == 5) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][2], Bh[s], c1, 0, 0, 0);
+            if (gap < 4) { RC_FRAG_WAIT(); RC_SB; }   // the fragment this MFMA is the first to use (see rc_ll_step)
+            if (gap == 0) RC_MFMA_AVA(c0, A[s & 1][1], Bh[s]);
+            if (gap == 1) RC_MFMA_AVA(c1, A[s & 1][3], Bh[s]);
+            if (gap == 2) RC_MFMA_AVV(c0, A[s & 1][0], Bl[s]);
+            if (gap == 3) RC_MFMA_AVV(c1, A[s & 1][2], Bl[s]);
+            if (gap == 4) RC_MFMA_AVA(c0, A[s & 1][0], Bh[s]);
+            if (gap == 5) RC_MFMA_AVA(c1, A[s & 1][2], Bh[s]);
             RC_SB;
             if (s < 15) {
                 const unsigned ra = (ns & 1) ? f.r1 : f.r0;
-                if (gap == 0) RC_DS_READ(A[nb][0], ra, (ns >> 1) * 1024);
-                if (gap == 1) RC_DS_READ(A[nb][1], ra, 16384 + (ns >> 1) * 1024);
-                if (gap == 2) RC_DS_READ(A[nb][2], ra, RC_SLOT + (ns >> 1) * 1024);
-                if (gap == 3) RC_DS_READ(A[nb][3], ra, RC_SLOT + 16384 + (ns >> 1) * 1024);
-            } else {   // first fragments of the next step, from the other ring half
-                if (gap == 0) RC_DS_READ(A[0][0], fn.r0, 0);
-                if (gap == 1) RC_DS_READ(A[0][1], fn.r0, 16384);
-                if (gap == 2) { if (NEXT_BODY) RC_DS_READ(A[0][2], fn.k0, RC_SLOT); else RC_DS_READ(A[0][2], fn.r0, RC_SLOT); }
-                if (gap == 3) { if (NEXT_BODY) RC_DS_READ(A[0][3], fn.k0, RC_SLOT + 16384); else RC_DS_READ(A[0][3], fn.r0, RC_SLOT + 16384); }
+                if (gap == 0) RC_DS_READ(A[nb][1], ra, 16384 + (ns >> 1) * 1024);
+                if (gap == 1) RC_DS_READ(A[nb][3], ra, RC_SLOT + 16384 + (ns >> 1) * 1024);
+                if (gap == 2) RC_DS_READ(A[nb][0], ra, (ns >> 1) * 1024);
+                if (gap == 3) RC_DS_READ(A[nb][2], ra, RC_SLOT + (ns >> 1) * 1024);
             }
             if (s < 8 && (gap == 1 || gap == 3)) rc_dma_piece(L, wr, (s >> 2) ? n1 : n0, nxt + (s >> 2) * RC_SLOT, s, gap >> 1);
             RC_SB;
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the next step's first fragments: waited for before any block boundary
+    // first fragments of the next step, from the other ring half (published by the barrier of slice 15)
+    if (NEXT_BODY) RC_DS_READ4_WAIT(A[0][1], fn.r0, 16384, A[0][3], fn.k0, RC_SLOT + 16384, A[0][0], fn.r0, 0, A[0][2], fn.k0, RC_SLOT);
+    else RC_DS_READ4_WAIT(A[0][1], fn.r0, 16384, A[0][3], fn.r0, RC_SLOT + 16384, A[0][0], fn.r0, 0, A[0][2], fn.r0, RC_SLOT);
 }
 
 // exact-erf GELU of gemm_split.hip (same polynomial), two elements at a time, cut into 12 stages of 4 VALU instructions: one stage per
@@ -549,31 +573,27 @@ __device__ __forceinline__ void rc_body_step(const RcLane &L, char *smem, int ha
     RcGelu g;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (s == 15) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s == 15) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         RC_SB;
         const int nb = (s + 1) & 1, ns = (s + 1) & 15;
         const int blk = s >> 1, t = s & 1;
 #pragma unroll
         for (int gap = 0; gap < 6; ++gap) {
+            if (gap < 4) { RC_FRAG_WAIT(); RC_SB; }   // the fragment this MFMA is the first to use (see rc_ll_step)
             // P1 k-step s on chain a1n (fragments A[.][0] hi, A[.][1] lo) and P2 (blk, t) on chain Y[blk] (A[.][2] hi, A[.][3] lo), alternating
-            if (gap == 0 && HAS_P1) a1n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][1], Xh[s], a1n, 0, 0, 0);
-            if (gap == 1) Y[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][3], __builtin_bit_cast(rbf16x8, Hch[t]), Y[blk], 0, 0, 0);
-            if (gap == 2 && HAS_P1) a1n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0], Xl[s], a1n, 0, 0, 0);
-            if (gap == 3) Y[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][2], __builtin_bit_cast(rbf16x8, Hcl[t]), Y[blk], 0, 0, 0);
-            if (gap == 4 && HAS_P1) a1n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0], Xh[s], a1n, 0, 0, 0);
-            if (gap == 5) Y[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][2], __builtin_bit_cast(rbf16x8, Hch[t]), Y[blk], 0, 0, 0);
+            if (gap == 0 && HAS_P1) RC_MFMA_AVA(a1n, A[s & 1][1], Xh[s]);
+            if (gap == 1) RC_MFMA_AVV(Y[blk], A[s & 1][3], Hch[t]);
+            if (gap == 2 && HAS_P1) RC_MFMA_AVV(a1n, A[s & 1][0], Xl[s]);
+            if (gap == 3) RC_MFMA_AVV(Y[blk], A[s & 1][2], Hcl[t]);
+            if (gap == 4 && HAS_P1) RC_MFMA_AVA(a1n, A[s & 1][0], Xh[s]);
+            if (gap == 5) RC_MFMA_AVV(Y[blk], A[s & 1][2], Hch[t]);
             RC_SB;
             if (s < 15) {
-                if (gap == 0 && HAS_P1) RC_DS_READ(A[nb][0], (ns & 1) ? f.r1 : f.r0, (ns >> 1) * 1024);
-                if (gap == 1 && HAS_P1) RC_DS_READ(A[nb][1], (ns & 1) ? f.r1 : f.r0, 16384 + (ns >> 1) * 1024);
-                if (gap == 2) RC_DS_READ(A[nb][2], (ns & 1) ? f.k1 : f.k0, RC_SLOT + (ns >> 1) * 2048);
-                if (gap == 3) RC_DS_READ(A[nb][3], (ns & 1) ? f.k1 : f.k0, RC_SLOT + 16384 + (ns >> 1) * 2048);
-            } else {   // first fragments of the next step, from the other ring half
-                if (gap == 0) RC_DS_READ(A[0][0], fn.r0, 0);
-                if (gap == 1) RC_DS_READ(A[0][1], fn.r0, 16384);
-                if (gap == 2) { if (NEXT == 0) RC_DS_READ(A[0][2], fn.k0, RC_SLOT); else RC_DS_READ(A[0][2], fn.r0, RC_SLOT); }
-                if (gap == 3) { if (NEXT == 0) RC_DS_READ(A[0][3], fn.k0, RC_SLOT + 16384); else RC_DS_READ(A[0][3], fn.r0, RC_SLOT + 16384); }
+                // (always four reads per slice, also where P1 is over: the counted waits rely on it)
+                if (gap == 0) RC_DS_READ(A[nb][1], (ns & 1) ? f.r1 : f.r0, 16384 + (ns >> 1) * 1024);
+                if (gap == 1) RC_DS_READ(A[nb][3], (ns & 1) ? f.k1 : f.k0, RC_SLOT + 16384 + (ns >> 1) * 2048);
+                if (gap == 2) RC_DS_READ(A[nb][0], (ns & 1) ? f.r1 : f.r0, (ns >> 1) * 1024);
+                if (gap == 3) RC_DS_READ(A[nb][2], (ns & 1) ? f.k1 : f.k0, RC_SLOT + (ns >> 1) * 2048);
             }
             if (s < 8 && (gap == 1 || gap == 3)) rc_dma_piece(L, wr, (s >> 2) ? n1 : n0, nxt + (s >> 2) * RC_SLOT, s, gap >> 1);
             if (HAS_GELU) {   // element pair (2 k, 2 k + 1) of the finished P1 chain, k = s >> 1: registers 2 k, 2 k + 1 = fragment (k >> 2), elements 2 (k & 3), + 1
@@ -586,7 +606,9 @@ __device__ __forceinline__ void rc_body_step(const RcLane &L, char *smem, int ha
             RC_SB;
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the next step's first fragments: waited for before any block boundary
+    // first fragments of the next step, from the other ring half (published by the barrier of slice 15)
+    if (NEXT == 0) RC_DS_READ4_WAIT(A[0][1], fn.r0, 16384, A[0][3], fn.k0, RC_SLOT + 16384, A[0][0], fn.r0, 0, A[0][2], fn.k0, RC_SLOT);
+    else RC_DS_READ4_WAIT(A[0][1], fn.r0, 16384, A[0][3], fn.r0, RC_SLOT + 16384, A[0][0], fn.r0, 0, A[0][2], fn.r0, RC_SLOT);
 }
 
 __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a) {
@@ -633,7 +655,7 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
     {
         SCP_BARRIER_DMA(0);
         const RcFragAddr f = rc_frag_addr(L, smem);
-        RC_DS_READ(A[0][0], f.r0, 0); RC_DS_READ(A[0][1], f.r0, 16384); RC_DS_READ(A[0][2], f.r0, RC_SLOT); RC_DS_READ(A[0][3], f.r0, RC_SLOT + 16384);
+        RC_DS_READ4_WAIT(A[0][1], f.r0, 16384, A[0][3], f.r0, RC_SLOT + 16384, A[0][0], f.r0, 0, A[0][2], f.r0, RC_SLOT);
     }
     int gstep = 0;
     for (; tile < ntiles; tile += gridDim.x) {
@@ -642,7 +664,8 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
         const int rowc = row < a.M ? row : a.M - 1;
         const bool more = tile + (int)gridDim.x < ntiles;
         rf32x16 Y[8];
-        // ---- phase 0: x1 = x + bp + proj(attention rows): four steps of two 32-channel blocks (one copy of the step's code).  The residual
+        // ---- phase 0: x1 = x + bp + proj(attention rows): four steps of two 32-channel blocks (ONE copy of the step's code; the unrolled
+        // form that accumulates straight into Y[2 j], Y[2 j + 1] is 680 instructions longer and no faster).  The residual
         // rows of a step's 64 channels (accumulator layout: channel 32 b + 8 q + 4 h + u) are requested in front of the step - older than
         // its LDS-DMA pieces, so the step's barrier covers them - and added behind it.
         const float *xsrc = a.x + (int64_t)rowc * a.ldx + 4 * L.h;
@@ -820,9 +843,6 @@ extern "C" SCP_API int scp_swin_ln_linear(const float *x, int64_t ldx, const flo
     static bool configured = false;
     if (!configured) {
         HIP_TRY(hipFuncSetAttribute((const void *)rc_ln_linear_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
-        HIP_TRY(hipFuncSetAttribute((const void *)rc_ln_linear_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
-        HIP_TRY(hipFuncSetAttribute((const void *)rc_ln_linear_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
-        HIP_TRY(hipFuncSetAttribute((const void *)rc_ln_linear_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
         configured = true;
     }
     RcLnLinArgs a;
@@ -833,12 +853,7 @@ extern "C" SCP_API int scp_swin_ln_linear(const float *x, int64_t ldx, const flo
     a.dbg = g_rc_dbg;
     const int ntiles = (M + RC_ROWS - 1) / RC_ROWS;
     const int ncu = rc_num_cu();
-    const dim3 grid((unsigned)(ntiles < ncu ? ntiles : ncu));
-    // SCP_RC_PROBE (tools/mb_rowchain_probe.py; RESULTS ARE WRONG): builds without the LDS-DMA (2), the bounce + stores (8), or both and the row prefetch (14)
-    if ((a.probe & 14) == 14) hipLaunchKernelGGL(rc_ln_linear_kernel<14>, grid, dim3(256), RC_LDS, (hipStream_t)stream, a);
-    else if (a.probe & 8) hipLaunchKernelGGL(rc_ln_linear_kernel<8>, grid, dim3(256), RC_LDS, (hipStream_t)stream, a);
-    else if (a.probe & 2) hipLaunchKernelGGL(rc_ln_linear_kernel<2>, grid, dim3(256), RC_LDS, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(rc_ln_linear_kernel<0>, grid, dim3(256), RC_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(rc_ln_linear_kernel<0>, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;
 }
