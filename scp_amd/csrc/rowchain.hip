@@ -147,19 +147,23 @@ __device__ __forceinline__ void rc_mfma3x2(rf32x16 &c0, rf32x16 &c1, const rbf16
 // (r & 3)) as fp32 rows: through the wave's private 4 KiB bounce buffer (16-byte chunk c of row n at chunk c ^ (n & 7): conflict-free
 // both ways), so that every global store instruction writes 8 rows x one whole 128-byte line.  `rs` addresses the tile's first
 // row of the output (buffer resource: rows beyond M are dropped by the range check, no branch).
-__device__ __forceinline__ void rc_store_block(const RcLane &L, char *bounce, const rf32x4 v[4], __amdgpu_buffer_rsrc_t rs, int64_t ldo_bytes,
-                                               int row_in_tile0, int ch0) {
+__device__ __forceinline__ void rc_store_block(const RcLane &L, char *bounce, const rf32x4 v[4], __amdgpu_buffer_rsrc_t rs, int ldo_bytes, int voff,
+                                               int ch0) {
+    // voff = (32 w + (lane >> 3)) * ldo_bytes + (lane & 7) * 16: the one per-lane offset; row group and channel block go into the scalar
+    // offset of the store (32 per-lane offsets, one per store of a tile, were hoisted, spilled, and each store then waited for its
+    // reload - and with it, vmcnt being in order, for every store before it: 20 k cycles per tile)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         *(rf32x4 *)(bounce + L.col * 128 + (((2 * q + L.h) ^ (L.col & 7)) << 4)) = v[q];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    rf32x4 y[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int rho = 8 * it + (L.lane >> 3), kap = L.lane & 7;
-        const rf32x4 y = *(const rf32x4 *)(bounce + rho * 128 + ((kap ^ (rho & 7)) << 4));
-        const int64_t off = (int64_t)(row_in_tile0 + rho) * ldo_bytes + (ch0 + 4 * kap) * 4;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ri32x4, y), rs, (int)off, 0, 0);
+        y[it] = *(const rf32x4 *)(bounce + rho * 128 + ((kap ^ (rho & 7)) << 4));
     }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ri32x4, y[it]), rs, voff, it * 8 * ldo_bytes + ch0 * 4, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the bounce buffer is free again
 }
 
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) o[q][u] = acc[1][blk][4 * q + u];
-            rc_store_block(L, bounce, o, rs, a.ldo * 4, 32 * L.w, 64 * (nsteps - 1) + 32 * blk);
+            rc_store_block(L, bounce, o, rs, ldo_bytes, voff, 64 * (nsteps - 1) + 32 * blk);
         }
         stamp(t_drain);
         ++n_tiles;
@@ -558,6 +562,17 @@ __device__ __forceinline__ void rc_gelu_stage(int st, RcGelu &g, float acc_a, fl
     case 10: g.ga = fmaf(g.ya, g.pa, g.ya); g.gb = fmaf(g.yb, g.pb, g.yb); g.hw = rc_pack2(g.ga, g.gb); wh = g.hw; break;
     default: wl = rc_pack2(g.ga - __builtin_bit_cast(float, g.hw << 16), g.gb - __builtin_bit_cast(float, g.hw & 0xffff0000u)); break;
     }
+    // Pin the stage where it is written: the values are pure arithmetic, and without this the optimiser sinks all twelve stages of a pair
+    // to the last one's gap (and packs them into v_pk_fma_f32, which is dearer beside MFMAs) - one gap of 30 VALU instructions with the
+    // matrix pipe idle instead of 4 in each of 12 gaps.  An empty asm that "modifies" the live state ends every stage.
+    switch (st) {
+    case 0: asm volatile("" : "+v"(g.ya), "+v"(g.yb), "+v"(g.za), "+v"(g.zb)); break;
+    case 1: asm volatile("" : "+v"(g.ca), "+v"(g.cb), "+v"(g.ua), "+v"(g.ub)); break;
+    case 2: asm volatile("" : "+v"(g.ua), "+v"(g.ub), "+v"(g.pa), "+v"(g.pb)); break;
+    case 3: case 4: case 5: case 6: case 7: case 8: case 9: asm volatile("" : "+v"(g.pa), "+v"(g.pb)); break;
+    case 10: asm volatile("" : "+v"(g.ga), "+v"(g.gb), "+v"(g.hw)); break;
+    default: break;
+    }
 }
 
 // Body step c: slot 0 = W1' rows [32 (c + 2), +32) (row chunk), slot 1 = W2 hidden slab c (k chunk).
@@ -579,7 +594,10 @@ __device__ __forceinline__ void rc_body_step(const RcLane &L, char *smem, int ha
         const int blk = s >> 1, t = s & 1;
 #pragma unroll
         for (int gap = 0; gap < 6; ++gap) {
-            if (gap < 4) { RC_FRAG_WAIT(); RC_SB; }   // the fragment this MFMA is the first to use (see rc_ll_step)
+            // the fragment this MFMA is the first to use (see rc_ll_step); where P1 is over only the two W2 fragments are read per slice -
+            // a read nothing uses is a register the compiler hands to the next VALU instruction while the read is still in flight
+            if (HAS_P1 && gap < 4) { RC_FRAG_WAIT(); RC_SB; }
+            if (!HAS_P1 && (gap == 1 || gap == 3)) { asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); RC_SB; }
             // P1 k-step s on chain a1n (fragments A[.][0] hi, A[.][1] lo) and P2 (blk, t) on chain Y[blk] (A[.][2] hi, A[.][3] lo), alternating
             if (gap == 0 && HAS_P1) RC_MFMA_AVA(a1n, A[s & 1][1], Xh[s]);
             if (gap == 1) RC_MFMA_AVV(Y[blk], A[s & 1][3], Hch[t]);
@@ -589,10 +607,9 @@ __device__ __forceinline__ void rc_body_step(const RcLane &L, char *smem, int ha
             if (gap == 5) RC_MFMA_AVV(Y[blk], A[s & 1][2], Hch[t]);
             RC_SB;
             if (s < 15) {
-                // (always four reads per slice, also where P1 is over: the counted waits rely on it)
-                if (gap == 0) RC_DS_READ(A[nb][1], (ns & 1) ? f.r1 : f.r0, 16384 + (ns >> 1) * 1024);
+                if (gap == 0 && HAS_P1) RC_DS_READ(A[nb][1], (ns & 1) ? f.r1 : f.r0, 16384 + (ns >> 1) * 1024);
                 if (gap == 1) RC_DS_READ(A[nb][3], (ns & 1) ? f.k1 : f.k0, RC_SLOT + 16384 + (ns >> 1) * 2048);
-                if (gap == 2) RC_DS_READ(A[nb][0], (ns & 1) ? f.r1 : f.r0, (ns >> 1) * 1024);
+                if (gap == 2 && HAS_P1) RC_DS_READ(A[nb][0], (ns & 1) ? f.r1 : f.r0, (ns >> 1) * 1024);
                 if (gap == 3) RC_DS_READ(A[nb][2], (ns & 1) ? f.k1 : f.k0, RC_SLOT + (ns >> 1) * 2048);
             }
             if (s < 8 && (gap == 1 || gap == 3)) rc_dma_piece(L, wr, (s >> 2) ? n1 : n0, nxt + (s >> 2) * RC_SLOT, s, gap >> 1);
@@ -622,6 +639,8 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     char *bounce = smem + RC_OFF_BOUNCE + L.w * RC_BOUNCE;
+    const int ldc_bytes = (int)(a.ldc * 4);
+    const int voff = (32 * L.w + (L.lane >> 3)) * ldc_bytes + (L.lane & 7) * 16;
 
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.W, 0, 2 * RC_W_PLANE, 0x00020000);
     auto src_p = [&](int g) { RcSlotSrc r = {RC_W_PROJ + g * 16384, 1024}; return r; };             // proj rows [32 g, +32): 16 consecutive KiB
@@ -633,6 +652,9 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
     if (DBG) t_prev = __builtin_amdgcn_s_memtime();
     auto stamp = [&](unsigned long long &acc_t) { if (DBG) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_t += t - t_prev; t_prev = t; } };
 
+    // (Measured and dropped: starting the workgroups an eighth of a tile time apart, so that the 256 epilogues - 128 KB of row stores per
+    // CU, 20 k cycles per tile - do not hit HBM together: 2.366 against 2.376 ms per 590 848 rows, epilogue 20.9 k against 20.8 k cycles: the
+    // epilogue is not bandwidth-bound.)
     // first step's slots (proj rows 0 .. 63) and the first tile's attention rows (B fragments: k = 16 s + 8 h + i, natural order)
     {
         const RcSlotSrc s0 = src_p(0), s1 = src_p(1);
@@ -807,7 +829,7 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) o[q][u] = Y[b][4 * q + u];
-            rc_store_block(L, bounce, o, rs, a.ldc * 4, 32 * L.w, 32 * b);
+            rc_store_block(L, bounce, o, rs, ldc_bytes, voff, 32 * b);
         }
         stamp(t_epi);
         ++n_tiles;
