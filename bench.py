@@ -83,12 +83,23 @@ def measure_dominant_kernel(enc, xyz_dev):
     the C ABI launches them): the dominant kernel (gemm_split_kernel, all tile / epilogue variants) and, for the secondary
     roofline entries, the window attention and the feature-space kNN searches.  ALGORITHMIC flops only."""
     from scp_amd import native
-    recs = {"gemm": [], "attn": [], "knn": [], "mlp": []}
+    recs = {"gemm": [], "attn": [], "knn": [], "mlp": [], "post": [], "lnlin": []}
 
     def ev():
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     o_lin, o_att, o_knn, o_mlp = native.linear_split, native.swin_attention_packed, native.knn_topk_packed, native.mlp_split_fused
+    o_post, o_lnlin = native.swin_post_attn, native.swin_ln_linear
+
+    def post(o, x, pw, *args, **kw):
+        s, e = ev(); s.record(); y = o_post(o, x, pw, *args, **kw); e.record()
+        recs["post"].append((s, e, 2.0 * x.shape[0] * (256 * 256 + 2 * 256 * 1024)))     # proj + fc1 + fc2
+        return y
+
+    def lnlin(x, fw, *args, **kw):
+        s, e = ev(); s.record(); y = o_lnlin(x, fw, *args, **kw); e.record()
+        recs["lnlin"].append((s, e, 2.0 * x.shape[0] * fw.N * 256))
+        return y
 
     def lin(a, sw, *args, **kw):
         s, e = ev(); s.record(); y = o_lin(a, sw, *args, **kw); e.record()
@@ -112,18 +123,24 @@ def measure_dominant_kernel(enc, xyz_dev):
         return y
 
     native.linear_split, native.swin_attention_packed, native.knn_topk_packed, native.mlp_split_fused = lin, att, knn, mlp
+    native.swin_post_attn, native.swin_ln_linear = post, lnlin
     try:
         enc.encode(xyz_dev)
         torch.cuda.synchronize()
     finally:
         native.linear_split, native.swin_attention_packed, native.knn_topk_packed, native.mlp_split_fused = o_lin, o_att, o_knn, o_mlp
+        native.swin_post_attn, native.swin_ln_linear = o_post, o_lnlin
 
     def summ(rs):
         ms = sum(r[0].elapsed_time(r[1]) for r in rs)
         fl = sum(r[2] for r in rs)
         return dict(launches=len(rs), avg_launch_us=1e3 * ms / max(1, len(rs)), flops_per_launch=fl / max(1, len(rs)),
                     tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, total_ms=ms)
-    out = summ(recs["gemm"])
+    # dominant kernel: the post-attention row-chain kernel when the Swin blocks run on it (default), else the split GEMM of rounds 1 - 2
+    out = summ(recs["post"]) if recs["post"] else summ(recs["gemm"])
+    out["dominant"] = "post" if recs["post"] else "gemm"
+    out["gemm"] = summ(recs["gemm"])
+    out["lnlin"] = summ(recs["lnlin"])
     out["attn"] = summ(recs["attn"])
     out["mlp"] = summ(recs["mlp"])
     out["knn_feat"] = summ([r for r in recs["knn"] if r[3] > 4])
@@ -318,10 +335,11 @@ def main():
         if ehem:
             dom = measure_dominant_kernel(enc, frames[-1])
             st = enc.encode(frames[-1], timing=True)["times"]     # per-stage wall times with a device sync after every stage
-            for name in ("r2_pmc_traffic.json", "r1z_pmc_traffic.json"):   # HBM bytes per launch from the committed PMC passes
+            key = "rc_post_attn_kernel" if dom["dominant"] == "post" else "gemm_split_all_variants"
+            for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1z_pmc_traffic.json"):   # HBM bytes per launch from the committed PMC passes
                 try:
                     with open(os.path.join(ROOT, "profiles", name)) as f:
-                        traffic = json.load(f)["gemm_split_all_variants"]["hbm_bytes_per_launch"]
+                        traffic = json.load(f)[key]["hbm_bytes_per_launch"]
                     traffic_src = "profiles/" + name + " (separate rocprofv3 --pmc passes over the same frame; not measured by this run)"
                     break
                 except Exception:
@@ -333,7 +351,9 @@ def main():
                 metric = f"KITTI frames/sec encode (SCP-EHEM, level {cfg['level']} same-level) + bpp match vs ref"
             dtype = ("f32 (dense layers and attention as bf16x3 split on bf16 MFMA, feature kNN as f16x3 split on f16 MFMA, fp32 accumulate; "
                      "position kNN / CDF in fp32)")
-            kernel = "gemm_split_kernel (dense layers, both operands pre-split: 3x v_mfma_f32_32x32x16_bf16 per fp32-class product)"
+            kernel = ("rc_post_attn_kernel (attention projection + residual + LayerNorm + fc1 + GELU + fc2 + residual of a Swin block in one launch, "
+                      "accumulators chained through registers: 3x v_mfma_f32_32x32x16_bf16 per fp32-class product)" if dom["dominant"] == "post" else
+                      "gemm_split_kernel (dense layers, both operands pre-split: 3x v_mfma_f32_32x32x16_bf16 per fp32-class product)")
             windows = len(EncodePlan(results[-1]["level_sizes"], 8192).windows)
         else:
             dom = measure_dominant_kernel_octattn(enc, frames[-1])
@@ -368,7 +388,9 @@ def main():
         if ehem:
             # secondary kernels, same convention; the position search (3 features) is selection-bound, its MFMA share is negligible
             out["roofline_kernels"] = {
-                "mlp_fused_kernel": entry(dom["mlp"], note="fc1 + GELU + fc2 + residual of a Swin block in one launch, hidden activation in LDS"),
+                "rc_ln_linear_kernel": entry(dom["lnlin"], note="LayerNorm + q|k|v projection in one launch, rows resident as MFMA B fragments"),
+                "gemm_split_kernel": entry(dom["gemm"], note="the remaining dense layers (geometry MLPs, patch merges, concat layers, probability heads)"),
+                "mlp_fused_kernel": entry(dom["mlp"], note="fc1 + GELU + fc2 + residual of a Swin block in one launch, hidden activation in LDS (SCP_SWIN=split only)"),
                 "swin_attn_bf16x3_kernel": entry(dom["attn"]),
                 "knn_f16x3_wg256_kernel": entry(dom["knn_feat"], note="fused distance + top-20 selection, 256-query workgroups on the XCD-affine schedule; every phase of a wave is latency-bound (DESIGN.md 4.5), L2-miss traffic 2.0 GB per launch"),
                 "knn_mfma_kernel<2,16> (positions)": {"bound": "valu", "launches_per_frame": dom["knn_pos"]["launches"],

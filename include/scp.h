@@ -36,6 +36,26 @@ SCP_API int scp_device_count(void);
 SCP_API int scp_device_name(char *buf, int cap);
 
 /* ------------------------------------------------------------------------------------------------
+ * Numeric profile - a property of an encoder / decoder HANDLE, not of the process.
+ * Two kernels offer a choice of arithmetic: the 144- / 192-feature kNN searches (dgcnn.py:10-45) run either "f16x3" (rows
+ * scaled by a power of two, two f16 terms, three f16 MFMA products, fp32 accumulate: distances within ~1e-6 relative of the
+ * fp32 chain; default) or the exact k-ordered fp32 MFMA chain (bit-identical distance values to PyTorch-CPU; the 3-feature
+ * position search always is), and the two products inside window attention (swin_transformer.py:443-501) run either as bf16x3
+ * splits on bf16 MFMA (default) or on plain fp32 MFMA.  The choice decides the last bits of the logits, i.e. the integer CDFs a
+ * decoder must reproduce: an encoder and the decoder of its streams must use one profile (the stream's side-info file names it).
+ * A context holds the choice; the calls of a host thread follow that thread's current context (NULL = the process default:
+ * f16x3 / bf16x3 unless SCP_KNN=f32 / SCP_ATTN=f32 are set when the library is loaded).  Contexts of different threads, or
+ * different contexts made current one after the other, never influence each other.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct scp_ctx scp_ctx;
+enum { SCP_CTX_KNN_F16X3 = 1, SCP_CTX_ATTENTION_BF16X3 = 2 };
+SCP_API int scp_ctx_create(scp_ctx **out);                          /* both keys 1 */
+SCP_API int scp_ctx_destroy(scp_ctx *c);
+SCP_API int scp_ctx_set(scp_ctx *c, int32_t key, int32_t value);    /* value 0 / 1 */
+SCP_API int scp_ctx_get(const scp_ctx *c, int32_t key);             /* 0 / 1, or SCP_EINVAL */
+SCP_API int scp_ctx_make_current(const scp_ctx *c);                 /* for the calling thread; NULL = process default */
+
+/* ------------------------------------------------------------------------------------------------
  * Stage G1 - coordinate transform + quantiser
  * replaces: data_preproc/data_preprocess.py:40-68 (proc_pc) / :107-137 (mul_proc_pc),
  *           cart2spher :200-207, cart2cylin :171-177
@@ -143,20 +163,6 @@ SCP_API int scp_knn_topk(const float *x, int32_t B, int32_t n, int32_t C, int32_
 /* packed ("varlen") form for many windows in one launch: x [total_rows][C], every sequence padded to a multiple of 512 rows;
  * ctab[2c] = first row of the sequence owning 512-row chunk c, ctab[2c+1] = its real length; idx [total_rows][20] holds GLOBAL rows */
 SCP_API int scp_knn_topk_packed(const float *x, const int32_t *ctab, int32_t total_rows, int32_t C, int32_t *idx, void *stream);
-/* numerics of the 144- / 192-feature searches: 1 (default) = "f16x3" (rows scaled by a power of two, two f16 terms, three
- * f16 MFMA products, fp32 accumulate: distance values within ~1e-6 relative of the fp32 chain), 0 = exact fp32 MFMA chain
- * (bit-identical distance values to PyTorch-CPU).  The 3-feature position search is always exact. */
-SCP_API int scp_set_knn_mode(int32_t f16x3);
-/* workgroup shape of the packed f16x3 search (identical neighbour lists, a performance bracket for microbenchmarks): 256 (default)
- * = 256-query workgroups on the XCD-affine schedule, one barrier per group of 3 / 4 candidate tiles; 257 / 258 = groups of 2 / 1;
- * +16 = outward sweep order; 128 = 128-query workgroups in launch order, one barrier per tile. */
-SCP_API int scp_set_knn_workgroup(int32_t shape);
-/* diagnostic: with a device buffer of (blocks * 8 * 4) u64 set, the K = 192 search of shape 256 runs its cycle-stamped build and
- * writes per wave [cycles at barrier + DMA issue, in the MFMA block, in the selection, tiles]; NULL (default) = the product kernel */
-SCP_API int scp_knn_debug_buffer(unsigned long long *dev_buf);
-/* the same for scp_mlp_split_fused: (workgroups * 8 * 8) u64, per wave [cycles at barriers, phase-1 products, GELU + split, phase-2
- * products, epilogue, row tiles, -, -] */
-SCP_API int scp_mlp_debug_buffer(unsigned long long *dev_buf);
 /* scp_knn_topk_packed with an a-priori pruning bound per row: thr0[row] = a value of (2 x.y - |x|^2 - |y|^2) that at least 20
  * candidates of the row's sequence are known to reach (e.g. the 20th best over last layer's neighbours); same result, fewer
  * list insertions.  thr0 may be NULL. */
@@ -254,8 +260,6 @@ SCP_API int scp_swin_attention_packed_split(const float *q, const float *k, cons
                                     int32_t total_windows, int32_t shift, int32_t ldq, int32_t ldkv, void *ohi, void *olo, int64_t ldo,
                                     void *stream);
 
-/* numerics of the two products inside scp_swin_attention*: 1 (default) = bf16x3 split on bf16 MFMA, 0 = plain fp32 MFMA */
-SCP_API int scp_set_attention_mode(int32_t bf16x3);
 
 /* packed form: total_windows windows of 512 rows; wtab[2w] = first row of the sequence owning window w, wtab[2w+1] = its padded length */
 SCP_API int scp_swin_attention_packed(const float *q, const float *k, const float *v, const float *bias_table, const int32_t *wtab,
@@ -361,6 +365,31 @@ SCP_API int scp_embed_gather(const uint8_t *ctx, const float *pos, const int64_t
  * tables_dev: int64 scratch of 36 * W entries. */
 SCP_API int scp_packed_plan_sizes(const int64_t *lengths, int32_t W, int64_t *rows_out);
 SCP_API int scp_packed_plan(const int64_t *lengths, int32_t W, int64_t *tables_dev, void *const *outs, int32_t n_outs, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Swin blocks on the row-chain kernels (csrc/rowchain.hip): a workgroup keeps 128 token rows in registers as the B operand of
+ * every product, weights stream through LDS, and the accumulator of one product is the B fragment of the next.
+ * replaces: models/swin_transformer.py:654-706 (SwinLayer.forward) around the attention kernel -
+ *   scp_swin_ln_linear : layernorm_before + query|key|value (:443-501,654-660), or layernorm(query) + query of a cross layer:
+ *                        out[m] = valid[m] * n(x[m]) . W'^T + bias + valid[m] * wbeta, n = the row normalised WITHOUT affine;
+ *                        the caller folds the LayerNorm affine into the weight: W' = W diag(gamma), wbeta = W beta.  valid (may be
+ *                        NULL) zeroes the rows a window pads AFTER LayerNorm (:638-641): they come out as the bias alone.
+ *                        x fp32 [M][ldx] (256 channels); W' as scp_split_weight_bf16 + scp_tile_weight_bf16 planes [Npad][256];
+ *                        N % 128 == 0, N <= 1024; out fp32 [M][ldo].
+ *   scp_swin_post_attn : attention.output.dense + residual, layernorm_after, intermediate.dense + GELU, output.dense + residual
+ *                        (:503-571,662-706) in ONE launch: x2 = x1 + fc2(GELU(fc1(LN(x1)))), x1 = x + proj(o).  o: the attention
+ *                        output as bf16 hi/lo planes [M][ldo_in]; x fp32 [M][ldx]; out fp32 [M][ldc] (may be x).  W: ONE buffer of
+ *                        scp_swin_post_attn_weight_bytes() bytes = tiled planes proj hi | fc1 hi | fc2 hi | proj lo | fc1 lo | fc2 lo,
+ *                        proj [256][256], fc1 = (W1 diag(gamma))[:, P] [1024][256], fc2 = W2[:, P] [256][1024], P = inside every
+ *                        16 columns, columns 4-7 and 8-11 change places (the order in which an MFMA accumulator holds a row's
+ *                        channels); b1 = fc1 bias + W1 beta.
+ * Results are per row: independent of M, of the row's position and of what else is in the launch.
+ * ---------------------------------------------------------------------------------------------- */
+SCP_API int scp_swin_ln_linear(const float *x, int64_t ldx, const float *valid, const void *Whi, const void *Wlo, const float *bias,
+                               const float *wbeta, float eps, float *out, int64_t ldo, int32_t M, int32_t N, void *stream);
+SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int64_t ldo_in, const float *x, int64_t ldx, const void *W, const float *bp,
+                               const float *b1, const float *b2, float eps, float *out, int64_t ldc, int32_t M, void *stream);
+SCP_API int64_t scp_swin_post_attn_weight_bytes(void);
 
 #ifdef __cplusplus
 }

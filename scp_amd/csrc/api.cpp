@@ -1,5 +1,6 @@
 // Library-level entry points of libscp_hip.so.
 #include <string.h>
+#include <new>
 #include "scp_internal.h"
 
 int g_scp_last_hip_error = 0;
@@ -21,3 +22,41 @@ extern "C" int scp_device_name(char *buf, int cap) {
     buf[cap - 1] = 0;
     return SCP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Numeric profile of one encoder / decoder: which arithmetic the kernels with a choice use.  The choice decides the last bits of the
+// logits, hence the integer CDFs a decoder must reproduce, so it belongs to a handle, not to the process: every host thread has a
+// current profile (scp_ctx_make_current; NULL = the process default, which SCP_KNN / SCP_ATTN select at load).
+struct scp_ctx { int knn_f16x3; int attn_bf16x3; };
+static thread_local const scp_ctx *t_ctx = nullptr;
+
+extern "C" int scp_ctx_create(scp_ctx **out) {
+    if (!out) return SCP_EINVAL;
+    scp_ctx *c = new (std::nothrow) scp_ctx;
+    if (!c) return SCP_ENOMEM;
+    c->knn_f16x3 = 1; c->attn_bf16x3 = 1;
+    *out = c;
+    return SCP_OK;
+}
+extern "C" int scp_ctx_destroy(scp_ctx *c) {
+    if (!c) return SCP_EINVAL;
+    if (t_ctx == c) t_ctx = nullptr;
+    delete c;
+    return SCP_OK;
+}
+extern "C" int scp_ctx_set(scp_ctx *c, int32_t key, int32_t value) {
+    if (!c || (value != 0 && value != 1)) return SCP_EINVAL;
+    if (key == SCP_CTX_KNN_F16X3) c->knn_f16x3 = value;
+    else if (key == SCP_CTX_ATTENTION_BF16X3) c->attn_bf16x3 = value;
+    else return SCP_EINVAL;
+    return SCP_OK;
+}
+extern "C" int scp_ctx_get(const scp_ctx *c, int32_t key) {
+    if (!c) return SCP_EINVAL;
+    if (key == SCP_CTX_KNN_F16X3) return c->knn_f16x3;
+    if (key == SCP_CTX_ATTENTION_BF16X3) return c->attn_bf16x3;
+    return SCP_EINVAL;
+}
+extern "C" int scp_ctx_make_current(const scp_ctx *c) { t_ctx = c; return SCP_OK; }
+int scp_ctx_knn_mode() { return t_ctx ? t_ctx->knn_f16x3 : -1; }
+int scp_ctx_attention_mode() { return t_ctx ? t_ctx->attn_bf16x3 : -1; }

@@ -389,6 +389,8 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bf16x3_kernel(const float *_
 
 static int g_attn_mode = -1;   // 0 = fp32 MFMA, 1 = bf16x3 (default); SCP_ATTN=f32 selects the former
 static inline bool attn_bf16x3() {
+    const int c = scp_ctx_attention_mode();      // the calling thread's current scp_ctx decides; without one, the process default
+    if (c >= 0) return c == 1;
     if (g_attn_mode < 0) { const char *e = getenv("SCP_ATTN"); g_attn_mode = (e && e[0] == 'f') ? 0 : 1; }
     return g_attn_mode == 1;
 }

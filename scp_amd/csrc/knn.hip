@@ -1019,6 +1019,8 @@ static DevBuf *knn_scratch(hipStream_t st) {
 
 static int g_knn_mode = -1;
 static int knn_mode() {   // 1 = f16x3 (default), 0 = exact fp32 MFMA (SCP_KNN=f32 or scp_set_knn_mode(0))
+    const int c = scp_ctx_knn_mode();            // the calling thread's current scp_ctx decides; without one, the process default
+    if (c >= 0) return c;
     if (g_knn_mode < 0) { const char *e = getenv("SCP_KNN"); g_knn_mode = (e && e[0] == 'f') ? 0 : 1; }
     return g_knn_mode;
 }

@@ -22,6 +22,10 @@ extern int g_scp_last_hip_error;
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// numeric profile of the calling thread's current scp_ctx (api.cpp): 0 / 1, or -1 = no context current (process default)
+int scp_ctx_knn_mode();
+int scp_ctx_attention_mode();
+
 // LDS-DMA (global_load_lds_*) completes on the VM counter.  hipcc usually drains it in front of a __syncthreads(), but whether it
 // does depends on the surrounding code (observed: adding an unrelated, never-executed DMA to a loop removed the wait) - so every
 // barrier that publishes DMA data is preceded by an explicit wait.  N = DMA instructions of THIS wave that may stay in flight.

@@ -42,7 +42,7 @@ def write_sidecar(outfile, enc, res, model_name):
     side = dict(model=model_name, type=enc.data_type, lidar_level=int(enc.lidar_level), mullevel=bool(enc.mullevel),
                 spher=bool(enc.spher), cylin=bool(enc.cylin), n_points=int(res["n_points"]), n_nodes=int(res["n_nodes"]),
                 bin_nums=[float(b) for b in res.get("bin_nums", [res["bin_num"]])],
-                z_offset=float(res["z_offset"]), profile=native.numeric_profile(model_name))
+                z_offset=float(res["z_offset"]), profile=native.numeric_profile(model_name, getattr(enc, "profile", None)))
     with open(outfile + SIDECAR, "w") as f:
         json.dump(side, f)
     return side
@@ -75,7 +75,7 @@ def dequantise_leaves(leaves, qs, bin_num, z_offset, spher, cylin, data_type=KIT
     return metrics.dequantize(leaves, q, off, spher=spher, cylin=cylin)
 
 
-def decode_file(binfile, model, lidar_level=None, data_type=None, mullevel=False, device=None):
+def decode_file(binfile, model, lidar_level=None, data_type=None, mullevel=False, device=None, profile=None):
     """A stream file written by the encode CLIs -> dict(codes per shell, leaves per shell, points [U,3] float64 Cartesian).
     Side information exactly as the reference's decoders take it (`extract_info`); the `.scp.json` written next to the stream
     supplies what that cannot carry.  Without it the reference's own rules apply: lidar level = the level count (decode_ehem.py:218),
@@ -83,7 +83,7 @@ def decode_file(binfile, model, lidar_level=None, data_type=None, mullevel=False
     spher, cylin, pos_mm, n_levels, bin_num, z_offset = extract_info(binfile)
     side = read_sidecar(binfile)
     if side is not None:
-        prof = native.numeric_profile(side.get("model", "EHEM"))
+        prof = native.numeric_profile(side.get("model", "EHEM"), profile)
         if side["profile"] != prof:
             raise native.ScpError(f"{binfile}: coded under numeric profile {side['profile']!r}, this process runs {prof!r}: the "
                                   "integer CDFs would differ and the range decoder would desynchronise")
@@ -98,7 +98,7 @@ def decode_file(binfile, model, lidar_level=None, data_type=None, mullevel=False
         bins = side["bin_nums"]
     else:
         bins = [bin_num] + [round((bin_num - 1) * qs[0] / q) + 1 for q in qs[1:]]
-    dec = FrameDecoder(model, lidar_level, mullevel=mullevel, polar=spher or cylin, device=device)
+    dec = FrameDecoder(model, lidar_level, mullevel=mullevel, polar=spher or cylin, device=device, profile=profile)
     with open(binfile, "rb") as f:
         stream = f.read()
     shells = dec.decode(stream, n_levels, pos_mm)
@@ -108,8 +108,9 @@ def decode_file(binfile, model, lidar_level=None, data_type=None, mullevel=False
 
 
 class FrameDecoder:
-    def __init__(self, model, lidar_level=12, mullevel=False, polar=True, device=None):
+    def __init__(self, model, lidar_level=12, mullevel=False, polar=True, device=None, profile=None):
         self.model = model
+        self.profile = profile        # native.NumericProfile: must be the one the stream was coded under (None: process default)
         self.lidar_level = lidar_level
         self.mullevel = mullevel
         self.polar = polar            # spherical / cylindrical: positions normalised with the .dat (min, max) pairs
@@ -224,7 +225,8 @@ class FrameDecoder:
         else:
             depths = [n_levels]
         out, off = [], 0
-        for d in depths:
-            out.append(self._decode_tree(dec, d, pos_mm[off:off + d] if self.polar else None))
-            off += d
+        with native.use_profile(self.profile):
+            for d in depths:
+                out.append(self._decode_tree(dec, d, pos_mm[off:off + d] if self.polar else None))
+                off += d
         return out

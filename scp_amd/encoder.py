@@ -77,8 +77,9 @@ class EncodePlan:
 
 class FrameEncoder:
     def __init__(self, model, data_type=KITTI, lidar_level=12, spher=True, cylin=False, mullevel=False, max_batch=8,
-                 device=None, packed=True, max_tokens=1_000_000, host_transform=None):
+                 device=None, packed=True, max_tokens=1_000_000, host_transform=None, profile=None):
         self.model = model
+        self.profile = profile          # native.NumericProfile of THIS encoder (None: the process default); current around every launch
         # strict-identity switch (CLI --host_transform, SCP_XFORM=numpy): the float -> integer step of the reference on the host
         # (numpy float32 arctan2 / arccos, data_preprocess.py:42-70) instead of the device transform, whose float64 atan2 / acos is
         # more accurate and therefore gives other integers for a few points per frame.  Everything after the
@@ -203,6 +204,13 @@ class FrameEncoder:
 
     # ------------------------------------------------------------------------------------------ stage M + C
     def logits_in_coding_order(self, pre, plan):
+        with native.use_profile(self.profile):
+            return self._logits_in_coding_order(pre, plan)
+
+    def profile_string(self):
+        return native.numeric_profile("EHEM", self.profile)
+
+    def _logits_in_coding_order(self, pre, plan):
         if self.packed:
             return self.logits_packed(pre, plan)
         N = plan.n_rows

@@ -72,6 +72,12 @@ def lib():
         "scp_swin_attention_packed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp]),
         "scp_swin_attention_packed_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, i64, _vp]),
         "scp_set_attention_mode": (C.c_int, [i32]),
+        "scp_ctx_create": (C.c_int, [C.POINTER(_vp)]),
+        "scp_ctx_destroy": (C.c_int, [_vp]),
+        "scp_ctx_set": (C.c_int, [_vp, i32, i32]),
+        "scp_ctx_get": (C.c_int, [_vp, i32]),
+        "scp_ctx_make_current": (C.c_int, [_vp]),
+        "scp_rc_debug_buffer": (C.c_int, [_vp]),
         "scp_set_knn_mode": (C.c_int, [i32]),
         "scp_row_scale_f16": (C.c_int, [_vp, i64, i32, i32, _vp, _vp, _vp]),
         "scp_linear_f16x3_scaled": (C.c_int, [_vp, i64, _vp, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp, _vp, _vp]),
@@ -376,7 +382,8 @@ _MODES = {"knn": "f32" if os.environ.get("SCP_KNN", "")[:1] == "f" else "f16x3",
 
 
 def set_knn_mode(f16x3):
-    """True (default): f16x3 distances for the 144-/192-feature searches; False: exact fp32 MFMA chain."""
+    """PROCESS default (test hook, include/scp_debug.h; an encoder uses a NumericProfile): True = f16x3 distances for the 144-/192-feature
+    searches, False = exact fp32 MFMA chain."""
     _check(lib().scp_set_knn_mode(1 if f16x3 else 0), "scp_set_knn_mode")
     _MODES["knn"] = "f16x3" if f16x3 else "f32"
 
@@ -387,15 +394,70 @@ def set_knn_workgroup(shape):
     _check(lib().scp_set_knn_workgroup(int(shape)), "scp_set_knn_workgroup")
 
 
-def numeric_profile(model_name):
-    """The arithmetic variants that decide the logits' last bits - hence the integer CDFs a decoder must reproduce.  The encoder
-    writes this string into its side-info file and the decoder refuses a stream coded under another profile (the alternates are
-    test / benchmark brackets: SCP_GEMM, SCP_KNN, SCP_ATTN, SCP_CONCAT, SCP_OCTATTN; SCP_MLP=split is bit-identical)."""
+class NumericProfile:
+    """The numeric profile of ONE encoder / decoder (an scp_ctx of include/scp.h): which arithmetic the kernels with a choice use -
+    feature kNN searches f16x3 (default) or the exact fp32 chain, window attention bf16x3 (default) or fp32 MFMA.  It belongs to the
+    handle, not to the process: FrameEncoder / FrameDecoder make theirs current (for the calling thread) around their launches, so two
+    encoders with different profiles in one process, or in different threads, each get their own arithmetic and their own streams."""
+
+    def __init__(self, knn_f16x3=True, attention_bf16x3=True):
+        self._h = _vp()
+        _check(lib().scp_ctx_create(C.byref(self._h)), "scp_ctx_create")
+        self.knn_f16x3, self.attention_bf16x3 = bool(knn_f16x3), bool(attention_bf16x3)
+        _check(lib().scp_ctx_set(self._h, 1, int(self.knn_f16x3)), "scp_ctx_set")
+        _check(lib().scp_ctx_set(self._h, 2, int(self.attention_bf16x3)), "scp_ctx_set")
+
+    def describe(self, model_name):
+        return numeric_profile(model_name, self)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().scp_ctx_destroy(self._h)
+        except Exception:
+            pass
+
+
+_TLS = __import__("threading").local()
+
+
+def current_profile():
+    """The NumericProfile current for this thread (None = the process default)."""
+    return getattr(_TLS, "profile", None)
+
+
+class use_profile:
+    """`with native.use_profile(p):` - p (a NumericProfile or None) is the calling thread's current profile inside the block."""
+
+    def __init__(self, profile):
+        self.profile = profile
+
+    def __enter__(self):
+        self.prev = current_profile()
+        _TLS.profile = self.profile
+        _check(lib().scp_ctx_make_current(self.profile._h if self.profile is not None else None), "scp_ctx_make_current")
+        return self.profile
+
+    def __exit__(self, *exc):
+        _TLS.profile = self.prev
+        lib().scp_ctx_make_current(self.prev._h if self.prev is not None else None)
+        return False
+
+
+def numeric_profile(model_name, profile="current"):
+    """The arithmetic variants that decide the logits' last bits - hence the integer CDFs a decoder must reproduce - as a string.  The
+    encoder writes it into its side-info file and the decoder refuses a stream coded under another profile.  `profile`: a
+    NumericProfile, None (process default) or "current" (this thread's).  (The other alternates are process-wide test / benchmark
+    brackets read once at import: SCP_GEMM, SCP_CONCAT, SCP_SWIN, SCP_OCTATTN; SCP_MLP=split is bit-identical.)"""
     from . import ops
     from .models import packed
     if model_name == "OctAttention":
         return f"octattn/1:gemm={ops.MODE},attn={OCTATTN_MODE}"
-    return (f"ehem/2:gemm={ops.MODE},knn={_MODES['knn']},attn={_MODES['attn']},concat={'hier' if packed.HIER else 'direct'},"
+    if profile == "current":
+        profile = current_profile()
+    knn = _MODES["knn"] if profile is None else ("f16x3" if profile.knn_f16x3 else "f32")
+    attn = _MODES["attn"] if profile is None else ("bf16x3" if profile.attention_bf16x3 else "f32")
+    return (f"ehem/2:gemm={ops.MODE},knn={knn},attn={attn},concat={'hier' if packed.HIER else 'direct'},"
             f"swin={'rowchain' if packed.ROWCHAIN else 'split'}")
 
 
@@ -415,7 +477,8 @@ def edge_gather_max(u, v, idx, scale, shift, out=None):
 
 
 def set_attention_mode(bf16x3=True):
-    """True (default): QK^T / PV as bf16x3 splits on bf16 MFMA; False: plain fp32 MFMA."""
+    """PROCESS default (test hook, include/scp_debug.h; an encoder uses a NumericProfile): True = QK^T / PV as bf16x3 splits on bf16 MFMA,
+    False = plain fp32 MFMA."""
     _check(lib().scp_set_attention_mode(1 if bf16x3 else 0), "scp_set_attention_mode")
     _MODES["attn"] = "bf16x3" if bf16x3 else "f32"
 

@@ -8,19 +8,26 @@ import numpy as np
 from conftest import ROOT, golden
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "scp.h")).read()
+def declared_symbols(header="scp.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     return re.findall(r"SCP_API\s+[A-Za-z_0-9 \*]+?\b([A-Za-z_0-9]+)\s*\(", src)
 
 
 def test_library_exports_every_declared_symbol():
+    """Both headers: the drop-in boundary (scp.h) and the test / measurement hooks (scp_debug.h); the hooks and the process-global
+    setters are NOT in the public header."""
     import ctypes
     from scp_amd import native
     L = native.lib()
-    names = declared_symbols()
-    assert len(names) >= 30
-    missing = [n for n in names if not hasattr(L, n)]
+    names, dbg = declared_symbols(), declared_symbols("scp_debug.h")
+    assert len(names) >= 30 and len(dbg) >= 6
+    missing = [n for n in names + dbg if not hasattr(L, n)]
     assert not missing, missing
+    assert not (set(names) & set(dbg))
+    for n in ("scp_set_knn_mode", "scp_set_attention_mode", "scp_set_knn_workgroup", "scp_knn_debug_buffer", "scp_mlp_debug_buffer", "scp_rc_debug_buffer"):
+        assert n in dbg and n not in names
+    for n in ("scp_ctx_create", "scp_ctx_set", "scp_ctx_make_current", "scp_swin_ln_linear", "scp_swin_post_attn", "scp_swin_post_attn_weight_bytes"):
+        assert n in names
     assert L.scp_version() >= 100
     assert isinstance(L, ctypes.CDLL)
 
@@ -114,3 +121,50 @@ def test_model_kernel_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 2, 2048, 4, 150, one, one, 4096, need, z) == -1
     assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 2, 1024, 4, 150, one, one, 4096, need - 1, z) == -1
     assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 2, 1024, 4, 150, one, one, 4097, need, z) == -1
+
+
+def test_numeric_profile_contexts_are_per_handle_and_per_thread():
+    """scp_ctx: the numeric profile belongs to a handle; the current context is per host thread; bad keys / values are refused.  (No
+    GPU call: only the host-side state.)"""
+    import ctypes as C
+    import threading
+    from scp_amd import native
+    L = native.lib()
+    a, b = C.c_void_p(), C.c_void_p()
+    assert L.scp_ctx_create(C.byref(a)) == 0 and L.scp_ctx_create(C.byref(b)) == 0
+    assert L.scp_ctx_get(a, 1) == 1 and L.scp_ctx_get(a, 2) == 1
+    assert L.scp_ctx_set(a, 1, 0) == 0 and L.scp_ctx_get(a, 1) == 0 and L.scp_ctx_get(b, 1) == 1       # b untouched
+    assert L.scp_ctx_set(a, 7, 1) == -1 and L.scp_ctx_set(a, 1, 2) == -1 and L.scp_ctx_set(None, 1, 1) == -1 and L.scp_ctx_create(None) == -1
+    p1 = native.NumericProfile(knn_f16x3=False)
+    p2 = native.NumericProfile()
+    assert "knn=f32" in p1.describe("EHEM") and "knn=f16x3" in p2.describe("EHEM")
+    seen = {}
+
+    def worker():
+        seen["other thread"] = native.current_profile()
+        with native.use_profile(p2):
+            seen["other thread inside"] = native.current_profile()
+    with native.use_profile(p1):
+        assert native.current_profile() is p1
+        t = threading.Thread(target=worker); t.start(); t.join()
+        with native.use_profile(p2):
+            assert native.current_profile() is p2
+        assert native.current_profile() is p1
+    assert native.current_profile() is None and seen["other thread"] is None and seen["other thread inside"] is p2
+    assert L.scp_ctx_destroy(a) == 0 and L.scp_ctx_destroy(b) == 0 and L.scp_ctx_destroy(None) == -1
+
+
+def test_row_chain_entry_points_reject_bad_arguments_without_a_gpu():
+    from scp_amd import native
+    L = native.lib()
+    z, one = None, 4096
+    assert L.scp_swin_post_attn_weight_bytes() == 2 * (256 * 512 + 1024 * 512 + 256 * 2048)
+    assert L.scp_swin_ln_linear(z, 256, z, one, one, z, z, 1e-5, one, 768, 10, 768, z) == -1              # x NULL
+    assert L.scp_swin_ln_linear(one, 256, z, one, one, z, z, 1e-5, one, 768, 10, 700, z) == -1            # N % 128
+    assert L.scp_swin_ln_linear(one, 250, z, one, one, z, z, 1e-5, one, 768, 10, 768, z) == -1            # ldx < 256
+    assert L.scp_swin_ln_linear(one, 256, z, one, one, z, z, 1e-5, one, 512, 10, 768, z) == -1            # ldo < N
+    assert L.scp_swin_ln_linear(one, 256, z, one, one, z, z, 1e-5, one, 768, 0, 768, z) == -1             # M == 0
+    assert L.scp_swin_post_attn(one, one, 256, one, 256, z, one, one, one, 1e-5, one, 256, 10, z) == -1    # W NULL
+    assert L.scp_swin_post_attn(one, one, 250, one, 256, one, one, one, one, 1e-5, one, 256, 10, z) == -1  # ldo_in
+    assert L.scp_swin_post_attn(one, one, 256, one, 256, one, one, one, one, 1e-5, one, 254, 10, z) == -1  # ldc
+    assert L.scp_swin_post_attn(one, one, 256, one, 256, one, one, one, one, 1e-5, one, 256, -1, z) == -1  # M

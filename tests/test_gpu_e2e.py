@@ -766,3 +766,34 @@ def test_cli_decode_picks_the_stream_of_the_right_sequence(tmp_path, orc):
         find_stream(str(out) + "/", files[0])
     with pytest.raises(native.ScpError):
         find_stream(str(out) + "/", str(tmp_path / "13" / "000001.bin"))
+
+
+def test_two_encoders_with_different_numeric_profiles_in_one_process(enc_parts):
+    """The numeric profile belongs to the encoder handle (scp_ctx), not to the process: an exact-kNN encoder and a default encoder used
+    alternately in one process each produce exactly the stream they produce alone, the two differ, the side info names each one's
+    profile, and a decoder with the wrong profile refuses the stream."""
+    from scp_amd import native
+    from scp_amd.decoder import FrameDecoder
+    from scp_amd.encoder import FrameEncoder
+    from scp_amd.synth import synth_frame
+    model, dev = enc_parts
+    xyz = synth_frame(5)[::12].copy()
+    exact = native.NumericProfile(knn_f16x3=False, attention_bf16x3=False)
+    a = FrameEncoder(model, "kitti", 12, spher=True, device=dev)
+    b = FrameEncoder(model, "kitti", 12, spher=True, device=dev, profile=exact)
+    ra1, rb1, ra2, rb2 = a.encode(xyz), b.encode(xyz), a.encode(xyz), b.encode(xyz)
+    assert ra1["bytes"] == ra2["bytes"] and rb1["bytes"] == rb2["bytes"]
+    assert not torch.equal(ra1["_debug"]["table"], rb1["_debug"]["table"])                 # different arithmetic, really used
+    assert "knn=f16x3" in a.profile_string() and "knn=f32" in b.profile_string() and "attn=f32" in b.profile_string()
+    # alone, under the process-wide test hooks, the exact profile gives the same stream
+    native.set_knn_mode(False); native.set_attention_mode(False)
+    try:
+        alone = FrameEncoder(model, "kitti", 12, spher=True, device=dev).encode(xyz)
+    finally:
+        native.set_knn_mode(True); native.set_attention_mode(True)
+    assert alone["bytes"] == rb1["bytes"]
+    # a stream decodes under its own profile
+    dec = FrameDecoder(model, 12, mullevel=False, polar=True, device=dev, profile=exact)
+    shells = dec.decode(rb1["bytes"], rb1["n_levels"], rb1["pos_mm"])
+    want = b.geom.nodes(("occ",))["occ"].cpu().numpy()                     # (b encoded last: its octree is still in its workspace)
+    assert np.array_equal(torch.cat(shells[0][0]).cpu().numpy(), want)

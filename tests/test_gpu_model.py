@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from cfgs import ehem_cfg, octattn_cfg
 from conftest import GOLDEN, golden, parity_record
@@ -960,3 +961,80 @@ def test_hierarchical_concat_layers_equal_direct_form(dev, ehem):
     worst = max((a[0] - b[0]).abs().max().item(), (a[1] - b[1]).abs().max().item())
     print(f"hierarchical vs direct concat layers: max|dlogit| = {worst:.3e}")
     assert worst < 5e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------- row-chain kernels
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N", [(1, 256), (31, 768), (128, 768), (129, 512), (1000, 256), (70001, 768)])
+def test_swin_ln_linear_vs_float64(dev, M, N):
+    """scp_swin_ln_linear (csrc/rowchain.hip): LayerNorm + dense layer in one launch against float64 - LayerNorm affine folded into
+    the weight, rows the window pads after LayerNorm (valid = 0) come out as the bias alone, any row count; and the rows of a launch do
+    not depend on what else is in it (bit-identical to a launch of a prefix)."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn((M, 256), generator=g) * 1.5 + 0.3).to(dev)
+    gamma, beta = (1 + 0.1 * torch.randn(256, generator=g)).to(dev), (0.1 * torch.randn(256, generator=g)).to(dev)
+    W, b = (torch.randn((N, 256), generator=g) * 0.05).to(dev), (torch.randn(N, generator=g) * 0.1).to(dev)
+    valid = (torch.rand(M, generator=g) > 0.2).float().to(dev)
+    fw = native.LnFoldedWeight(W, gamma, beta)
+    y = native.swin_ln_linear(x, fw, b, 1e-5, valid)
+    ref = (F.layer_norm(x.double(), (256,), gamma.double(), beta.double(), 1e-5) * valid.double()[:, None]) @ W.double().T + b.double()
+    err = (y.double() - ref).abs().max().item()
+    assert err < 1e-4, err
+    if (valid == 0).any():
+        pad = (valid == 0).nonzero().flatten()[:5]
+        assert torch.equal(y[pad], b[None].expand(len(pad), N))                  # exactly the bias
+    y2 = native.swin_ln_linear(x, fw, None, 1e-5, None)
+    assert (y2.double() - F.layer_norm(x.double(), (256,), gamma.double(), beta.double(), 1e-5) @ W.double().T).abs().max().item() < 1e-4
+    k = max(1, M // 3)
+    assert torch.equal(native.swin_ln_linear(x[:k].contiguous(), fw, b, 1e-5, valid[:k].contiguous()), y[:k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 33, 128, 129, 1000, 70001])
+def test_swin_post_attn_vs_float64_and_the_launches_it_replaces(dev, M):
+    """scp_swin_post_attn: attention projection + residual + LayerNorm + fc1 + GELU + fc2 + residual in one launch, the intermediate
+    activations chained through MFMA accumulators (never in memory), against float64 and against the three launches of rounds 1 - 2
+    (scp_linear_split, scp_layernorm_rows_split, scp_mlp_split_fused); batch-invariant bit for bit; works in place."""
+    from scp_amd import native
+    from scp_amd.ops import linear_s, _split
+    g = torch.Generator().manual_seed(M)
+    rn = lambda *sh, s=1.0: (torch.randn(sh, generator=g) * s).to(dev)
+    x, o = rn(M, 256), rn(M, 256)
+    wp, bp = rn(256, 256, s=0.05), rn(256, s=0.1)
+    gamma, beta = 1 + rn(256, s=0.1), rn(256, s=0.1)
+    w1, b1, w2, b2 = rn(1024, 256, s=0.05), rn(1024, s=0.1), rn(256, 1024, s=0.03), rn(256, s=0.1)
+    osp = native.split_rows(o)
+    pw = native.PostAttnWeights(wp, bp, gamma, beta, w1, b1, w2, b2)
+    y = native.swin_post_attn(osp, x, pw)
+    x1 = x.double() + o.double() @ wp.double().T + bp.double()
+    h = F.gelu(F.layer_norm(x1, (256,), gamma.double(), beta.double(), 1e-5) @ w1.double().T + b1.double())
+    ref = x1 + h @ w2.double().T + b2.double()
+    err = (y.double() - ref).abs().max().item()
+    x1o = linear_s(osp, wp, bp, residual=x)
+    old = native.mlp_split_fused(native.layernorm_rows(x1o, gamma, beta, 1e-5, split=True), _split(w1), b1, _split(w2), b2, residual=x1o)
+    err_old = (old.double() - ref).abs().max().item()
+    print(f"M={M}: max err vs float64 {err:.2e} (the three launches: {err_old:.2e})")
+    assert err < 1e-4 and err < 3 * err_old + 1e-5
+    k = max(1, M // 2)
+    assert torch.equal(native.swin_post_attn(native.split_rows(o[:k].contiguous()), x[:k].contiguous(), pw), y[:k])
+    xc = x.clone()
+    assert native.swin_post_attn(osp, xc, pw, out=xc) is xc and torch.equal(xc, y)      # in place: a tile reads its rows before it writes them
+
+
+@pytest.mark.gpu
+def test_rowchain_weights_follow_parameter_updates(dev, ehem):
+    """The folded / permuted weights of the row-chain kernels are caches keyed on their sources: an in-place parameter update after a
+    forward takes effect (the same contract as every other derived weight)."""
+    from scp_amd.models.packed import _rowchain_weights
+    layer = ehem.swin_self_transformer.layers[0].blocks[0]
+    w0 = _rowchain_weights(layer, False)
+    assert _rowchain_weights(layer, False) is w0
+    with torch.no_grad():
+        layer.layernorm_after.weight.mul_(1.5)
+    try:
+        w1 = _rowchain_weights(layer, False)
+        assert w1 is not w0 and not torch.equal(w1["post"].packed, w0["post"].packed)
+    finally:
+        with torch.no_grad():
+            layer.layernorm_after.weight.div_(1.5)

@@ -24,9 +24,16 @@ for k in tot["FETCH_SIZE"]:
 g = [v for k, v in out["per_kernel"].items() if "gemm_split_kernel" in k]
 out["gemm_split_all_variants"] = {"launches": sum(v["launches"] for v in g),
                                   "hbm_bytes_per_launch": sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in g) / max(1, sum(v["launches"] for v in g))}
+for name in ("rc_post_attn_kernel", "rc_ln_linear_kernel"):
+    g2 = [v for k, v in out["per_kernel"].items() if name in k]
+    if g2:
+        out[name] = {"launches": sum(v["launches"] for v in g2),
+                     "hbm_bytes_per_launch": sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in g2) / max(1, sum(v["launches"] for v in g2))}
+frames = 2
+out["frame_hbm_bytes"] = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in out["per_kernel"].values()) / frames
 big = dict(sorted(out["per_kernel"].items(), key=lambda kv: -(kv[1]["fetch_bytes_corrected"] + kv[1]["write_bytes"]))[:14])
 out["per_kernel"] = big
 json.dump(out, open(f"/root/repo/profiles/{tag}_pmc_traffic.json", "w"), indent=1)
-print(json.dumps(out["gemm_split_all_variants"]))
+print(json.dumps(out["gemm_split_all_variants"]), "frame HBM traffic %.1f GB" % (out["frame_hbm_bytes"] / 1e9))
 for k, v in big.items():
     print(f"{k[:60]:60s} {v['launches']:5d} {v['hbm_bytes_per_launch']/1e6:10.1f} MB/launch")
