@@ -496,13 +496,15 @@ def test_ehem_logits_vs_reference_packed_path(dev, ehem, name):
         models_ref.KNN_OVERRIDE = None
     d = max(np.abs(o1 - r1.numpy()).max(), np.abs(o2 - r2.numpy()).max() if o2.size else 0.0)
     parity_record(f"{name}/packed", max_dlogit_vs_reference=e.max(), rows_within_1e3_vs_reference=rows_ok, max_dlogit_vs_oracle_same_knn=d)
-    assert rows_ok >= ROWS_OK_MIN.get(name, 0.97), (e.max(), rows_ok)
+    # (the fraction is a recorded number, not a criterion: test_every_out_of_tolerance_lattice_row_is_explained_by_a_knn_tie and
+    # test_given_the_reference_neighbour_choice_every_lattice_row_matches are the proof)
     assert d <= LOGIT_TOL, d
 
 
 # measured fractions of rows within 1e-3 of the reference's golden logits (lattice positions: exact distance ties at the 20th /
 # 21st neighbour are resolved by the reference's top-k implementation) minus a small margin; profiles/parity_r2.json has the values
-ROWS_OK_MIN = {"logits_ehem_b2_c256": 0.985, "logits_ehem_c1024": 0.994, "logits_ehem_c600": 0.99, "logits_ehem_c1": 1.0, "logits_ehem_c7": 1.0,
+ROWS_OK_MIN = {"logits_ehem_b2_c256": 0.985,   # (no longer asserted: kept as the record of what round 2 measured)
+                "logits_ehem_c1024": 0.994, "logits_ehem_c600": 0.99, "logits_ehem_c1": 1.0, "logits_ehem_c7": 1.0,
                "logits_ehem_c8192": 1.0, "logits_ehem_lvl1_c6": 1.0}      # measured: 0.9902 / 0.9971 / 0.9933 / 1 / 1 / 1 / 1
 
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_ehem_*.npz"))))
@@ -530,10 +532,9 @@ def test_ehem_logits_vs_reference(dev, ehem, name):
           f"rows within 1e-3: {100 * rows_ok:.2f}%")
     parity_record(f"{name}/window", max_dlogit_vs_reference=e.max(), rows_within_1e3_vs_reference=rows_ok)
     # The reference's neighbour choice among EXACTLY tied distances is an artefact of its top-k implementation
-    # (std::partial_sort on CPU, radix-select on CUDA); rows whose 20th/21st neighbours tie can differ.  Demand
-    # that the bulk of the rows agree with the golden logits ...
-    assert rows_ok >= ROWS_OK_MIN.get(name, 0.97), (e.max(), rows_ok)
-    # ... and that ALL rows agree to 1e-3 with the CPU oracle once it is given the same neighbour sets.
+    # (std::partial_sort on CPU, radix-select on CUDA); rows whose 20th/21st neighbours tie can differ: the fraction of rows that
+    # agree is recorded (profiles/parity_r3.json), the proof that every other row is a tie is in the two tests at the end of this file.
+    # ALL rows agree to 1e-3 with the CPU oracle once it is given the same neighbour sets:
     from oracle import models_ref
     sd = {k: v.cpu() for k, v in ehem.state_dict().items()}
     models_ref.KNN_OVERRIDE = gpu_knn_for_oracle(dev)
@@ -1038,3 +1039,108 @@ def test_rowchain_weights_follow_parameter_updates(dev, ehem):
     finally:
         with torch.no_grad():
             layer.layernorm_after.weight.div_(1.5)
+
+
+# ---------------------------------------------------------------------------------------------------------------- lattice rows: the proof
+def _tied_points(feat, c, dev, rel=4e-6):
+    """Points of a window whose 20th and 21st nearest candidates are tied (float64 distances of the features the kernel saw; `rel` x
+    (|x_i|^2 + max |x|^2) = the rounding of an fp32 distance evaluation, the same yardstick as _knn_sets_vs_reference): the reference's
+    choice among them is an artefact of its top-k (std::partial_sort on CPU, dgcnn.py:10-45), not of the model."""
+    x = feat[:c].to(dev).double()
+    sq = (x * x).sum(1)
+    tied = torch.zeros(c, dtype=torch.bool, device=dev)
+    if c <= 20:
+        return tied.cpu().numpy()
+    for a in range(0, c, 2048):
+        d = sq[a:a + 2048, None] + sq[None, :] - 2.0 * (x[a:a + 2048] @ x.T)
+        ds = torch.sort(d, 1)[0]
+        scale = sq[a:a + 2048] + sq.max()
+        tied[a:a + 2048] = (ds[:, 20] - ds[:, 19]) <= rel * scale
+    return tied.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["logits_ehem_b2_c256", "logits_ehem_c600", "logits_ehem_c1024", "logits_ehem_c8192", "logits_ehem_c7"])
+def test_every_out_of_tolerance_lattice_row_is_explained_by_a_knn_tie(dev, ehem, monkeypatch, name):
+    """Octree positions are lattice points: exactly tied distances at the 20th / 21st neighbour are common, and which of the tied
+    candidates the reference keeps is decided by its top-k implementation.  Every row of the lattice fixtures that misses the 1e-3
+    tolerance against the reference must be EXPLAINED by such a tie: the row itself, or a row in one of its three neighbour lists, has
+    its 20th and 21st candidates tied in one of the three searches (float64 distances of the features the kernel saw).  unexplained == 0
+    is asserted; the fraction of rows inside the tolerance is only recorded."""
+    z = golden(name)
+    data, pos = _ehem_case(z)
+    B, c = data.shape[:2]
+    spy = _KnnSpy(monkeypatch)
+    o1, o2 = _run_packed(ehem, data, pos, dev)
+    st, w1, w2 = _want_rows(z)
+    assert len(spy.calls) == 3
+    cp = -(-(c + (c & 1)) // 512) * 512                        # rows a window owns in the packed layout (even-padded, x512)
+    total_bad = unexplained = tied_pts = 0
+    for b in range(B):
+        e1 = np.abs(o1[b, ::st] - w1[b]).max(1)
+        e2 = np.abs(o2[b, ::st] - w2[b]).max(1) if o2.shape[1] else np.zeros(0)
+        bad_tok = np.concatenate([2 * st * np.where(e1 > LOGIT_TOL)[0], 2 * st * np.where(e2 > LOGIT_TOL)[0] + 1]).astype(np.int64)
+        total_bad += len(bad_tok)
+        if not len(bad_tok):
+            continue
+        ce = c + (c & 1)                                       # the window as the model sees it (ehem.py:92-99 pads odd windows)
+        tied = np.zeros(ce, bool)
+        lists = []
+        for feat, idx in spy.calls:
+            f, ix = feat[b * cp:b * cp + ce], idx[b * cp:b * cp + ce].numpy().astype(np.int64) - b * cp
+            tied |= _tied_points(f, ce, dev)
+            lists.append(ix)
+        tied_pts += int(tied.sum())
+        for t in bad_tok:
+            ok = tied[t] or any(tied[np.clip(ix[t], 0, ce - 1)].any() for ix in lists)
+            unexplained += 0 if ok else 1
+    rows = sum(len(np.abs(o1[b, ::st])) + len(np.abs(o2[b, ::st])) for b in range(B))
+    parity_record(f"{name}/tie proof", rows=rows, rows_outside_1e3=total_bad, unexplained=unexplained, tied_points=tied_pts)
+    print(f"{name}: {total_bad} of {rows} rows outside 1e-3, unexplained {unexplained} (points with a tie at rank 20 / 21: {tied_pts})")
+    assert unexplained == 0
+
+
+@pytest.mark.parametrize("name", ["logits_ehem_b2_c256", "logits_ehem_c600", "logits_ehem_c1024", "logits_ehem_c8192"])
+def test_given_the_reference_neighbour_choice_every_lattice_row_matches(dev, ehem, monkeypatch, name):
+    """The constructive half of the proof: the CPU oracle (the reference's algorithm, torch.topk's own tie-breaking - its logits ARE the
+    fixture's) records the neighbour lists of its three searches; the product forward (packed path, every kernel of the encoder) is
+    then run with those lists in place of its own kNN results.  EVERY row of the fixture is then reproduced within 1e-3 - 100 %, no
+    fraction: the neighbour choice among tied candidates is the only thing that separates the two implementations on lattice inputs."""
+    from oracle import models_ref
+    from scp_amd import native
+    z = golden(name)
+    data, pos = _ehem_case(z)
+    B, c = data.shape[:2]
+    ce = c + (c & 1)
+    cp = -(-ce // 512) * 512
+    sd = {k: v.cpu() for k, v in ehem.state_dict().items()}
+    ref_lists = []
+
+    def record(x, k):
+        idx = models_ref.knn_default(x, k)
+        ref_lists.append(idx.clone())
+        return idx
+    models_ref.KNN_OVERRIDE = record
+    try:
+        with torch.no_grad():
+            r1, r2 = models_ref.ehem_forward(sd, data, pos)
+    finally:
+        models_ref.KNN_OVERRIDE = None
+    assert len(ref_lists) == 3 and ref_lists[0].shape == (B, ce, 20)
+    st, w1, w2 = _want_rows(z)
+    assert _row_err(r1.numpy(), r2.numpy(), st, w1, w2).max() < 2e-4          # the oracle run IS the reference run (float noise of the CPU build)
+    calls = []
+
+    def forced(x, ktab, thr0=None):
+        lists = ref_lists[len(calls)]
+        calls.append(1)
+        idx = torch.zeros((x.shape[0], 20), dtype=torch.int32)
+        for b in range(B):
+            idx[b * cp:b * cp + ce] = (lists[b] + b * cp).to(torch.int32)
+        return idx.to(x.device)
+    monkeypatch.setattr(native, "knn_topk_packed", forced)
+    o1, o2 = _run_packed(ehem, data, pos, dev)
+    assert len(calls) == 3
+    e = _row_err(o1, o2, st, w1, w2)
+    parity_record(f"{name}/reference neighbour lists", rows=e.shape[0], rows_within_1e3=(e.max(1) <= LOGIT_TOL).mean(), max_dlogit=e.max())
+    print(f"{name}: with the reference's neighbour lists max|dlogit| = {e.max():.3e}, rows within 1e-3: {100 * (e.max(1) <= LOGIT_TOL).mean():.2f} %")
+    assert e.max() <= LOGIT_TOL
