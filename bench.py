@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=4, help="frames in flight (encode_async handles not yet finished); 4 measured 1.2 % above 3, 5 no better")
+    ap.add_argument("--batch", type=int, default=None, help="frames per stage-G / packed-forward / CDF launch (FrameEncoder.encode_batch_async); "
+                    "default: 4 for the level-12 EHEM configuration (a 115 k-node frame is 22 windows), 1 elsewhere")
     ap.add_argument("--host-transform", action="store_true", help="strict-identity mode: numpy float32 transform + quantiser on the host (inside the timed region)")
     ap.add_argument("--all-configs", action="store_true", help="run every configuration of CONFIGS in turn (child processes), one JSON line each")
     ap.add_argument("--out-dir", default=None, help="with --all-configs: also write <out-dir>/<tag>_bench_<config>.json")
@@ -287,19 +289,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    batch = args.batch if args.batch is not None else (4 if args.config == "ehem-L12-s" else 1)
+    if batch > 1 and not ehem:
+        raise SystemExit("--batch is an EHEM option")
     for i in range(args.warmup):
         enc.finish(enc.encode_async(frames[i]))
+    if batch > 1:
+        enc.finish_batch(enc.encode_batch_async(frames[:batch]))
     barrier()
     cpu0 = time.process_time()                      # CPU seconds of this rank, all threads (launch thread, coder worker, reader)
     t0 = time.perf_counter()
     # frame i is range-coded on a worker thread while frames i+1 .. i+depth run on the GPU; a handle pins its ~590 MB logits table,
     # so at most `depth` frames are in flight (memory stays O(depth), not O(steps))
     pending, results = [], []
-    for i in range(args.warmup, total):
-        pending.append(enc.encode_async(frames[i]))
-        if len(pending) > args.depth:
-            results.append(enc.finish(pending.pop(0)))
-    results += [enc.finish(h) for h in pending]
+    if batch > 1:      # `batch` frames per launch sequence, two batches in flight (the range coder of one under the kernels of the next)
+        for i in range(args.warmup, total, batch):
+            pending.append(enc.encode_batch_async(frames[i:min(total, i + batch)]))
+            if len(pending) > 1:
+                results += enc.finish_batch(pending.pop(0))
+        for h in pending:
+            results += enc.finish_batch(h)
+    else:
+        for i in range(args.warmup, total):
+            pending.append(enc.encode_async(frames[i]))
+            if len(pending) > args.depth:
+                results.append(enc.finish(pending.pop(0)))
+        results += [enc.finish(h) for h in pending]
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0               # this rank's own time for its frames (before the barrier)
     cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps
@@ -368,7 +383,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": cfg["workload"] + ", seeded random weights", "nodes_per_frame": int(n_nodes), "windows_per_frame": windows,
-                       "frames_per_gpu": args.steps, "frames_in_flight": args.depth, "transform": "host-numpy (strict identity)" if enc.host_transform else "device", "parallelism": f"frame-sharded x{world}",
+                       "frames_per_gpu": args.steps, "frames_in_flight": args.depth if batch == 1 else 2 * batch, "frames_per_launch_sequence": batch, "transform": "host-numpy (strict identity)" if enc.host_transform else "device", "parallelism": f"frame-sharded x{world}",
                        "rank_cores": len(pinned) if pinned else None},
             "rccl_world": dist.get_world_size() if world > 1 else 1, "dist_backend": backend if world > 1 else None,
             "host_cpu_ms_per_frame": cpu_ms,

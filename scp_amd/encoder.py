@@ -271,6 +271,18 @@ class FrameEncoder:
         return self._encode_pre(self.preprocess_ints(dq, bin_num, z_offset, n_points), t0, timing)
 
     # ------------------------------------------------------------------------------------------ pipelined variant
+    def _init_streams(self):
+        if hasattr(self, "_pool"):
+            return
+        self._pool = ThreadPoolExecutor(max_workers=2)
+        self._copy_stream = torch.cuda.Stream(device=self.device)
+        self._front_stream = torch.cuda.Stream(device=self.device, priority=-1)   # high priority: its tiny kernels slip in between the model's
+        # Lanes: consecutive frames run their model part on alternating streams, so the launch gaps and tails of one frame's
+        # kernels are filled by the other's (the kernels are whole-GPU persistent launches: they interleave rather than
+        # co-run).  SCP_LANES=1 keeps every frame on the caller's stream.
+        self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(os.environ.get("SCP_LANES", "2"))))]
+        self._lane_i = 0
+
     def encode_async(self, xyz, ints=None):
         """Like encode(), but the D2H copy of the (c_low, c_high) pairs and the serial host range coder run on a worker
         thread (ctypes releases the GIL) behind an event on a side stream, so the caller can enqueue the next frame while this
@@ -281,15 +293,7 @@ class FrameEncoder:
             xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
         if self.host_transform and ints is None:
             ints = self.host_ints(xyz)
-        if not hasattr(self, "_pool"):
-            self._pool = ThreadPoolExecutor(max_workers=2)
-            self._copy_stream = torch.cuda.Stream(device=self.device)
-            self._front_stream = torch.cuda.Stream(device=self.device, priority=-1)   # high priority: its tiny kernels slip in between the model's
-            # Lanes: consecutive frames run their model part on alternating streams, so the launch gaps and tails of one frame's
-            # kernels are filled by the other's (the kernels are whole-GPU persistent launches: they interleave rather than
-            # co-run).  SCP_LANES=1 keeps every frame on the caller's stream.
-            self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(os.environ.get("SCP_LANES", "2"))))]
-            self._lane_i = 0
+        self._init_streams()
         # Front part on its own stream: stage G (with its small D2H syncs) and the window plans (one plan_kernel launch per chunk)
         # are launch-bound; on a side stream they run under the previous frame's model kernels instead of in front of this
         # frame's.  Everything allocated here stays referenced by the handle until finish(), i.e. past its last use on the
@@ -334,6 +338,102 @@ class FrameEncoder:
 
         fut = self._pool.submit(work)
         return dict(future=fut, pre=pre, plan=plan, t0=t0, keep=(order, sym_coded, table, lohi))
+
+    # ------------------------------------------------------------------------------------------ batches of small frames
+    def preprocess_batch(self, frames):
+        """Stage G of k frames at once: one scp_geom_build with every (frame, shell) as a segment - one radix sort, one tree pass - and
+        the frames' context tables back to back.  Frames share nothing (encode.py:274-291 rebuilds everything per frame): the batch is
+        ONE sequence of levels - the frames' level lists one after the other - for the window plan, the packed forward and the CDF
+        kernel, and is cut into frames again in front of the range coder.  Returns (combined `pre`, per-frame meta)."""
+        L = self.lidar_level
+        qs_all, metas = [], []
+        for xyz_dev in frames:
+            qs, bin_num, z_off = self.quantize(xyz_dev)
+            qs_all.append(qs)
+            metas.append(dict(bin_num=bin_num, z_offset=z_off, n_points=int(xyz_dev.shape[0]), bin_nums=[float(i.bin_num) for i in self._infos]))
+        flat = [q for qs in qs_all for q in qs]
+        if len(flat) > 62:
+            raise native.ScpError("a batch holds at most 62 (frame, shell) trees (SCP_MAX_SEGMENTS)")
+        segs, off = [], 0
+        for qs in qs_all:
+            for (path, _), qq in zip(self.shells(), qs):
+                segs.append((off, qq.shape[0], path, self.mullevel))
+                off += qq.shape[0]
+        self.geom.build(torch.cat(flat).contiguous(), segs)
+        pos_mode = native.POS_MINMAX_MUL if self.mullevel else (native.POS_POW2 if self.mode == native.CART else native.POS_MINMAX)
+        ctxs, poss, syms, sizes = [], [], [], []
+        ns = len(self.shells())
+        for f, meta in enumerate(metas):
+            mms, fsizes = [], []
+            for s in range(f * ns, (f + 1) * ns):
+                ctx, pos, sym, mm = self.geom.context_ehem(s, pos_mode, L)
+                ctxs.append(ctx); poss.append(pos); syms.append(sym); mms.append(mm)
+                counts = self.geom.level_counts(s)
+                if self.mullevel:
+                    counts[-1] -= 1
+                fsizes += counts
+            meta.update(pos_mm=torch.cat(mms), level_sizes=fsizes, n_nodes=int(sum(fsizes)))
+            sizes += fsizes
+        return dict(ctx=torch.cat(ctxs), pos=torch.cat(poss), sym=torch.cat(syms), level_sizes=sizes), metas
+
+    def encode_batch_async(self, frames):
+        """k frames through ONE stage G, ONE packed forward and ONE CDF launch (the small-frame configurations: a level-12 frame has
+        22 windows, far too few for an MI355X - BASELINE.json configs[1] is a batch of 16 of them).  The streams are byte-identical
+        to the per-frame path (every kernel is per window / per row).  Returns a handle for finish_batch()."""
+        t0 = time.perf_counter()
+        self._init_streams()
+        # the same stream structure as encode_async: stage G + plans on the high-priority front stream, the model part on the next lane
+        caller = torch.cuda.current_stream(self.device)
+        if len(self._lanes) > 1:
+            main = self._lanes[self._lane_i % len(self._lanes)]
+            self._lane_i += 1
+            main.wait_stream(caller)
+        else:
+            main = caller
+        fills0 = native.CACHE_FILLS
+        with torch.cuda.stream(self._front_stream):
+            self._front_stream.wait_stream(caller)
+            dev_frames = [(torch.from_numpy(np.ascontiguousarray(x, np.float32)) if isinstance(x, np.ndarray) else x).to(self.device, non_blocking=True)
+                          for x in frames]
+            pre, metas = self.preprocess_batch(dev_frames)
+            plan = EncodePlan(pre["level_sizes"], self.context_size)
+            if self.packed:
+                pre["packed_plans"] = self.packed_plans(plan)
+            order = plan.coding_order_device(self.device)
+            sym_coded = pre["sym"][order].contiguous()
+            ready = torch.cuda.Event()
+            ready.record()
+        main.wait_event(ready)
+        with torch.cuda.stream(main):
+            table = self.logits_in_coding_order(pre, plan)
+            lohi = native.softmax_cdf(table, sym_coded)["lohi"]
+            done = torch.cuda.Event()
+            done.record()
+            if native.CACHE_FILLS != fills0:
+                main.synchronize()
+        host = torch.empty(lohi.shape, dtype=lohi.dtype, pin_memory=True)
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(done)
+            host.copy_(lohi, non_blocking=True)
+            lohi.record_stream(self._copy_stream)
+            copied = torch.cuda.Event()
+            copied.record()
+        cuts = np.concatenate(([0], np.cumsum([m["n_nodes"] for m in metas])))
+
+        def work():
+            copied.synchronize()
+            h = host.numpy()
+            return [native.ac_encode_lohi(h[cuts[f]:cuts[f + 1]]) for f in range(len(metas))]
+        return dict(future=self._pool.submit(work), metas=metas, t0=t0, keep=(pre, plan, order, sym_coded, table, lohi, dev_frames))
+
+    def finish_batch(self, h):
+        out = []
+        for stream, m in zip(h["future"].result(), h["metas"]):
+            bits = 8 * len(stream)
+            out.append(dict(bytes=stream, bits=bits, bpp=bits / m["n_points"], n_nodes=m["n_nodes"], n_points=m["n_points"], bin_num=m["bin_num"],
+                            z_offset=m["z_offset"], n_levels=len(m["level_sizes"]), pos_mm=m["pos_mm"].cpu().numpy(), level_sizes=m["level_sizes"],
+                            bin_nums=m["bin_nums"], times=dict(total=(time.perf_counter() - h["t0"]) / len(h["metas"]))))
+        return out
 
     def finish(self, h):
         stream = h["future"].result()

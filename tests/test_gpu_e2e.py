@@ -856,3 +856,26 @@ def test_e2e_given_the_reference_neighbour_choice_every_pmf_row_matches(enc_part
           f"{res['bits']} vs {8 * len(z['bytes'])}")
     assert d.max() < 1e-4
     assert res["bits"] == 8 * len(z["bytes"])
+
+
+@pytest.mark.parametrize("mul,level", [(False, 12), (True, 12)])
+def test_batched_frames_give_the_per_frame_streams(enc_parts, mul, level):
+    """FrameEncoder.encode_batch_async: k frames through one stage G (every (frame, shell) a segment of one scp_geom_build), one packed
+    forward and one CDF launch - byte-identical streams, node counts, side information to k separate encodes (frames of different
+    sizes, one of them tiny)."""
+    from scp_amd.encoder import FrameEncoder
+    from scp_amd.synth import synth_frame
+    model, dev = enc_parts
+    enc = FrameEncoder(model, "kitti", level, spher=True, mullevel=mul, device=dev)
+    frames = [synth_frame(20)[::9].copy(), synth_frame(21)[::31].copy(), synth_frame(22)[:50].copy(), synth_frame(23)[::14].copy()]
+    single = [enc.encode(f) for f in frames]
+    got = enc.finish_batch(enc.encode_batch_async(frames))
+    assert len(got) == len(frames)
+    for a, b in zip(single, got):
+        assert a["bytes"] == b["bytes"] and a["n_nodes"] == b["n_nodes"] and a["n_points"] == b["n_points"] and a["bin_num"] == b["bin_num"]
+        assert a["level_sizes"] == b["level_sizes"] and np.array_equal(a["pos_mm"], b["pos_mm"]) and a["bin_nums"] == b["bin_nums"]
+        assert enc.outfile("x", a) == enc.outfile("x", b)
+    # a second batch on the same encoder (workspace reuse) and a batch of one
+    again = enc.finish_batch(enc.encode_batch_async(frames[::-1]))
+    assert [r["bytes"] for r in again] == [r["bytes"] for r in single[::-1]]
+    assert enc.finish_batch(enc.encode_batch_async(frames[:1]))[0]["bytes"] == single[0]["bytes"]
