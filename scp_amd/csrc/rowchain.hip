@@ -649,7 +649,8 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
 
     unsigned long long t_p0 = 0, t_ln = 0, t_mlp = 0, t_epi = 0, t_prev = 0, n_tiles = 0;
     const bool DBG = a.dbg != nullptr;
-    if (DBG) t_prev = __builtin_amdgcn_s_memtime();
+    unsigned long long t_first = 0, r_first = 0;
+    if (DBG) { t_prev = t_first = __builtin_amdgcn_s_memtime(); r_first = __builtin_amdgcn_s_memrealtime(); }
     auto stamp = [&](unsigned long long &acc_t) { if (DBG) { const unsigned long long t = __builtin_amdgcn_s_memtime(); acc_t += t - t_prev; t_prev = t; } };
 
     // (Measured and dropped: starting the workgroups an eighth of a tile time apart, so that the 256 epilogues - 128 KB of row stores per
@@ -837,6 +838,7 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
     if (DBG && L.lane == 0) {
         unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 4 + L.w) * 8;
         o[0] = t_p0; o[1] = t_mlp; o[2] = t_ln; o[3] = t_epi; o[4] = n_tiles;
+        o[5] = __builtin_amdgcn_s_memtime() - t_first; o[6] = __builtin_amdgcn_s_memrealtime() - r_first;     // shader clock = o[5] / o[6] x 100 MHz
     }
     SCP_WAIT_DMA(0);
 }
