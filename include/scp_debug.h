@@ -30,6 +30,9 @@ SCP_API int scp_mlp_debug_buffer(unsigned long long *dev_buf);
 /* the same for the row-chain kernels (scp_swin_ln_linear / scp_swin_post_attn): (workgroups * 4 * 8) u64, per wave the cycle sums of
  * the kernel's phases and its tile count (tools/mb_rowchain_probe.py, tools/mb_postattn.py) */
 SCP_API int scp_rc_debug_buffer(unsigned long long *dev_buf);
+/* persistent workgroups of the row-chain launches (0 = one per CU of the device): for launches on a stream created with a CU mask
+ * (tools/mb_cumask.py), whose CU set is smaller than the device's */
+SCP_API int scp_rc_set_grid(int32_t workgroups);
 
 #ifdef __cplusplus
 }

@@ -846,8 +846,12 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
 static unsigned long long *g_rc_dbg = nullptr;   // diagnostic only (tools/mb_rowchain_probe.py): [workgroup][wave][8] cycle sums
 extern "C" SCP_API int scp_rc_debug_buffer(unsigned long long *dev_buf) { g_rc_dbg = dev_buf; return SCP_OK; }
 
-static int g_rc_num_cu = 0;
+static int g_rc_num_cu = 0, g_rc_grid = 0;
+// measurement hook (scp_debug.h): number of persistent workgroups of the row-chain launches; 0 = one per CU of the device.  For streams
+// created with a CU mask (tools/mb_cumask.py) - a persistent grid larger than the stream's CU set would run in two rounds.
+extern "C" SCP_API int scp_rc_set_grid(int32_t workgroups) { g_rc_grid = workgroups > 0 ? workgroups : 0; return SCP_OK; }
 static int rc_num_cu() {
+    if (g_rc_grid) return g_rc_grid;
     if (!g_rc_num_cu) {
         int dev = 0;
         hipDeviceProp_t p;
