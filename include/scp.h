@@ -29,6 +29,15 @@ extern "C" {
 #define SCP_MAX_DEPTH 21      /* 3*21 = 63 Morton bits                     */
 #define SCP_MAX_SEGMENTS 62   /* trees built by one scp_geom_build call    */
 
+/* SCP_ABI_VERSION is what this header describes, scp_version() what the loaded library implements; a caller compares the two once
+ * after loading (scp_amd/native.py does) instead of finding out through wrong numbers.  History of incompatible changes:
+ *   100  rounds 1 - 2a
+ *   200  WEIGHT LAYOUT: every dense entry point (scp_linear_bf16x3, scp_linear_f16x3*, scp_linear_split*, scp_mlp_split_fused and the
+ *        row-chain entry points) reads its weight planes in the TILED layout of scp_tile_weight_bf16; planes straight out of
+ *        scp_split_weight_bf16 / scp_split_weight_f16 (the version-100 contract) give SCP_OK and wrong products.  Pass every plane
+ *        through scp_tile_weight_bf16 once, or load the library with SCP_WTILE=0 in the environment for the row-major contract;
+ *        the process-wide numeric-profile setters and the debug hooks moved to scp_debug.h, scp_ctx replaces the setters. */
+#define SCP_ABI_VERSION 200
 SCP_API int scp_version(void);
 SCP_API int scp_last_hip_error(void);
 /* number of HIP devices visible / name of device 0 (for bench reports) */

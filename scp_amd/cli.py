@@ -100,7 +100,8 @@ def obj_ints(xyz, name, dev):
     p = torch.from_numpy(np.ascontiguousarray(xyz[:, :3], np.float32)).to(dev)
     if any(m in name for m in MVUB_NAMES):
         p = torch.stack((p[:, 0], p[:, 2], -p[:, 1]), 1)
-    return torch.round((p - p.min(0)[0]).double()).to(torch.int32).contiguous()
+    off = p.min(0)[0]
+    return torch.round((p - off).double()).to(torch.int32).contiguous(), [float(v) for v in off.cpu()]
 
 
 def refuse_unsupported(args, name, mullevel):
@@ -269,8 +270,9 @@ def main(argv=None, mullevel=False):
             recs = [np.load(pp + sfx + ".npy") for sfx in (("_0_0", "_0_1", "_1") if mullevel else ("",))]
             res = enc.encode_records(recs, float(meta[0]), float(meta[2]) if len(meta) > 2 else 0.0, len(xyz))
         elif obj:
-            q = obj_ints(xyz, cur, dev)
+            q, off = obj_ints(xyz, cur, dev)
             res = enc.encode_ints(q, 0, len(xyz), sequential=args.sequential) if name == "OctAttention" else enc.encode_ints([q], 0, 0.0, len(xyz))
+            res["quant"] = [dict(qs=[1.0, 1.0, 1.0], offset=off)]     # the sidecar is the only carrier of the per-axis minimum
         elif name == "OctAttention":
             res = enc.encode(xyz, sequential=args.sequential)
         else:
@@ -308,7 +310,7 @@ def get_decode_args(argv=None):
     p.add_argument("--random_weights", type=int, default=None)
     p.add_argument("--out_dir", type=str, default=None)
     p.add_argument("--lidar_level", type=int, default=None, help="overrides the side-info file / the reference's level-count rule")
-    p.add_argument("--type", type=str, default=None, choices=[None, "kitti", "ford"])
+    p.add_argument("--type", type=str, default=None, choices=[None, "obj", "kitti", "ford"])
     return p.parse_args(argv)
 
 

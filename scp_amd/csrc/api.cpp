@@ -5,7 +5,7 @@
 
 int g_scp_last_hip_error = 0;
 
-extern "C" int scp_version(void) { return 100; }
+extern "C" int scp_version(void) { return SCP_ABI_VERSION; }
 extern "C" int scp_last_hip_error(void) { return g_scp_last_hip_error; }
 
 extern "C" int scp_device_count(void) {

@@ -38,11 +38,13 @@ def write_sidecar(outfile, enc, res, model_name):
     """`<outfile>.scp.json` - what the reference's two side-info carriers cannot hold (an extension; the `.bin` / `.dat` pair stays
     exactly the reference's): lidar level and dataset type (the reference decoder takes the level count for the lidar level,
     decode_ehem.py:218), each shell's own bin_num (the file name has the first shell's only, but every shell de-quantises its
-    angles with its own), the un-truncated z offset, and the numeric profile of the kernels that produced the CDFs."""
+    angles with its own), the un-truncated z offset, `quant` = per shell the (qs[3], offset[3]) the integers were made with when the encoder quantised the
+    frame itself (None on the --preproc_path / encode_ints paths: the dataset rules of `shell_qs` then apply, and `--type obj`, whose
+    per-axis-minimum offset exists nowhere else, cannot be de-quantised), and the numeric profile of the kernels that produced the CDFs."""
     side = dict(model=model_name, type=enc.data_type, lidar_level=int(enc.lidar_level), mullevel=bool(enc.mullevel),
                 spher=bool(enc.spher), cylin=bool(enc.cylin), n_points=int(res["n_points"]), n_nodes=int(res["n_nodes"]),
                 bin_nums=[float(b) for b in res.get("bin_nums", [res["bin_num"]])],
-                z_offset=float(res["z_offset"]), profile=native.numeric_profile(model_name, getattr(enc, "profile", None)))
+                z_offset=float(res["z_offset"]), quant=res.get("quant"), profile=native.numeric_profile(model_name, getattr(enc, "profile", None)))
     with open(outfile + SIDECAR, "w") as f:
         json.dump(side, f)
     return side
@@ -102,7 +104,15 @@ def decode_file(binfile, model, lidar_level=None, data_type=None, mullevel=False
     with open(binfile, "rb") as f:
         stream = f.read()
     shells = dec.decode(stream, n_levels, pos_mm)
-    pts = [dequantise_leaves(lv, q, b, z_offset, spher, cylin, data_type) for (_, lv), q, b in zip(shells, qs, bins)]
+    quant = side.get("quant") if side is not None else None
+    if quant is not None and len(quant) == len(shells):
+        from . import metrics
+        pts = [metrics.dequantize(lv, qd["qs"], qd["offset"], spher=spher, cylin=cylin) for (_, lv), qd in zip(shells, quant)]
+    elif data_type == "obj":
+        raise native.ScpError(f"{binfile}: --type obj streams are quantised with the frame's per-axis minimum as offset "
+                              "(data_preprocess.py:31-37), which only the sidecar's `quant` entry records - it is missing here")
+    else:
+        pts = [dequantise_leaves(lv, q, b, z_offset, spher, cylin, data_type) for (_, lv), q, b in zip(shells, qs, bins)]
     return dict(codes=[torch.cat(c) for c, _ in shells], leaves=[lv for _, lv in shells], points=torch.cat(pts),
                 spher=spher, cylin=cylin, n_levels=n_levels, bin_num=bin_num, z_offset=z_offset, lidar_level=lidar_level)
 

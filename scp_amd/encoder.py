@@ -75,6 +75,12 @@ class EncodePlan:
         return order
 
 
+def _quant_of(infos):
+    """Per shell the quantiser's (qs[3], offset[3]) as plain floats: what de-quantisation needs and the reference's file name cannot
+    carry exactly (decoder.write_sidecar)."""
+    return [dict(qs=[float(v) for v in i.qs], offset=[float(v) for v in i.offset]) for i in infos]
+
+
 class FrameEncoder:
     def __init__(self, model, data_type=KITTI, lidar_level=12, spher=True, cylin=False, mullevel=False, max_batch=8,
                  device=None, packed=True, max_tokens=1_000_000, host_transform=None, profile=None):
@@ -145,6 +151,7 @@ class FrameEncoder:
         qs, bin_num, z_off = self.quantize(xyz_dev, ints)
         pre = self.preprocess_ints(qs, bin_num, z_off, xyz_dev.shape[0])
         pre["bin_nums"] = [float(i.bin_num) for i in self._infos]      # every shell's own (the file name carries the first)
+        pre["quant"] = _quant_of(self._infos)                          # the steps and offsets the integers were made with (sidecar)
         return pre
 
     def preprocess_ints(self, qs, bin_num, z_offset, n_points):
@@ -350,7 +357,8 @@ class FrameEncoder:
         for xyz_dev in frames:
             qs, bin_num, z_off = self.quantize(xyz_dev)
             qs_all.append(qs)
-            metas.append(dict(bin_num=bin_num, z_offset=z_off, n_points=int(xyz_dev.shape[0]), bin_nums=[float(i.bin_num) for i in self._infos]))
+            metas.append(dict(bin_num=bin_num, z_offset=z_off, n_points=int(xyz_dev.shape[0]), bin_nums=[float(i.bin_num) for i in self._infos],
+                              quant=_quant_of(self._infos)))
         flat = [q for qs in qs_all for q in qs]
         if len(flat) > 62:
             raise native.ScpError("a batch holds at most 62 (frame, shell) trees (SCP_MAX_SEGMENTS)")
@@ -432,7 +440,7 @@ class FrameEncoder:
             bits = 8 * len(stream)
             out.append(dict(bytes=stream, bits=bits, bpp=bits / m["n_points"], n_nodes=m["n_nodes"], n_points=m["n_points"], bin_num=m["bin_num"],
                             z_offset=m["z_offset"], n_levels=len(m["level_sizes"]), pos_mm=m["pos_mm"].cpu().numpy(), level_sizes=m["level_sizes"],
-                            bin_nums=m["bin_nums"], times=dict(total=(time.perf_counter() - h["t0"]) / len(h["metas"]))))
+                            bin_nums=m["bin_nums"], quant=m.get("quant"), times=dict(total=(time.perf_counter() - h["t0"]) / len(h["metas"]))))
         return out
 
     def finish(self, h):
@@ -442,7 +450,7 @@ class FrameEncoder:
         return dict(bytes=stream, bits=bits, bpp=bits / pre["n_points"], n_nodes=plan.n_rows, n_points=pre["n_points"],
                     bin_num=pre["bin_num"], z_offset=pre["z_offset"], n_levels=len(pre["level_sizes"]),
                     pos_mm=pre["pos_mm"].cpu().numpy(), level_sizes=pre["level_sizes"], bin_nums=pre.get("bin_nums", [float(pre["bin_num"])]),
-                    times=dict(total=time.perf_counter() - h["t0"]))
+                    quant=pre.get("quant"), times=dict(total=time.perf_counter() - h["t0"]))
 
     def _encode_pre(self, pre, t0, timing):
         if timing:
@@ -463,7 +471,7 @@ class FrameEncoder:
         return dict(bytes=stream, bits=bits, bpp=bits / pre["n_points"], n_nodes=plan.n_rows, n_points=pre["n_points"],
                     bin_num=pre["bin_num"], z_offset=pre["z_offset"], n_levels=len(pre["level_sizes"]),
                     pos_mm=pre["pos_mm"].cpu().numpy(), level_sizes=pre["level_sizes"], bin_nums=pre.get("bin_nums", [float(pre["bin_num"])]),
-                    times=dict(geom=t1 - t0, model=t2 - t1, cdf=t3 - t2, coder=t4 - t3, total=t4 - t0),
+                    quant=pre.get("quant"), times=dict(geom=t1 - t0, model=t2 - t1, cdf=t3 - t2, coder=t4 - t3, total=t4 - t0),
                     _debug=dict(table=table, sym_coded=sym_coded, order=order, pre=pre))
 
     def outfile(self, base, res):

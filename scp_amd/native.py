@@ -42,6 +42,9 @@ _lib = None
 _vp = C.c_void_p
 
 
+ABI_VERSION = 200      # include/scp.h: SCP_ABI_VERSION
+
+
 def lib():
     """Load libscp_hip.so; raises if it has not been built (python -m scp_amd.build / __graft_entry__.build())."""
     global _lib
@@ -126,6 +129,9 @@ def lib():
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
+    if L.scp_version() != ABI_VERSION:
+        raise ScpError(f"{LIB_PATH} implements ABI {L.scp_version()}, this binding is written for {ABI_VERSION} (include/scp.h: "
+                       "SCP_ABI_VERSION; the weight-plane layout differs between versions): rebuild with `python scp_amd/build.py`")
     _lib = L
     return L
 
@@ -512,10 +518,25 @@ def note_cache_fill():
 
 
 
-class SplitWeight:
-    """bf16 hi/lo planes of a Linear weight [N,K], zero-padded to [Npad,Kpad] (built once per weight)."""
+# SCP_WTILE=0: the dense kernels take row-major weight planes (A/B bracket).  Read ONCE, here - csrc/gemm.hip and gemm_split.hip read
+# it once too (a static), so a value changed after the first launch could only make the two sides disagree.
+WTILE = os.environ.get("SCP_WTILE", "1")[:1] != "0"
 
-    def __init__(self, w):
+
+def _tile_in_place_of(hi, lo, Npad, Kpad):
+    """The tiled images (scp_tile_weight_bf16) of two row-major 16-bit planes, on the current stream."""
+    th, tl = torch.empty_like(hi), torch.empty_like(lo)
+    for src, dst in ((hi, th), (lo, tl)):
+        _check(lib().scp_tile_weight_bf16(src.data_ptr(), Npad, Kpad, dst.data_ptr(), _stream()), "scp_tile_weight_bf16")
+    return th, tl
+
+
+class SplitWeight:
+    """bf16 hi/lo planes of a Linear weight [N,K], zero-padded to [Npad,Kpad], in the layout the dense kernels stream (built once per
+    weight, split AND tiled in the constructor - one cache fill, on one stream; the row-major intermediate is not kept).
+    `.hi / .lo`: the planes; `.tiled_layout`: whether they are tiled (always, unless SCP_WTILE=0)."""
+
+    def __init__(self, w, tiled=None):
         N, K = w.shape
         self.N, self.K = N, K
         self.Npad, self.Kpad = -(-N // 256) * 256, -(-K // 32) * 32
@@ -524,12 +545,14 @@ class SplitWeight:
         wc = w.detach().contiguous().float()
         _check(lib().scp_split_weight_bf16(_dev(wc), N, K, self.Npad, self.Kpad, _dev(self.hi), _dev(self.lo), _stream()),
                "scp_split_weight_bf16")
-        self._tiled = None
+        self.tiled_layout = WTILE if tiled is None else bool(tiled)
+        if self.tiled_layout:
+            self.hi, self.lo = _tile_in_place_of(self.hi, self.lo, self.Npad, self.Kpad)
         note_cache_fill()
 
     def tiled(self):
-        """(hi, lo) in the tiled layout of _tile_planes (built once): what the dense kernels stream (SCP_WTILE=0: row-major)."""
-        return _tiled_pair(self)
+        """(hi, lo) as the dense kernels stream them: tiled (_tile_planes) by default, row-major under SCP_WTILE=0."""
+        return (self.hi, self.lo)
 
 
 def linear_bf16x3(x, sw, bias=None, act=ACT_NONE, residual=None, out=None):
@@ -559,22 +582,14 @@ def linear_bf16x3(x, sw, bias=None, act=ACT_NONE, residual=None, out=None):
 
 
 def _tiled_pair(sw):
-    if os.environ.get("SCP_WTILE", "1")[:1] == "0":
-        return (sw.hi, sw.lo)
-    if getattr(sw, "_tiled", None) is None:
-        th, tl = torch.empty_like(sw.hi), torch.empty_like(sw.lo)
-        for src, dst in ((sw.hi, th), (sw.lo, tl)):
-            _check(lib().scp_tile_weight_bf16(src.data_ptr(), sw.Npad, sw.Kpad, dst.data_ptr(), _stream()), "scp_tile_weight_bf16")
-        sw._tiled = (th, tl)
-    return sw._tiled
+    return (sw.hi, sw.lo)
 
 
 def _tiled_planes_always(sw):
     """(hi, lo) of a SplitWeight in the tiled layout whatever SCP_WTILE says (the row-chain kernels have no row-major mode)."""
-    th, tl = torch.empty_like(sw.hi), torch.empty_like(sw.lo)
-    for src, dst in ((sw.hi, th), (sw.lo, tl)):
-        _check(lib().scp_tile_weight_bf16(src.data_ptr(), sw.Npad, sw.Kpad, dst.data_ptr(), _stream()), "scp_tile_weight_bf16")
-    return th, tl
+    if sw.tiled_layout:
+        return sw.hi, sw.lo
+    return _tile_in_place_of(sw.hi, sw.lo, sw.Npad, sw.Kpad)
 
 
 def _tile_planes(t):
@@ -602,6 +617,9 @@ class SplitWeightF16:
         wc = w.detach().contiguous().float()
         _check(lib().scp_split_weight_f16(_dev(wc), N, K, self.Npad, self.Kpad, _dev(self.hi), _dev(self.lo), _dev(self.inv_scale),
                                           _stream()), "scp_split_weight_f16")
+        self.tiled_layout = WTILE
+        if self.tiled_layout:       # the tiling is a permutation of 16-bit elements: the same kernel serves f16 planes
+            self.hi, self.lo = _tile_in_place_of(self.hi, self.lo, self.Npad, self.Kpad)
         note_cache_fill()
 
 

@@ -28,7 +28,9 @@ def test_library_exports_every_declared_symbol():
         assert n in dbg and n not in names
     for n in ("scp_ctx_create", "scp_ctx_set", "scp_ctx_make_current", "scp_swin_ln_linear", "scp_swin_post_attn", "scp_swin_post_attn_weight_bytes"):
         assert n in names
-    assert L.scp_version() >= 100
+    import re
+    hdr = open(os.path.join(ROOT, 'include', 'scp.h')).read()
+    assert L.scp_version() == int(re.search(r'#define SCP_ABI_VERSION (\d+)', hdr).group(1)) == native.ABI_VERSION
     assert isinstance(L, ctypes.CDLL)
 
 

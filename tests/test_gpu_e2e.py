@@ -305,6 +305,34 @@ def test_cli_obj_and_octattn_mullevel(tmp_path, orc):
         assert (int(bins[0].split("_")[2]) == 3) == (not lw)
 
 
+def test_cli_obj_stream_decodes_with_the_sidecars_offsets(tmp_path):
+    """`--type obj` EHEM stream: the per-axis-minimum offset (data_preprocess.py:31-37) exists only in the sidecar's `quant` entry; the
+    decode CLI must give the input's points back exactly (integer grid, qs 1) and refuse the stream when the entry is missing instead
+    of de-quantising it with another data set's rule."""
+    import json
+    from scp_amd import native
+    from scp_amd.cli import decode_main
+    from scp_amd.data_preproc.pt import ptread, write_ply_data
+    rng = np.random.default_rng(11)
+    pts = np.unique(rng.integers(0, 128, size=(6000, 3)), axis=0).astype(np.float32) + np.float32([3.0, -11.0, 40.0])
+    ply = str(tmp_path / "thing_vox7.ply")
+    write_ply_data(ply, pts)
+    out = tmp_path / "o"
+    r = _run_cli("encode.py", ["--test_files", ply, "--random_weights", "0", "--out_dir", str(out)], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    side = [p for p in out.iterdir() if p.name.endswith(".scp.json")]
+    assert len(side) == 1
+    sj = json.load(open(side[0]))
+    assert sj["type"] == "obj" and sj["quant"][0]["qs"] == [1.0, 1.0, 1.0] and np.allclose(sj["quant"][0]["offset"], pts.min(0))
+    res = decode_main(["--test_files", ply, "--random_weights", "0", "--out_dir", str(out)], mullevel=False)      # type from the sidecar
+    got = ptread(res[0][0])[:, :3]
+    assert sorted(map(tuple, np.round(got, 3).tolist())) == sorted(map(tuple, pts.tolist()))
+    del sj["quant"]
+    json.dump(sj, open(side[0], "w"))
+    with pytest.raises(native.ScpError, match="per-axis minimum"):
+        decode_main(["--test_files", ply, "--random_weights", "0", "--out_dir", str(out), "--type", "obj"], mullevel=False)
+
+
 @pytest.mark.parametrize("mullevel,mode", [(False, "spher"), (True, "spher"), (False, "cylin"), (False, "cart")])
 def test_cli_encode_then_decode_files(tmp_path, orc, mullevel, mode):
     """f1 through the FILES: encode CLI -> `.bin` + `.dat` (+ `.scp.json`) -> decode CLI (side info parsed like

@@ -802,9 +802,10 @@ def test_tiled_weight_planes(dev):
     from scp_amd import native
     g = torch.Generator().manual_seed(5)
     w = torch.randn((300, 600), generator=g).to(dev)
-    sw = native.SplitWeight(w)
+    sw, rm = native.SplitWeight(w), native.SplitWeight(w, tiled=False)
     th, tl = sw.tiled()
-    assert torch.equal(th.view(-1), native._tile_planes(sw.hi).view(-1)) and torch.equal(tl.view(-1), native._tile_planes(sw.lo).view(-1))
+    assert sw.tiled_layout and not rm.tiled_layout
+    assert torch.equal(th.view(-1), native._tile_planes(rm.hi).view(-1)) and torch.equal(tl.view(-1), native._tile_planes(rm.lo).view(-1))
     code = ("import torch, hashlib, sys; sys.path.insert(0, %r); from scp_amd import native; dev = torch.device('cuda:0'); g = torch.Generator().manual_seed(9);"
             "x = torch.randn((1000, 256), generator=g).to(dev); w1 = (torch.randn((1024, 256), generator=g) / 16).to(dev); b1 = torch.randn(1024, generator=g).to(dev);"
             "w2 = (torch.randn((256, 1024), generator=g) / 32).to(dev); b2 = torch.randn(256, generator=g).to(dev); a = native.split_rows(x);"

@@ -177,10 +177,11 @@ def test_obj_quantisation_matches_proc_pc_defaults():
     p = (rng.random((500, 3)) * 300 - 40).astype(np.float32)
     p[:7] = np.round(p[:7]) + 0.5                                       # exact halves: round half to even
     want = np.round(p - np.min(p, 0)).astype(np.int32)                  # the reference's arithmetic (float32 - float32, np.round)
-    assert np.array_equal(obj_ints(p, "thing_vox9.ply", torch.device("cpu")).numpy(), want)
+    q, off = obj_ints(p, "thing_vox9.ply", torch.device("cpu"))
+    assert np.array_equal(q.numpy(), want) and np.array_equal(np.float32(off), np.min(p, 0))
     r = p[:, [0, 2, 1]].copy(); r[:, 2] = -r[:, 2]
     want_r = np.round(r - np.min(r, 0)).astype(np.int32)
-    assert np.array_equal(obj_ints(p, "data/mvub/phil9/frame0001.ply", torch.device("cpu")).numpy(), want_r)
+    assert np.array_equal(obj_ints(p, "data/mvub/phil9/frame0001.ply", torch.device("cpu"))[0].numpy(), want_r)
 
 
 def test_host_quantize_equals_the_reference_integers_on_full_frames():
