@@ -410,6 +410,7 @@ def main():
                 "knn_f16x3_wg256_kernel": entry(dom["knn_feat"], note="fused distance + top-20 selection, 256-query workgroups on the XCD-affine schedule; every phase of a wave is latency-bound (DESIGN.md 4.5), L2-miss traffic 2.0 GB per launch"),
                 "knn_mfma_kernel<2,16> (positions)": {"bound": "valu", "launches_per_frame": dom["knn_pos"]["launches"],
                                                       "avg_launch_us": dom["knn_pos"]["avg_launch_us"]}}
+            out["roofline_kernels"] = {k: v for k, v in out["roofline_kernels"].items() if v.get("launches_per_frame", 1)}   # kernels this configuration never launched
             out["roofline_stages"] = {
                 "G": {"bound": "hbm", "achieved": bytes_G / st["geom"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": bytes_G / st["geom"] / 1e9 / HBM_PEAK_GBS, "bytes": bytes_G, "note": "host wall time of the whole stage incl. its small D2H syncs"},
