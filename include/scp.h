@@ -227,6 +227,17 @@ SCP_API int scp_linear_f16x3_scaled(const float *A, int64_t lda, const void *Whi
 /* weight plane [Npad][Kpad] (row-major bf16, scp_split_weight_bf16) -> tiled: 1 KiB blocks ordered [16-row group][32-element k-slab],
  * each block the LDS image of one LDS-DMA instruction (row r at bytes 64 r, its 16-byte chunk q at position q ^ ((r >> 2) & 3)). */
 SCP_API int scp_tile_weight_bf16(const void *plane, int32_t Npad, int32_t Kpad, void *tiled, void *stream);
+/* OctAttention's dense layers on PRE-SPLIT f16 planes (oct_attention.py:48-83, attention_model.py:97-125): scp_split_rows_f16 writes, once
+ * per activation tensor, what scp_linear_f16x3 converts in every tile that reads a row - the power-of-two row scale (largest magnitude
+ * into [2^13, 2^14)), its inverse, and the two IEEE-half planes of the scaled row ([M][ldp], ldp >= K rounded up to 32, ldp % 8 == 0,
+ * padding columns zero; K % 4 == 0, K <= 1024); scp_linear_split_f16 streams those planes by LDS-DMA (weights: scp_split_weight_f16 with
+ * Npad % 256 == 0, then scp_tile_weight_bf16 per plane; act 0 none / 3 ReLU; C = act(A W^T + bias) + residual).  Bit-identical to
+ * scp_linear_f16x3_scaled on the same fp32 rows. */
+SCP_API int scp_split_rows_f16(const float *A, int64_t lda, int32_t M, int32_t K, void *hi, void *lo, int64_t ldp, float *scale, float *inv_scale,
+                               void *stream);
+SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, int64_t lda, const float *a_inv_scale, const void *Whi, const void *Wlo,
+                                 const float *w_inv_scale, int32_t Npad, int32_t Kpad, const float *bias, const float *residual, int64_t ldr,
+                                 float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, void *stream);
 /* The same dense layer with the ACTIVATION pre-split too: A arrives as bf16 planes hi/lo [M][lda] (lda % 8 == 0, lda >= Kpad,
  * columns K..Kpad zero) written by the producing kernel (scp_split_rows, scp_layernorm_rows_split, the attention kernels, or this
  * function's own split output), so operand tiles go global -> LDS by LDS-DMA with no conversion.  Outputs: C fp32 [M][ldc]

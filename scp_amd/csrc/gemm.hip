@@ -361,6 +361,71 @@ extern "C" SCP_API int scp_split_weight_f16(const float *W, int32_t N, int32_t K
     return SCP_OK;
 }
 
+// A [M][lda] fp32 (K % 4 == 0, K <= 1024) -> what the f16x3 kernel would stage for these rows, once, in HBM: scale / inverse scale per
+// row and the two IEEE-half planes of the scaled row ([M][ldp], columns K .. Kp zero) - the operand format of scp_linear_split_f16.
+// Same arithmetic as gemm_bf16x3_kernel<.., true>'s commit (x = a * scale; hi = half(x); lo = half(x - hi)): a layer fed with these
+// planes gives the bits of the layer fed with the fp32 rows.  Four rows per wavefront, all loads in flight before the first reduction.
+template <int NIT>
+__global__ __launch_bounds__(256) void split_rows_f16_kernel(const float *__restrict__ A, int64_t lda, int M, int K, int Kp, _Float16 *__restrict__ hi,
+                                                            _Float16 *__restrict__ lo, int64_t ldp, float *__restrict__ sc, float *__restrict__ isc) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (row0 >= M) return;
+    f32x4 v[NIT][4];
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int k = 4 * lane + 256 * it;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[it][i] = k < K ? *(const f32x4 *)(A + (int64_t)(row0 + i < M ? row0 + i : M - 1) * lda + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            mx[i] = fmaxf(fmaxf(mx[i], fmaxf(fabsf(v[it][i][0]), fabsf(v[it][i][1]))), fmaxf(fabsf(v[it][i][2]), fabsf(v[it][i][3])));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], o));
+        if (row0 + i >= M) continue;
+        float s, is;
+        pow2_scale(mx[i], s, is);
+        if (lane == 0) { sc[row0 + i] = s; isc[row0 + i] = is; }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int k = 4 * lane + 256 * it;
+            if (k >= Kp) continue;
+            f16x4 h4, l4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x = v[it][i][u] * s;
+                const _Float16 hh = (_Float16)x;
+                h4[u] = hh;
+                l4[u] = (_Float16)(x - (float)hh);
+            }
+            *(f16x4 *)(hi + (int64_t)(row0 + i) * ldp + k) = h4;
+            *(f16x4 *)(lo + (int64_t)(row0 + i) * ldp + k) = l4;
+        }
+    }
+}
+
+extern "C" SCP_API int scp_split_rows_f16(const float *A, int64_t lda, int32_t M, int32_t K, void *hi, void *lo, int64_t ldp, float *scale,
+                                          float *inv_scale, void *stream) {
+    const int Kp = (K + 31) & ~31;
+    if (!A || !hi || !lo || !scale || !inv_scale || M <= 0 || K <= 0 || (K & 3) || K > 1024 || (lda & 3) || lda < K || ldp < Kp || (ldp & 7) ||
+        ((uintptr_t)A & 15) || (((uintptr_t)hi | (uintptr_t)lo) & 15))
+        return SCP_EINVAL;
+    const dim3 grid((unsigned)((M + 15) / 16));
+#define GOR(N_) hipLaunchKernelGGL((split_rows_f16_kernel<N_>), grid, dim3(256), 0, (hipStream_t)stream, A, lda, M, K, Kp, (_Float16 *)hi, (_Float16 *)lo, \
+                                   ldp, scale, inv_scale)
+    if (Kp <= 256) GOR(1); else if (Kp <= 512) GOR(2); else if (Kp <= 768) GOR(3); else GOR(4);
+#undef GOR
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
 // row scales of an activation on their own (scale [M], 1 / scale [M]): several layers reading the SAME rows (OctAttention's key / value /
 // query projections of one embedding tensor) share them through scp_linear_f16x3_scaled
 extern "C" SCP_API int scp_row_scale_f16(const float *A, int64_t lda, int32_t M, int32_t K, float *scale, float *inv_scale, void *stream) {

@@ -23,6 +23,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -81,11 +82,16 @@ struct GemmSplitArgs {
     int vec_ok;                                  // fp32 rows of C / residual are 16-byte aligned
     int ncols_out;                               // split output: columns written (N rounded up to 32, <= ldo): zero filled beyond N
     int wtiled;                                  // weight planes in the tiled layout (default) / row-major [Npad][Kpad] (SCP_WTILE=0)
+    const float *a_isc, *w_isc;                  // F16 kernels: inverse power-of-two scale per activation row [M] / weight row [Npad]
 };
 
 // EXT: the epilogue extensions (gathered residual before the activation, scattered output rows) are compiled only into the
 // variant that needs them - as run-time options they cost every dense layer ~12 % (measured)
-template <int WM, int WN, int TM, int ACT, bool EXT>
+// F16: the planes are IEEE half of power-of-two scaled rows (scp_split_rows_f16 / scp_split_weight_f16: 22 significant bits per operand
+// instead of 16), the products run on v_mfma_f32_32x32x16_f16 and the accumulator is multiplied back by the two inverse scales in the
+// epilogue - the arithmetic of gemm_bf16x3_kernel<.., true> (gemm.hip), same products in the same order: bit-identical results, without
+// its fp32 -> plane conversion in every tile that reads a row.  OctAttention's dense layers (models/oct_attention.py).
+template <int WM, int WN, int TM, int ACT, bool EXT, bool F16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmSplitArgs a) {
     constexpr int NW = WM * WN;                            // waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU)
     constexpr int TN = 2;
@@ -193,17 +199,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
             for (int i = 0; i < HM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[p * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ab][i], Bh[bb][j], acc[p * HM + i][j], 0, 0, 0);
+                    acc[p * HM + i][j] = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, Al[ab][i]), __builtin_bit_cast(sf16x8, Bh[bb][j]), acc[p * HM + i][j], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ab][i], Bh[bb][j], acc[p * HM + i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < HM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[p * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ab][i], Bl[bb][j], acc[p * HM + i][j], 0, 0, 0);
+                    acc[p * HM + i][j] = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, Ah[ab][i]), __builtin_bit_cast(sf16x8, Bl[bb][j]), acc[p * HM + i][j], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ab][i], Bl[bb][j], acc[p * HM + i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < HM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[p * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ab][i], Bh[bb][j], acc[p * HM + i][j], 0, 0, 0);
+                    acc[p * HM + i][j] = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, Ah[ab][i]), __builtin_bit_cast(sf16x8, Bh[bb][j]), acc[p * HM + i][j], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ab][i], Bh[bb][j], acc[p * HM + i][j], 0, 0, 0);
         };
 
         SCP_WAIT_DMA(0);
@@ -256,11 +265,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
 
         // ---- epilogue through this wave's private 8 KiB slice of stage 1 ---------------------------------------------------
         float *stg = (float *)(smem + STAGE + w * 8192);
-        float bv[TN];
+        float bv[TN], wsc[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = cn0 + wn * 64 + j * 32 + col;
             bv[j] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+            wsc[j] = F16 ? a.w_isc[n] : 1.f;                       // [Npad]: always in range
         }
         const int c4 = (lane & 15) * 4, rsub = lane >> 4;
         const int nb = cn0 + wn * 64 + c4;
@@ -279,12 +289,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                     rr[it] = *(const f32x4 *)(a.res + rrow * a.ldr + nb);
                 }
             }
+            float ia[16];
+            if (F16) {   // inverse scale of the accumulator registers' rows (powers of two: the two multiplications are exact)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = cm0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    ia[r] = a.a_isc[m < a.M ? m : a.M - 1];
+                }
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ml = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float t0 = acc[i][j][r] + bv[j];
+                    const float t0 = (F16 ? (acc[i][j][r] * ia[r]) * wsc[j] : acc[i][j][r]) + bv[j];
                     stg[ml * 64 + j * 32 + col] = (EXT && a.res_first) ? t0 : apply_act_s<ACT>(t0);
                 }
             if (full) {
@@ -452,6 +470,7 @@ static int linear_split_impl(const void *Ahi, const void *Alo, int64_t lda, cons
         g_num_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     }
     GemmSplitArgs ga;
+    ga.a_isc = nullptr; ga.w_isc = nullptr;
     ga.Ahi = (const __bf16 *)Ahi; ga.Alo = (const __bf16 *)Alo; ga.lda = lda;
     ga.Whi = (const __bf16 *)Whi; ga.Wlo = (const __bf16 *)Wlo; ga.Kpad = Kpad;
     ga.bias = bias; ga.res = residual; ga.ldr = ldr; ga.C = C; ga.ldc = ldc;
@@ -486,6 +505,45 @@ extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_
                                         const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, void *Ohi, void *Olo,
                                         int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream) {
     return linear_split_impl(Ahi, Alo, lda, Whi, Wlo, Npad, Kpad, bias, residual, ldr, nullptr, 0, nullptr, C, ldc, Ohi, Olo, ldo, M, N, K, act, cfg, stream);
+}
+
+// f16x3 form (OctAttention's dense layers, oct_attention.py:48-83 / attention_model.py:97-125): A planes + inverse row scales from
+// scp_split_rows_f16, W planes (tiled) + inverse row scales from scp_split_weight_f16 with Npad % 256 == 0; act: 0 none, 3 ReLU.
+// Bit-identical to scp_linear_f16x3_scaled on the fp32 rows the planes were made from.
+extern "C" SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, int64_t lda, const float *a_inv_scale, const void *Whi, const void *Wlo,
+                                            const float *w_inv_scale, int32_t Npad, int32_t Kpad, const float *bias, const float *residual, int64_t ldr,
+                                            float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, void *stream) {
+    if (!Ahi || !Alo || !a_inv_scale || !Whi || !Wlo || !w_inv_scale || !C || M <= 0 || N <= 0 || K <= 0 || (lda & 7) || Kpad < K || (Kpad & 31) ||
+        lda < Kpad || (Npad & 255) || Npad < N || (act != ACT_NONE && act != ACT_RELU) || ldc < N || (residual && ldr < N) ||
+        (((uintptr_t)Ahi | (uintptr_t)Alo | (uintptr_t)Whi | (uintptr_t)Wlo) & 15) || (((uintptr_t)C | (uintptr_t)residual) & 3))
+        return SCP_EINVAL;
+    if (!g_num_cu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipGetDeviceProperties(&p, dev));
+        g_num_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }
+    GemmSplitArgs ga = {};
+    ga.Ahi = (const __bf16 *)Ahi; ga.Alo = (const __bf16 *)Alo; ga.lda = lda;
+    ga.Whi = (const __bf16 *)Whi; ga.Wlo = (const __bf16 *)Wlo; ga.Kpad = Kpad;
+    ga.bias = bias; ga.res = residual; ga.ldr = ldr; ga.C = C; ga.ldc = ldc; ga.M = M; ga.N = N;
+    ga.a_isc = a_inv_scale; ga.w_isc = w_inv_scale;
+    { static int wt = -1; if (wt < 0) { const char *e = getenv("SCP_WTILE"); wt = (e && e[0] == '0') ? 0 : 1; } ga.wtiled = wt; }
+    ga.vec_ok = !((ldc & 3) || ((uintptr_t)C & 15) || (residual && ((ldr & 3) || ((uintptr_t)residual & 15))));
+    constexpr int STAGE = (256 + 256) * 128, LDS = 2 * STAGE;
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<2, 4, 4, ACT_NONE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<2, 4, 4, ACT_RELU, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        configured = true;
+    }
+    const int64_t ntiles = cdiv64(M, 256) * cdiv64(N, 256);
+    const unsigned grid = (unsigned)(ntiles < g_num_cu ? ntiles : g_num_cu);
+    if (act == ACT_RELU) hipLaunchKernelGGL((gemm_split_kernel<2, 4, 4, ACT_RELU, false, true>), dim3(grid), dim3(512), LDS, (hipStream_t)stream, ga);
+    else hipLaunchKernelGGL((gemm_split_kernel<2, 4, 4, ACT_NONE, false, true>), dim3(grid), dim3(512), LDS, (hipStream_t)stream, ga);
+    LAUNCH_CHECK();
+    return SCP_OK;
 }
 
 // the same with a GATHERED residual added BEFORE the activation: out[m] = act(A[m] . W^T + bias + residual[res_map[m]]).

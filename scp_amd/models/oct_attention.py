@@ -6,6 +6,7 @@ The dual-stream causal attention of attention_model.py:58-95 runs in one HIP ker
 the reference, forward() is a pure function (it does not edit `data` in place, Appendix B-13).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -14,6 +15,9 @@ import torch.nn.functional as F
 from .. import native
 from .. import ops as _ops
 from ..ops import linear as _linear
+
+# SCP_OA_DENSE=rows: the dense layers read fp32 rows and convert them in every tile (round 2; A/B bracket, identical bits)
+PLANES = os.environ.get("SCP_OA_DENSE", "planes") != "rows"
 
 
 def linear(x, w, b=None, act=None, residual=None, scales=None):
@@ -110,17 +114,39 @@ class OctAttention(nn.Module):
         # both streams travel as one [2, B, c, D] tensor (0: known, 1: unknown): every layer they share runs as one launch
         E = torch.stack((torch.cat(parts, 3).reshape(B, c, D), torch.cat(parts_u, 3).reshape(B, c, D))) * math.sqrt(D)
         E = E + self.transformer_encoder.position_enc.pe[:c]
+        # Every dense layer that reads an embedding tensor reads PRE-SPLIT f16 planes (native.SplitActF16: one pass per tensor writes the
+        # row scales and both planes; key / value / query / linear1 / decoder0 then stream them by LDS-DMA - csrc/gemm_split.hip, F16
+        # instantiation - instead of converting fp32 rows in every tile).  Bit-identical to the fp32-row kernel (SCP_OA_DENSE=rows).
+        planes = PLANES and _ops.MODE == "bf16x3"
+        n = B * c
+
+        def lin(a, x, w, b, act=None, residual=None, rows=None, scales=None):
+            if planes:
+                return native.linear_split_f16(a if rows is None else a.rows(*rows), _ops._split16(w), b, _ops._ACT[act], residual)
+            return linear(x, w, b, act=act, residual=residual, scales=scales)
+
         for lyr in self.transformer_encoder.layers:
             a = lyr.attn
-            # the three projections read the same rows: one pass for their power-of-two row scales (the query takes the unknown stream's half)
-            rs = native.RowScales(E.reshape(-1, D)) if (E.is_contiguous() and _ops.MODE == "bf16x3") else None
-            key = linear(E, a.mlp_key.weight, a.mlp_key.bias, scales=rs)
-            val = linear(E, a.mlp_value.weight, a.mlp_value.bias, scales=rs)
-            q_u = linear(E[1], a.mlp_query.weight, a.mlp_query.bias, scales=None if rs is None else rs.rows(B * c, 2 * B * c))
+            E2 = E.reshape(-1, D)
+            if planes:
+                pa, rs, rsq = native.SplitActF16(E2 if E2.is_contiguous() else E2.contiguous()), None, None
+            else:
+                # the three projections read the same rows: one pass for their power-of-two row scales (the query takes the unknown stream's half)
+                pa = None
+                rs = native.RowScales(E2) if (E.is_contiguous() and _ops.MODE == "bf16x3") else None
+                rsq = None if rs is None else rs.rows(n, 2 * n)
+            key = lin(pa, E, a.mlp_key.weight, a.mlp_key.bias, scales=rs).reshape(2, B, c, D)
+            val = lin(pa, E, a.mlp_value.weight, a.mlp_value.bias, scales=rs).reshape(2, B, c, D)
+            q_u = lin(pa, E[1], a.mlp_query.weight, a.mlp_query.bias, rows=(n, 2 * n), scales=rsq).reshape(B, c, D)
             att = torch.empty_like(E)
             native.octattn_attention(q_u, key[0], key[1], val[0], val[1], self.heads, out=att[0], out_u=att[1])
             E = native.layernorm_add(att, E, lyr.norm1.weight, lyr.norm1.bias, 1e-5)          # norm(x + residual), one pass
-            E = native.layernorm_add(linear(linear(E, lyr.linear1.weight, lyr.linear1.bias, act="relu"), lyr.linear2.weight,
-                                            lyr.linear2.bias, residual=E), None, lyr.norm2.weight, lyr.norm2.bias, 1e-5)
+            p1 = native.SplitActF16(E.reshape(-1, D)) if planes else None
+            h1 = lin(p1, E, lyr.linear1.weight, lyr.linear1.bias, act="relu")
+            E = native.layernorm_add(linear(h1, lyr.linear2.weight, lyr.linear2.bias, residual=E.reshape(h1.shape[:-1] + (D,))).reshape(E.shape),
+                                     None, lyr.norm2.weight, lyr.norm2.bias, 1e-5)
         emu = E[1]
+        if planes:
+            d0 = native.linear_split_f16(native.SplitActF16(emu.reshape(-1, D)), _ops._split16(self.decoder0.weight), self.decoder0.bias, native.ACT_RELU)
+            return linear(d0, self.decoder1.weight, self.decoder1.bias).reshape(B, c, -1)
         return linear(linear(emu, self.decoder0.weight, self.decoder0.bias, act="relu"), self.decoder1.weight, self.decoder1.bias)

@@ -57,6 +57,8 @@ def lib():
     i32, i64 = C.c_int32, C.c_int64
     sig = {
         "scp_version": (C.c_int, []),
+        "scp_split_rows_f16": (C.c_int, [_vp, i64, i32, i32, _vp, _vp, i64, _vp, _vp, _vp]),
+        "scp_linear_split_f16": (C.c_int, [_vp, _vp, i64, _vp, _vp, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp]),
         "scp_last_hip_error": (C.c_int, []),
         "scp_device_count": (C.c_int, []),
         "scp_device_name": (C.c_int, [C.c_char_p, C.c_int]),
@@ -610,7 +612,7 @@ class SplitWeightF16:
     def __init__(self, w):
         N, K = w.shape
         self.N, self.K = N, K
-        self.Npad, self.Kpad = -(-N // 128) * 128, -(-K // 32) * 32
+        self.Npad, self.Kpad = -(-N // 256) * 256, -(-K // 32) * 32      # 256: the row tile of scp_linear_split_f16 (128 suffices for scp_linear_f16x3)
         self.hi = torch.empty((self.Npad, self.Kpad), dtype=torch.float16, device=w.device)
         self.lo = torch.empty_like(self.hi)
         self.inv_scale = torch.empty((self.Npad,), dtype=torch.float32, device=w.device)
@@ -639,6 +641,53 @@ class RowScales:
 
     def rows(self, a, b):
         return RowScales(None, self.sc[a:b], self.isc[a:b])
+
+
+class SplitActF16:
+    """An fp32 activation [M, K] as the f16x3 kernels' operand, made ONCE (scp_split_rows_f16): power-of-two row scales (sc, isc) and
+    the IEEE-half planes hi / lo [M, ld] of the scaled rows (ld = K rounded up to 32, padding zero).  `rows(a, b)`: the same for the row
+    range [a, b) (views)."""
+
+    __slots__ = ("hi", "lo", "sc", "isc", "K")
+
+    def __init__(self, x2=None, parts=None):
+        if x2 is not None:
+            M, K = x2.shape
+            ld = -(-K // 32) * 32
+            pl = torch.empty((2, M, ld), dtype=torch.float16, device=x2.device)
+            ws = torch.empty((2, M), dtype=torch.float32, device=x2.device)
+            _check(lib().scp_split_rows_f16(x2.data_ptr(), x2.stride(0), M, K, pl[0].data_ptr(), pl[1].data_ptr(), ld, ws[0].data_ptr(), ws[1].data_ptr(),
+                                            _stream()), "scp_split_rows_f16")
+            parts = (pl[0], pl[1], ws[0], ws[1], K)
+        self.hi, self.lo, self.sc, self.isc, self.K = parts
+
+    @property
+    def M(self):
+        return self.hi.shape[0]
+
+    def rows(self, a, b):
+        return SplitActF16(parts=(self.hi[a:b], self.lo[a:b], self.sc[a:b], self.isc[a:b], self.K))
+
+
+def linear_split_f16(a, sw, bias=None, act=ACT_NONE, residual=None):
+    """act(A W^T + bias) + residual on pre-split f16 planes (SplitActF16 x SplitWeightF16) -> fp32 [M, N]; bit-identical to linear_f16x3
+    on the fp32 rows the planes were made from (csrc/gemm_split.hip, F16 instantiation: operands by LDS-DMA, no conversion in the tile)."""
+    if not sw.tiled_layout and WTILE:
+        raise ScpError("linear_split_f16: weight planes are not tiled")
+    M, N = a.M, sw.N
+    if a.K != sw.K:
+        raise ScpError("linear_split_f16: K mismatch")
+    out = torch.empty((M, N), dtype=torch.float32, device=a.hi.device)
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, N)
+        if r2.stride(1) != 1:
+            r2 = r2.contiguous()
+    rc = lib().scp_linear_split_f16(a.hi.data_ptr(), a.lo.data_ptr(), a.hi.stride(0), a.isc.data_ptr(), sw.hi.data_ptr(), sw.lo.data_ptr(),
+                                    sw.inv_scale.data_ptr(), sw.Npad, sw.Kpad, _opt(bias), None if r2 is None else r2.data_ptr(),
+                                    0 if r2 is None else r2.stride(0), out.data_ptr(), out.stride(0), M, N, sw.K, act, _stream())
+    _check(rc, "scp_linear_split_f16")
+    return out
 
 
 def _rows_f16x3(x, K):

@@ -647,6 +647,52 @@ def test_linear_f16x3_vs_float64(dev, M, N, K, act):
     assert torch.equal(one[0], y[M // 2])
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 255, 600), (7, 16, 32), (300, 600, 300), (1000, 300, 600), (4100, 600, 600), (513, 240, 80), (70000, 600, 600)])
+@pytest.mark.parametrize("act", [None, "relu"])
+def test_linear_split_f16_is_bit_identical_to_the_fp32_row_kernel(dev, M, N, K, act):
+    """OctAttention's dense layers on pre-split f16 planes (scp_split_rows_f16 + scp_linear_split_f16): the planes and row scales
+    are what the fp32-row kernel stages (scp_row_scale_f16 + its in-tile conversion), products and epilogue in the same order, so
+    the result has the SAME BITS - for rows of very different magnitude, zero rows, a residual, ragged M / N, and row ranges taken as
+    views of one plane set (the query projection reads the second half of the stacked streams)."""
+    from scp_amd import native, ops
+    g = torch.Generator().manual_seed(3 * M + N + K)
+    x = torch.randn((M, K), generator=g) * 25.0 * torch.pow(10.0, torch.randint(-6, 7, (M, 1), generator=g).float())
+    if M > 4:
+        x[3] = 0.0
+    w = (torch.randn((N, K), generator=g) / K ** 0.5) * torch.pow(10.0, torch.randint(-3, 4, (N, 1), generator=g).float())
+    b, r = torch.randn(N, generator=g), torch.randn((M, N), generator=g)
+    ops.set_mode("bf16x3")
+    xd, wd, bd, rd = x.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    sw = ops._split16(wd)
+    pa = native.SplitActF16(xd)
+    rs = native.RowScales(xd)
+    assert torch.equal(pa.sc, rs.sc) and torch.equal(pa.isc, rs.isc)
+    a = ops._ACT[act]
+    want = native.linear_f16x3(xd, sw, bd, a, rd, scales=rs)
+    got = native.linear_split_f16(pa, sw, bd, a, rd)
+    assert torch.equal(got, want)
+    assert torch.equal(native.linear_split_f16(pa, sw, None, a), native.linear_f16x3(xd, sw, None, a))
+    if M >= 300:
+        lo, hi = M // 3, M // 3 + 129
+        assert torch.equal(native.linear_split_f16(pa.rows(lo, hi), sw, bd, a), native.linear_f16x3(xd[lo:hi], sw, bd, a))
+
+
+def test_octattn_forward_on_planes_equals_forward_on_rows(dev, octattn):
+    """The model with its dense layers on pre-split planes (default) against SCP_OA_DENSE=rows: identical logits, bit for bit."""
+    from scp_amd.models import oct_attention as oa
+    z = golden(sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_octattn_*.npz")))[-1])
+    data = torch.from_numpy(z["data"].astype(np.int64))[None].to(dev).repeat(3, 1, 1, 1)
+    pos = torch.from_numpy(z["pos"])[None].to(dev).repeat(3, 1, 1, 1)
+    assert oa.PLANES
+    a = octattn(data, pos)
+    try:
+        oa.PLANES = False
+        b = octattn(data, pos)
+    finally:
+        oa.PLANES = True
+    assert torch.equal(a, b)
+
+
 # ----------------------------------------------------------------------------------------------- OctAttention
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_octattn_*.npz"))))
 def test_octattn_logits_vs_reference(dev, octattn, name):
