@@ -235,6 +235,9 @@ SCP_API int scp_tile_weight_bf16(const void *plane, int32_t Npad, int32_t Kpad, 
  * scp_linear_f16x3_scaled on the same fp32 rows. */
 SCP_API int scp_split_rows_f16(const float *A, int64_t lda, int32_t M, int32_t K, void *hi, void *lo, int64_t ldp, float *scale, float *inv_scale,
                                void *stream);
+/* scp_layernorm_add (below) that also writes the f16x3 operand of its output in the same pass - what scp_split_rows_f16 would make of `out` */
+SCP_API int scp_layernorm_add_split_f16(const float *a, const float *b, int64_t rows, int32_t C, const float *gamma, const float *beta, float eps,
+                                        float *out, void *hi, void *lo, int64_t ldp, float *scale, float *inv_scale, void *stream);
 SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, int64_t lda, const float *a_inv_scale, const void *Whi, const void *Wlo,
                                  const float *w_inv_scale, int32_t Npad, int32_t Kpad, const float *bias, const float *residual, int64_t ldr,
                                  float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, void *stream);

@@ -9,6 +9,7 @@
 //                        even/odd token split (ehem.py:113-114) written straight into their slot of the concatenated buffer.
 #include "scp_internal.h"
 
+typedef _Float16 sf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -112,10 +113,15 @@ extern "C" SCP_API int scp_layernorm_rows_split(const float *x, int64_t ldx, int
 
 // LayerNorm(a + b) for any row width C = 4 * NQ (OctAttention: 600; attention_model.py:117,123 `norm(x + residual)`): one wavefront per
 // row, the row's float4 pieces round-robin over the lanes, both operands read once, the sum never written.  b may be null.
-template <int NP>   // float4 pieces per lane (C <= 256 * NP)
+// PLANES: the row also leaves as the f16x3 operand of the dense layers that read it (scp_linear_split_f16): power-of-two row scale of
+// the OUTPUT row, its inverse, and the two IEEE-half planes of the scaled row (columns C .. Cp zero) - what scp_split_rows_f16 would
+// make of `out` in a second pass over it (same arithmetic, same bits).
+template <int NP, bool PLANES = false>   // NP: float4 pieces per lane (C <= 256 * NP)
 __global__ __launch_bounds__(256) void layernorm_add_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t rows, int C,
                                                            const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                                           float *__restrict__ out) {
+                                                           float *__restrict__ out, _Float16 *__restrict__ phi = nullptr,
+                                                           _Float16 *__restrict__ plo = nullptr, int64_t ldp = 0, float *__restrict__ psc = nullptr,
+                                                           float *__restrict__ pisc = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -151,6 +157,33 @@ __global__ __launch_bounds__(256) void layernorm_add_kernel(const float *__restr
 #pragma unroll
             for (int u = 0; u < 4; ++u) y[u] = (v[p][u] - mean) * rstd * g[u] + bb[u];
             *(f32x4 *)(out + r * C + 4 * q) = y;
+            if (PLANES) v[p] = y;
+        }
+    }
+    if (PLANES) {
+        float mx = 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            if (lane + 64 * p < nq) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[p][0]), fabsf(v[p][1]))), fmaxf(fabsf(v[p][2]), fabsf(v[p][3])));
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sc, isc;
+        scp_pow2_scale(mx, sc, isc);
+        if (lane == 0) { psc[r] = sc; pisc[r] = isc; }
+        const int nqp = ((C + 31) & ~31) >> 2;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int q = lane + 64 * p;
+            if (q >= nqp) continue;
+            sf16x4 h4, l4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x = (q < nq ? v[p][u] : 0.f) * sc;
+                const _Float16 hh = (_Float16)x;
+                h4[u] = hh;
+                l4[u] = (_Float16)(x - (float)hh);
+            }
+            *(sf16x4 *)(phi + r * ldp + 4 * q) = h4;
+            *(sf16x4 *)(plo + r * ldp + 4 * q) = l4;
         }
     }
 }
@@ -167,6 +200,26 @@ extern "C" SCP_API int scp_layernorm_add(const float *a, const float *b, int64_t
     else if (C <= 512) hipLaunchKernelGGL(layernorm_add_kernel<2>, dim3(nb), dim3(256), 0, st, a, b, rows, C, gamma, beta, eps, out);
     else if (C <= 768) hipLaunchKernelGGL(layernorm_add_kernel<3>, dim3(nb), dim3(256), 0, st, a, b, rows, C, gamma, beta, eps, out);
     else hipLaunchKernelGGL(layernorm_add_kernel<4>, dim3(nb), dim3(256), 0, st, a, b, rows, C, gamma, beta, eps, out);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+// scp_layernorm_add + the f16x3 operand of its output in the same pass (see layernorm_add_kernel<.., true>): planes [rows][ldp] (ldp >= C
+// rounded up to 32, ldp % 8 == 0), scale / inv_scale [rows].
+extern "C" SCP_API int scp_layernorm_add_split_f16(const float *a, const float *b, int64_t rows, int32_t C, const float *gamma, const float *beta,
+                                                   float eps, float *out, void *hi, void *lo, int64_t ldp, float *scale, float *inv_scale,
+                                                   void *stream) {
+    const int Cp = (C + 31) & ~31;
+    if (!a || !gamma || !beta || !out || !hi || !lo || !scale || !inv_scale || rows < 0 || C <= 0 || (C & 3) || Cp > 1024 || ldp < Cp || (ldp & 7) ||
+        (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)hi | (uintptr_t)lo) & 15))
+        return SCP_EINVAL;
+    if (rows == 0) return SCP_OK;
+    const unsigned nb = (unsigned)cdiv64(rows, 4);
+    hipStream_t st = (hipStream_t)stream;
+#define GOP(NP_) hipLaunchKernelGGL((layernorm_add_kernel<NP_, true>), dim3(nb), dim3(256), 0, st, a, b, rows, C, gamma, beta, eps, out, (_Float16 *)hi, \
+                                    (_Float16 *)lo, ldp, scale, inv_scale)
+    if (Cp <= 256) GOP(1); else if (Cp <= 512) GOP(2); else if (Cp <= 768) GOP(3); else GOP(4);
+#undef GOP
     LAUNCH_CHECK();
     return SCP_OK;
 }

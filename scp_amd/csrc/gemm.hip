@@ -297,16 +297,7 @@ extern "C" SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void
 }
 
 // ---- f16x3: row scales, weight planes, launch ------------------------------------------------------------------------------------
-// power of two that maps a row maximum mx into [2^13, 2^14) (1 for an all-zero or non-finite row; exponent clamped to +-100)
-__device__ __forceinline__ void pow2_scale(float mx, float &sc, float &isc) {
-    int e = 0;
-    if (mx > 0.f && mx < INFINITY) {
-        e = 140 - (int)((__float_as_uint(mx) >> 23) & 0xffu);
-        e = e > 100 ? 100 : (e < -100 ? -100 : e);
-    }
-    sc = __uint_as_float((unsigned)(127 + e) << 23);
-    isc = __uint_as_float((unsigned)(127 - e) << 23);
-}
+#define pow2_scale scp_pow2_scale       // scp_internal.h
 
 // A [M][lda] (K % 4 == 0) -> scale and inverse scale per row.  A wavefront takes four consecutive rows and issues all their loads
 // before it reduces the first (one row per wavefront keeps too few bytes in flight to reach the bandwidth of HBM).

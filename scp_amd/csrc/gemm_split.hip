@@ -531,17 +531,20 @@ extern "C" SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, in
     ga.a_isc = a_inv_scale; ga.w_isc = w_inv_scale;
     { static int wt = -1; if (wt < 0) { const char *e = getenv("SCP_WTILE"); wt = (e && e[0] == '0') ? 0 : 1; } ga.wtiled = wt; }
     ga.vec_ok = !((ldc & 3) || ((uintptr_t)C & 15) || (residual && ((ldr & 3) || ((uintptr_t)residual & 15))));
-    constexpr int STAGE = (256 + 256) * 128, LDS = 2 * STAGE;
+    // 128 x 128 tiles, 4 waves, two workgroups per CU: N = 600 / 300 waste 6 % / 22 % of a 128-wide column tiling where 256-wide tiles
+    // waste 22 % / 41 % (tools/mb_oa_gemm.py: 660 against 711 us at M = 245 760, N = K = 600 with the bf16 planes)
+    constexpr int STAGE = (128 + 128) * 128, BOUNCE = 4 * 8192, LDS = STAGE + (STAGE > BOUNCE ? STAGE : BOUNCE);
     static bool configured = false;
     if (!configured) {
-        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<2, 4, 4, ACT_NONE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<2, 4, 4, ACT_RELU, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<2, 2, 2, ACT_NONE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<2, 2, 2, ACT_RELU, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         configured = true;
     }
-    const int64_t ntiles = cdiv64(M, 256) * cdiv64(N, 256);
-    const unsigned grid = (unsigned)(ntiles < g_num_cu ? ntiles : g_num_cu);
-    if (act == ACT_RELU) hipLaunchKernelGGL((gemm_split_kernel<2, 4, 4, ACT_RELU, false, true>), dim3(grid), dim3(512), LDS, (hipStream_t)stream, ga);
-    else hipLaunchKernelGGL((gemm_split_kernel<2, 4, 4, ACT_NONE, false, true>), dim3(grid), dim3(512), LDS, (hipStream_t)stream, ga);
+    const int64_t ntiles = cdiv64(M, 128) * cdiv64(N, 128);
+    const int64_t slots = 2 * (int64_t)g_num_cu;
+    const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    if (act == ACT_RELU) hipLaunchKernelGGL((gemm_split_kernel<2, 2, 2, ACT_RELU, false, true>), dim3(grid), dim3(256), LDS, (hipStream_t)stream, ga);
+    else hipLaunchKernelGGL((gemm_split_kernel<2, 2, 2, ACT_NONE, false, true>), dim3(grid), dim3(256), LDS, (hipStream_t)stream, ga);
     LAUNCH_CHECK();
     return SCP_OK;
 }

@@ -36,6 +36,18 @@ int scp_ctx_attention_mode();
 // wave (ds_read / ds_write) is drained by lgkmcnt(0); global stores that other waves must see still need __syncthreads().
 #define SCP_BARRIER_DMA(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// f16x3 operands (gemm.hip, gemm_split.hip, fused.hip): the power of two that maps a row maximum mx into [2^13, 2^14) and its inverse
+// (1 for an all-zero or non-finite row; exponent clamped to +-100)
+__device__ __forceinline__ void scp_pow2_scale(float mx, float &sc, float &isc) {
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) {
+        e = 140 - (int)((__float_as_uint(mx) >> 23) & 0xffu);
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    }
+    sc = __uint_as_float((unsigned)(127 + e) << 23);
+    isc = __uint_as_float((unsigned)(127 - e) << 23);
+}
+
 // growable device buffer owned by a handle
 struct DevBuf {
     void *p = nullptr;

@@ -125,28 +125,32 @@ class OctAttention(nn.Module):
                 return native.linear_split_f16(a if rows is None else a.rows(*rows), _ops._split16(w), b, _ops._ACT[act], residual)
             return linear(x, w, b, act=act, residual=residual, scales=scales)
 
+        pa = None                                      # planes of E, when the LayerNorm that produced E wrote them
         for lyr in self.transformer_encoder.layers:
             a = lyr.attn
             E2 = E.reshape(-1, D)
+            rs = rsq = None
             if planes:
-                pa, rs, rsq = native.SplitActF16(E2 if E2.is_contiguous() else E2.contiguous()), None, None
-            else:
+                if pa is None:                         # the embedding stage's output: one standalone pass
+                    pa = native.SplitActF16(E2 if E2.is_contiguous() else E2.contiguous())
+            elif E.is_contiguous() and _ops.MODE == "bf16x3":
                 # the three projections read the same rows: one pass for their power-of-two row scales (the query takes the unknown stream's half)
-                pa = None
-                rs = native.RowScales(E2) if (E.is_contiguous() and _ops.MODE == "bf16x3") else None
-                rsq = None if rs is None else rs.rows(n, 2 * n)
+                rs = native.RowScales(E2)
+                rsq = rs.rows(n, 2 * n)
             key = lin(pa, E, a.mlp_key.weight, a.mlp_key.bias, scales=rs).reshape(2, B, c, D)
             val = lin(pa, E, a.mlp_value.weight, a.mlp_value.bias, scales=rs).reshape(2, B, c, D)
             q_u = lin(pa, E[1], a.mlp_query.weight, a.mlp_query.bias, rows=(n, 2 * n), scales=rsq).reshape(B, c, D)
             att = torch.empty_like(E)
             native.octattn_attention(q_u, key[0], key[1], val[0], val[1], self.heads, out=att[0], out_u=att[1])
-            E = native.layernorm_add(att, E, lyr.norm1.weight, lyr.norm1.bias, 1e-5)          # norm(x + residual), one pass
-            p1 = native.SplitActF16(E.reshape(-1, D)) if planes else None
+            # norm(x + residual) in one pass; with `planes` the same pass writes the f16x3 operand of the layer that reads the result
+            E, p1 = native.layernorm_add(att, E, lyr.norm1.weight, lyr.norm1.bias, 1e-5, planes=True) if planes else \
+                (native.layernorm_add(att, E, lyr.norm1.weight, lyr.norm1.bias, 1e-5), None)
             h1 = lin(p1, E, lyr.linear1.weight, lyr.linear1.bias, act="relu")
-            E = native.layernorm_add(linear(h1, lyr.linear2.weight, lyr.linear2.bias, residual=E.reshape(h1.shape[:-1] + (D,))).reshape(E.shape),
-                                     None, lyr.norm2.weight, lyr.norm2.bias, 1e-5)
+            y2 = linear(h1, lyr.linear2.weight, lyr.linear2.bias, residual=E.reshape(h1.shape[:-1] + (D,))).reshape(E.shape)
+            E, pa = native.layernorm_add(y2, None, lyr.norm2.weight, lyr.norm2.bias, 1e-5, planes=True) if planes else \
+                (native.layernorm_add(y2, None, lyr.norm2.weight, lyr.norm2.bias, 1e-5), None)
         emu = E[1]
         if planes:
-            d0 = native.linear_split_f16(native.SplitActF16(emu.reshape(-1, D)), _ops._split16(self.decoder0.weight), self.decoder0.bias, native.ACT_RELU)
+            d0 = native.linear_split_f16(pa.rows(n, 2 * n), _ops._split16(self.decoder0.weight), self.decoder0.bias, native.ACT_RELU)
             return linear(d0, self.decoder1.weight, self.decoder1.bias).reshape(B, c, -1)
         return linear(linear(emu, self.decoder0.weight, self.decoder0.bias, act="relu"), self.decoder1.weight, self.decoder1.bias)

@@ -87,6 +87,7 @@ def lib():
         "scp_row_scale_f16": (C.c_int, [_vp, i64, i32, i32, _vp, _vp, _vp]),
         "scp_linear_f16x3_scaled": (C.c_int, [_vp, i64, _vp, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp, _vp, _vp]),
         "scp_layernorm_add": (C.c_int, [_vp, _vp, i64, i32, _vp, _vp, C.c_float, _vp, _vp]),
+        "scp_layernorm_add_split_f16": (C.c_int, [_vp, _vp, i64, i32, _vp, _vp, C.c_float, _vp, _vp, _vp, i64, _vp, _vp, _vp]),
         "scp_set_knn_workgroup": (C.c_int, [i32]),
         "scp_knn_debug_buffer": (C.c_int, [_vp]),
         "scp_mlp_debug_buffer": (C.c_int, [_vp]),
@@ -932,12 +933,21 @@ def layernorm_rows(x, gamma, beta, eps=1e-5, valid=None, ia=None, ib=None, out=N
     return out
 
 
-def layernorm_add(a, b, gamma, beta, eps=1e-5):
-    """LayerNorm(a + b) over the last axis (contiguous fp32 tensors of one shape; b may be None) in one kernel."""
+def layernorm_add(a, b, gamma, beta, eps=1e-5, planes=False):
+    """LayerNorm(a + b) over the last axis (contiguous fp32 tensors of one shape; b may be None) in one kernel.  planes=True: returns
+    (out, SplitActF16 of out's rows) - the f16x3 operand of the dense layers that read `out`, written in the same pass."""
     Cc = a.shape[-1]
     if not a.is_contiguous() or (b is not None and (not b.is_contiguous() or b.shape != a.shape)):
         raise ScpError("layernorm_add: contiguous operands of one shape expected")
     out = torch.empty_like(a)
+    if planes:
+        M, ld = a.numel() // Cc, -(-Cc // 32) * 32
+        pl = torch.empty((2, M, ld), dtype=torch.float16, device=a.device)
+        ws = torch.empty((2, M), dtype=torch.float32, device=a.device)
+        _check(lib().scp_layernorm_add_split_f16(_dev(a, torch.float32), None if b is None else _dev(b, torch.float32), M, Cc, _dev(gamma), _dev(beta),
+                                                 float(eps), out.data_ptr(), pl[0].data_ptr(), pl[1].data_ptr(), ld, ws[0].data_ptr(), ws[1].data_ptr(),
+                                                 _stream()), "scp_layernorm_add_split_f16")
+        return out, SplitActF16(parts=(pl[0], pl[1], ws[0], ws[1], Cc))
     _check(lib().scp_layernorm_add(_dev(a, torch.float32), None if b is None else _dev(b, torch.float32), a.numel() // Cc, Cc, _dev(gamma), _dev(beta),
                                    float(eps), out.data_ptr(), _stream()), "scp_layernorm_add")
     return out

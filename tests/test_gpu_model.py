@@ -677,6 +677,25 @@ def test_linear_split_f16_is_bit_identical_to_the_fp32_row_kernel(dev, M, N, K, 
         assert torch.equal(native.linear_split_f16(pa.rows(lo, hi), sw, bd, a), native.linear_f16x3(xd[lo:hi], sw, bd, a))
 
 
+@pytest.mark.parametrize("rows,C", [(1, 600), (37, 600), (5000, 600), (1000, 256), (129, 992), (64, 32)])
+def test_layernorm_add_planes_equal_a_second_pass(dev, rows, C):
+    """scp_layernorm_add_split_f16: the fp32 output is scp_layernorm_add's, and planes / scales are what scp_split_rows_f16 makes of that
+    output (bit for bit, padding columns zero)."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(rows + C)
+    a = (torch.randn((rows, C), generator=g) * torch.pow(10.0, torch.randint(-3, 4, (rows, 1), generator=g).float())).to(dev)
+    b = torch.randn((rows, C), generator=g).to(dev)
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.3 * torch.randn(C, generator=g)).to(dev)
+    for bb in (b, None):
+        want = native.layernorm_add(a, bb, gamma, beta, 1e-5)
+        out, pl = native.layernorm_add(a, bb, gamma, beta, 1e-5, planes=True)
+        ref = native.SplitActF16(want)
+        assert torch.equal(out, want)
+        assert torch.equal(pl.sc, ref.sc) and torch.equal(pl.isc, ref.isc)
+        assert torch.equal(pl.hi.view(torch.int16), ref.hi.view(torch.int16)) and torch.equal(pl.lo.view(torch.int16), ref.lo.view(torch.int16))
+        assert not pl.hi[:, C:].any() and not pl.lo[:, C:].any()
+
+
 def test_octattn_forward_on_planes_equals_forward_on_rows(dev, octattn):
     """The model with its dense layers on pre-split planes (default) against SCP_OA_DENSE=rows: identical logits, bit for bit."""
     from scp_amd.models import oct_attention as oa

@@ -17,6 +17,11 @@ for (M, N, K, act) in [(61440, 600, 600, 0), (122880, 600, 600, 0), (122880, 300
     rs = native.RowScales(a)
     t16s = timeit(lambda: native.linear_f16x3(a, sw16, b, act, scales=rs))
     sa = native.split_rows(a)
+    tsp = timeit(lambda: native.SplitActF16(a))
+    pa = native.SplitActF16(a)
+    tpl = timeit(lambda: native.linear_split_f16(pa, sw16, b, act))
+    trs = timeit(lambda: native.RowScales(a))
+    print(f"   planes: split_rows_f16 {tsp:.0f} us (row scales alone {trs:.0f} us), linear_split_f16 {tpl:.0f} us ({6.0*M*N*K/tpl/1e6:.0f} TF)")
     line = f"M={M} N={N} K={K}: f16x3 {t16:.0f} us ({6.0*M*N*K/t16/1e6:.0f} TF)  given scales {t16s:.0f} us ({6.0*M*N*K/t16s/1e6:.0f} TF)"
     for cfg in (1, 2, 3):
         out = torch.empty((M, N), device=dev)
