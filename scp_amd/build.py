@@ -37,8 +37,13 @@ def build(force=False, verbose=False):
     for s in srcs:
         o = os.path.join(CSRC, "build", os.path.basename(s) + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(s), []) + ["-c", s, "-o", o]
+        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(s), []) + ["-c", s, "-o", o]
+        # the command line is part of an object's identity (SCP_RC_DEFS probe builds must not survive into the next plain build)
+        stamp, line = o + ".cmd", " ".join(cmd)
+        same_cmd = os.path.exists(stamp) and open(stamp).read() == line
+        if force or not same_cmd or _stale(o, [s] + hdrs):
+            with open(stamp, "w") as f:
+                f.write(line)
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((s, subprocess.Popen(cmd)))

@@ -683,31 +683,54 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
     int gstep = 0;
     for (; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * RC_ROWS;
-        const int row = m0 + 32 * L.w + L.col;
-        const int rowc = row < a.M ? row : a.M - 1;
         const bool more = tile + (int)gridDim.x < ntiles;
         rf32x16 Y[8];
         // ---- phase 0: x1 = x + bp + proj(attention rows): four steps of two 32-channel blocks (ONE copy of the step's code; the unrolled
         // form that accumulates straight into Y[2 j], Y[2 j + 1] is 680 instructions longer and no faster).  The residual
         // rows of a step's 64 channels (accumulator layout: channel 32 b + 8 q + 4 h + u) are requested in front of the step - older than
         // its LDS-DMA pieces, so the step's barrier covers them - and added behind it.
-        const float *xsrc = a.x + (int64_t)rowc * a.ldx + 4 * L.h;
+        // The residual rows are fetched COALESCED - an instruction reads 8 rows x one whole 128-byte line (row 8 it + (lane >> 3), chunk
+        // lane & 7 of a 32-channel block) - and turned into the accumulator layout through the wave's bounce buffer behind the step (the
+        // reverse of rc_store_block).  Every lane fetching from its OWN row (32 rows x 32 bytes per instruction, every line touched by
+        // four instructions) cost 10 % of the launch: 31.3 k cycles of phase 0 against 21.2 k with the loads compiled out, and 10 k more in
+        // the MLP phase, whose weight DMA shares the address path; coalesced: 29.2 k and 152 k (2.29 -> 2.22 ms per 590 848 rows).
+        // Measured and dropped: the rows of step j + 1 requested inside step j behind its DMA pieces (barrier with vmcnt(8), two
+        // alternating register sets, phase 0 unrolled by two): the second set pushes the steps into scratch spills - 78 k cycles.
+        const int xrow = m0 + 32 * L.w + (L.lane >> 3);
+        const float *xsrc = a.x + (L.lane & 7) * 4;
         for (int j = 0; j < 4; ++j) {
-            rf32x4 xr[2][4];
+            rf32x4 xc[2][4];
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xr[b][q] = *(const rf32x4 *)(xsrc + 64 * j + 32 * b + 8 * q);
+                for (int it = 0; it < 4; ++it) {
+                    const int r = xrow + 8 * it;
+                    xc[b][it] = *(const rf32x4 *)(xsrc + (int64_t)(r < a.M ? r : a.M - 1) * a.ldx + 64 * j + 32 * b);
+                }
             rf32x16 c0, c1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
             rc_gemm_step<false>(L, smem, gstep & 1, c0, c1, Bh, Bl, A, wr, j < 3 ? src_p(2 * j + 2) : src_1(0), j < 3 ? src_p(2 * j + 3) : src_1(1));
             ++gstep;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const rf32x4 b0 = *(const rf32x4 *)(sbp + 64 * j + 8 * q + 4 * L.h), b1 = *(const rf32x4 *)(sbp + 64 * j + 32 + 8 * q + 4 * L.h);
+            for (int b = 0; b < 2; ++b) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { c0[4 * q + u] += xr[0][q][u] + b0[u]; c1[4 * q + u] += xr[1][q][u] + b1[u]; }
+                for (int it = 0; it < 4; ++it) {
+                    const int rho = 8 * it + (L.lane >> 3), kap = L.lane & 7;
+                    *(rf32x4 *)(bounce + rho * 128 + ((kap ^ (rho & 7)) << 4)) = xc[b][it];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const rf32x4 xq = *(const rf32x4 *)(bounce + L.col * 128 + (((2 * q + L.h) ^ (L.col & 7)) << 4));
+                    const rf32x4 bq = *(const rf32x4 *)(sbp + 64 * j + 32 * b + 8 * q + 4 * L.h);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (b == 0) c0[4 * q + u] += xq[u] + bq[u];
+                        else c1[4 * q + u] += xq[u] + bq[u];
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer is free for the next block
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             switch (j) {
@@ -803,7 +826,9 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
 #pragma unroll
             for (int t = 0; t < 2; ++t) { Hh[0][t] = Hnh[t]; Hl[0][t] = Hnl[t]; }
         }
-        // body 30: no P1 left; GELU(31).  The fragment registers are free: the next tile's attention rows are requested here
+        // body 30: no P1 left; GELU(31).  The fragment registers are free: the next tile's attention rows are requested here.  (They cost 7 k
+        // cycles per tile - probe without them: MLP phase 144.8 k against 151.9 k.  Requested INSIDE the step behind its DMA pieces, one per
+        // MFMA gap of slices 8 - 15 with the barrier leaving them in flight, they cost 7.5 k more: 159.4 k.)
         load_bias(31);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         {

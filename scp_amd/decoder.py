@@ -104,8 +104,10 @@ def decode_file(binfile, model, lidar_level=None, data_type=None, mullevel=False
     with open(binfile, "rb") as f:
         stream = f.read()
     shells = dec.decode(stream, n_levels, pos_mm)
+    # KITTI / Ford: the reference decoder's own rule (steps from the integer bin_num in float64, decode_ehem.py:237-249) - the cloud it
+    # would write.  obj: there is no rule (the offset is the frame's per-axis minimum): the sidecar's `quant` entry, or nothing.
     quant = side.get("quant") if side is not None else None
-    if quant is not None and len(quant) == len(shells):
+    if data_type == "obj" and quant is not None and len(quant) == len(shells):
         from . import metrics
         pts = [metrics.dequantize(lv, qd["qs"], qd["offset"], spher=spher, cylin=cylin) for (_, lv), qd in zip(shells, quant)]
     elif data_type == "obj":
