@@ -665,15 +665,40 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
             for (int plane = 0; plane < 2; ++plane) { rc_dma_piece(L, wr, s0, smem, q, plane); rc_dma_piece(L, wr, s1, smem + RC_SLOT, q, plane); }
     }
     rbf16x8 Bh[16], Bl[16];                                         // attention rows during phase 0, normalised rows afterwards
-    auto orow = [&](int t) {
-        const int r = t * RC_ROWS + 32 * L.w + L.col;
-        return (int64_t)(r < a.M ? r : a.M - 1) * a.ldo_in + 8 * L.h;
-    };
-    {
-        const int64_t o = orow(tile);
+    // The attention rows of a tile are fetched COALESCED like the residual rows (see phase 0): raw chunk [4 p + it] = row 8 it + (lane >> 3),
+    // 16-byte chunk lane & 7 of the row's 128-byte line p (k-steps 4 p .. 4 p + 3), and turned into B fragments (lane = row, k = 16 s + 8 h
+    // + i: chunk 2 (s & 3) + h of line s >> 2) through the bounce buffer once the tile before is stored: eight passes of 4 writes + 4 reads.
+    auto load_o = [&](int t) {
+        const int r0 = t * RC_ROWS + 32 * L.w + (L.lane >> 3);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) { Bh[s] = *(const rbf16x8 *)(a.Ohi + o + 16 * s); Bl[s] = *(const rbf16x8 *)(a.Olo + o + 16 * s); }
-    }
+        for (int it = 0; it < 4; ++it) {
+            const int r = r0 + 8 * it;
+            const int64_t o = (int64_t)(r < a.M ? r : a.M - 1) * a.ldo_in + (L.lane & 7) * 8;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) { Bh[4 * pp + it] = *(const rbf16x8 *)(a.Ohi + o + 64 * pp); Bl[4 * pp + it] = *(const rbf16x8 *)(a.Olo + o + 64 * pp); }
+        }
+    };
+    auto transpose_o = [&]() {
+#pragma unroll
+        for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rho = 8 * it + (L.lane >> 3), kap = L.lane & 7;
+                    *(rbf16x8 *)(bounce + rho * 128 + ((kap ^ (rho & 7)) << 4)) = plane ? Bl[4 * pp + it] : Bh[4 * pp + it];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const rbf16x8 fr = *(const rbf16x8 *)(bounce + L.col * 128 + (((2 * q + L.h) ^ (L.col & 7)) << 4));
+                    if (plane) Bl[4 * pp + q] = fr; else Bh[4 * pp + q] = fr;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+    };
+    load_o(tile);
+    transpose_o();
     rbf16x8 A[2][4];
     {
         SCP_BARRIER_DMA(0);
@@ -831,11 +856,7 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
         // MFMA gap of slices 8 - 15 with the barrier leaving them in flight, they cost 7.5 k more: 159.4 k.)
         load_bias(31);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        {
-            const int64_t o = orow(more ? tile + (int)gridDim.x : tile);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) { Bh[s] = *(const rbf16x8 *)(a.Ohi + o + 16 * s); Bl[s] = *(const rbf16x8 *)(a.Olo + o + 16 * s); }
-        }
+        load_o(more ? tile + (int)gridDim.x : tile);
         rc_body_step<false, true, 0>(L, smem, gstep & 1, Y, a1[0], a1[1], bg, Hh[0], Hl[0], Hnh, Hnl, Bh, Bl, A, wr, src_2(31), src_2(31));
         ++gstep;
         // body 31: P2 only; the step after it is phase 0 of the next tile
@@ -857,6 +878,7 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
                 for (int u = 0; u < 4; ++u) o[q][u] = Y[b][4 * q + u];
             rc_store_block(L, bounce, o, rs, ldc_bytes, voff, 32 * b);
         }
+        transpose_o();                                             // the next tile's attention rows (requested in front of body 30) -> B fragments
         stamp(t_epi);
         ++n_tiles;
     }
