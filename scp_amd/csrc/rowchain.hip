@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
     const int wbytes = ((a.N + 255) & ~255) * 512;                  // one weight plane: [Npad][256] bf16
     const __amdgpu_buffer_rsrc_t wr_hi = __builtin_amdgcn_make_buffer_rsrc((void *)a.Whi, 0, wbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr_lo = __builtin_amdgcn_make_buffer_rsrc((void *)a.Wlo, 0, wbytes, 0x00020000);
-    unsigned long long t_bar = 0, t_step = 0, t_ln = 0, t_drain = 0, t_prev = 0, n_tiles = 0;
+    unsigned long long t_step = 0, t_ln = 0, t_drain = 0, t_prev = 0, n_tiles = 0;
     unsigned long long tsl[5] = {0, 0, 0, 0, 0};
     const bool DBG = a.dbg != nullptr;
     if (DBG) t_prev = __builtin_amdgcn_s_memtime();
