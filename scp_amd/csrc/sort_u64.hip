@@ -27,14 +27,21 @@ __global__ __launch_bounds__(WG) void radix_hist_kernel(const uint64_t *__restri
     counts[(int64_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
 }
 
-// exclusive scan of `m` uint32 counters, single workgroup of 1024 threads
+// exclusive scan of `m` uint32 counters (16-byte aligned), single workgroup of 1024 threads.  A thread owns a run of
+// counters whose length is a multiple of 4 and walks it with 16-byte loads / stores, all loads of a pass in flight together (the scalar
+// walk - one dependent 4-byte access after the other - took 38 us for the 30 k counters of a four-frame build, 8 us for one frame's).
+// VEC = false: any alignment, one counter at a time.
+template <bool VEC>
 __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *__restrict__ counts, int64_t m) {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
-    const int64_t chunk = (m + 1023) / 1024;
+    const int64_t chunk = VEC ? ((((m + 1023) / 1024) + 3) & ~(int64_t)3) : (m + 1023) / 1024;
     const int64_t b = (int64_t)t * chunk, e = (b + chunk < m) ? b + chunk : m;
+    uint4 *c4 = (uint4 *)counts;
     uint32_t s = 0;
-    for (int64_t i = b; i < e; ++i) s += counts[i];
+    const int64_t ev = VEC ? b + ((e - b) & ~(int64_t)3) : b;      // whole groups of four; the (last thread's) remainder one by one
+    for (int64_t i = b; i < ev; i += 4) { const uint4 v = c4[i >> 2]; s += (v.x + v.y) + (v.z + v.w); }
+    for (int64_t i = ev > b ? ev : b; i < e; ++i) s += counts[i];
     part[t] = s;
     __syncthreads();
     // Hillis-Steele inclusive scan over 1024 partials
@@ -45,11 +52,14 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *__restrict__
         __syncthreads();
     }
     uint32_t run = part[t] - s;
-    for (int64_t i = b; i < e; ++i) {
-        uint32_t c = counts[i];
-        counts[i] = run;
-        run += c;
+    for (int64_t i = b; i < ev; i += 4) {
+        const uint4 v = c4[i >> 2];
+        uint4 o;
+        o.x = run; o.y = run + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
+        run = o.w + v.w;
+        c4[i >> 2] = o;
     }
+    for (int64_t i = ev > b ? ev : b; i < e; ++i) { const uint32_t c = counts[i]; counts[i] = run; run += c; }
 }
 
 __global__ __launch_bounds__(WG) void radix_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
@@ -110,7 +120,8 @@ __global__ __launch_bounds__(WG) void radix_scatter_kernel(const uint64_t *__res
 }
 
 void scp_launch_scan_u32(uint32_t *counts, int64_t m, hipStream_t st) {
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, counts, m);
+    if ((uintptr_t)counts & 15) hipLaunchKernelGGL(radix_scan_kernel<false>, dim3(1), dim3(1024), 0, st, counts, m);
+    else hipLaunchKernelGGL(radix_scan_kernel<true>, dim3(1), dim3(1024), 0, st, counts, m);
 }
 
 int scp_radix_sort_u64(uint64_t *keys_a, uint64_t *keys_b, int64_t n, const int *pass_lo, const int *pass_bits,
@@ -127,7 +138,7 @@ int scp_radix_sort_u64(uint64_t *keys_a, uint64_t *keys_b, int64_t n, const int 
         if (nb < 1 || nb > 8) return SCP_EINVAL;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(WG), 0, st, src, n, lo, (1u << nb) - 1u, counts, ntiles);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, counts, (int64_t)256 * ntiles);
+        scp_launch_scan_u32(counts, (int64_t)256 * ntiles, st);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(WG), 0, st, src, dst, n, lo, nb, counts, ntiles);
         LAUNCH_CHECK();

@@ -4,11 +4,14 @@ Bytes per call are the algorithmic reads + writes of the kernel at the L16 --sph
 577 515 nodes)."""
 import csv, sys
 f, nf = sys.argv[1], int(sys.argv[2])
-P, S, N = 120000, 3, 577515
-K = P * S
+# optional: points per frame, shells per frame, nodes per frame, frames per scp_geom_build call (round 3: batched L12 frames)
+P, S, N, FB = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (120000, 3, 577515, 1)
+K = P * S * FB          # keys per build
+N = N * FB              # nodes per build
+nf = nf / FB            # builds
 B = {   # kernel name fragment -> (bytes per call, what moves)
-    "transform_kernel": (24 * P, "xyz f32 in, (rho, phi, theta) f32 out, one shell"),
-    "quantize_kernel": (24 * P, "f32 in, int32 out, one shell"),
+    "transform_kernel": (24 * P, "xyz f32 in, (rho, phi, theta) f32 out, one shell of one frame"),
+    "quantize_kernel": (24 * P, "f32 in, int32 out, one shell of one frame"),
     "seg_minmax_kernel": (12 * K, "int32 coordinates in"),
     "morton_key_kernel": (20 * K, "int32 x3 in, 64-bit key out, all shells"),
     "radix_hist_kernel": (8 * K, "keys in (digit histogram)"),
@@ -17,7 +20,7 @@ B = {   # kernel name fragment -> (bytes per call, what moves)
     "tree_segrank_kernel": (8 * K, "sorted keys in"),
     "tree_write_kernel": (8 * K + 22 * N, "sorted keys in, node tables out"),
     "tree_occ_kernel": (10 * N, "octant / parent in, occupancy out"),
-    "ctx_ehem_kernel": (int(37 * N / S), "ancestor gathers in, 12 B context + 12 B position + 1 B symbol out, one shell"),
+    "ctx_ehem_kernel": (int(37 * N / (S * FB)), "ancestor gathers in, 12 B context + 12 B position + 1 B symbol out, one segment"),
 }
 rows = list(csv.DictReader(open(f)))
 print("| kernel | calls / frame | avg µs | algorithmic MB / call | achieved GB/s | moves |")
@@ -38,7 +41,7 @@ if scan:
     print(f"| `radix_scan_kernel` | {calls:.0f} | {us:.1f} | (256 x blocks counters) | - | exclusive scan of the digit counters: latency-bound, not bandwidth |")
     tot_t += us * calls
 print()
-print(f"Sum over the listed kernels: {tot_t / 1e3:.2f} ms of kernel time per frame, {tot_b / 1e6:.0f} MB moved = {tot_b / tot_t / 1e3:.0f} GB/s "
-      f"({100 * tot_b / tot_t / 1e3 / 8000:.1f} % of 8 TB/s).  A 120 k-point frame is 1.4 MB: every pass moves 3-6 MB in 5-15 µs, i.e. the "
-      "stage is bound by launch and DRAM latency, not by bandwidth; the passes reach ~450 GB/s each.  SURVEY.md 8d's algorithmic "
-      f"figure for the whole stage is 12 P + 25 N = {(12 * P + 25 * N) / 1e6:.1f} MB per frame.")
+unit = "build of %d frames" % FB if FB > 1 else "frame"
+print(f"Sum over the listed kernels: {tot_t / 1e3:.2f} ms of kernel time per {unit}, {tot_b / 1e6:.0f} MB moved = {tot_b / tot_t / 1e3:.0f} GB/s "
+      f"({100 * tot_b / tot_t / 1e3 / 8000:.1f} % of 8 TB/s).  SURVEY.md 8d's algorithmic figure for the whole stage is 12 P + 25 N = "
+      f"{(12 * P * S * FB + 25 * N) / 1e6:.1f} MB per {unit}.")
