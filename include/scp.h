@@ -414,6 +414,25 @@ SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int64_t ldo_in,
                                const float *b1, const float *b2, float eps, float *out, int64_t ldc, int32_t M, void *stream);
 SCP_API int64_t scp_swin_post_attn_weight_bytes(void);
 
+/* Keys and values handed from the projection to the window attention as bf16 hi / lo PLANES in the layout of the attention kernel's own
+ * LDS tiles (swin_transformer.py:443-501; round 3).  planes: [4][Tp][256] bf16 = K hi, K lo, V^T hi, V^T lo for Tp rows of the packed
+ * layout (Tp % 32 == 0; windows of 512 rows):
+ *   K   [row][4 heads][64 d], the eight 16-byte chunks of a head's 128 bytes at position chunk ^ (row & 7);
+ *   V^T [32-row block][head][32 super-rows of 128 B]: head dim d, 8-key chunk c at super-row d >> 1, slot ((d & 1) * 4 + c) ^ ((d >> 1) & 7),
+ *       the block's keys in the order p = 16 c' + 8 h + j  <->  key 16 c' + 4 h + (j & 3) + 8 (j >> 2).
+ * The attention kernel copies whole 1 KiB pieces of them into LDS by LDS-DMA: no conversion, no staging registers.
+ *   scp_swin_kv_planes              : fp32 k, v [rows][ldkv] -> planes (a plain conversion pass; rows % 32 == 0)
+ *   scp_swin_ln_qkv                 : scp_swin_ln_linear for N = 768 (query | key | value; q fp32 [M][ldq]) or N = 512 (key | value, q NULL)
+ *                                     writing the key / value heads as planes straight from the accumulators (M % 128 == 0, Tp >= M)
+ *   scp_swin_attention_packed_planes: scp_swin_attention_packed(_split) on (q fp32, planes); out fp32 [rows][256] or ohi / olo planes
+ * All three give the bits of the fp32 hand-over (scp_swin_ln_linear + scp_swin_attention_packed). */
+SCP_API int scp_swin_kv_planes(const float *k, const float *v, int64_t ldkv, int64_t rows, void *khi, void *klo, void *vthi, void *vtlo, void *stream);
+SCP_API int scp_swin_ln_qkv(const float *x, int64_t ldx, const float *valid, const void *Whi, const void *Wlo, const float *bias, const float *wbeta,
+                            float eps, float *q, int64_t ldq, void *planes, int64_t Tp, int32_t M, int32_t N, void *stream);
+SCP_API int scp_swin_attention_packed_planes(const float *q, const void *khi, const void *klo, const void *vthi, const void *vtlo,
+                                             const float *bias_table, const int32_t *wtab, int32_t total_windows, int32_t shift, int32_t ldq,
+                                             float *out, void *ohi, void *olo, int64_t ldo, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -387,6 +387,221 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bf16x3_kernel(const float *_
     }
 }
 
+// ================================================================================================================
+// The same bf16x3 attention with K and V arriving as bf16 hi / lo PLANES in the layout of its own LDS tiles, staged by LDS-DMA: no
+// conversion, no staging registers, no ds_write in this kernel.  32-key tiles, two stages (4 planes x 4 KiB each), ONE barrier per tile:
+//   K planes  [token][4 heads][64 d] bf16, the eight 16-byte chunks of a head's 128 bytes stored at position chunk ^ (token & 7);
+//   V^T planes [32-token block][head][32 super-rows of 128 B]: head dim d, key chunk c (8 keys, 16 B) at super-row d >> 1, slot
+//             ((d & 1) * 4 + c) ^ ((d >> 1) & 7); the 32 keys of a block in the order p = 16 c' + 8 h + j  <->  key 16 c' + 4 h + (j & 3) +
+//             8 (j >> 2) (bits 2 and 3 of the key index swapped: the 8 keys of a lane's P fragment are contiguous).
+// Both are linear images of the LDS tiles, so a DMA instruction copies 1 KiB as it lies.  Same products in the same order as
+// swin_attn_bf16x3_kernel: identical bits.  (scp_swin_kv_planes writes the planes from fp32 k / v.)
+typedef __attribute__((address_space(3))) void *attn_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *attn_glb_ptr_t;
+#define PKT 32          // keys per tile
+#define PST 16384       // bytes per stage: K hi | K lo | V hi | V lo, 4 KiB each
+
+__global__ __launch_bounds__(256, 3) void swin_attn_planes_kernel(const float *__restrict__ q, const __bf16 *__restrict__ khi, const __bf16 *__restrict__ klo,
+                                                                 const __bf16 *__restrict__ vthi, const __bf16 *__restrict__ vtlo,
+                                                                 const float *__restrict__ table, int shift, int ldq, float *__restrict__ out,
+                                                                 const int *__restrict__ wtab, __bf16 *__restrict__ ohi, __bf16 *__restrict__ olo, int64_t ldo) {
+    __shared__ __attribute__((aligned(1024))) char stg[2 * PST];
+    __shared__ float tab[2 * WIN - 1];
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+    const int qtile = bid & 3; bid >>= 2;
+    const int head = bid & 3; bid >>= 2;
+    const size_t seq_row = (size_t)wtab[2 * bid];
+    const int Lp = wtab[2 * bid + 1], nW = Lp / WIN;
+    const int wnd = (int)(((size_t)bid * WIN - seq_row) / WIN);
+    const size_t base = seq_row * (NH * HD) + head * HD;
+    const size_t qbase = seq_row * ldq + head * HD;
+    const bool masked = (shift > 0) && (wnd == nW - 1);
+    constexpr float LOG2E = 1.4426950408889634f;
+    for (int i = tid; i < 2 * WIN - 1; i += 256) tab[i] = table[i * NH + head] * LOG2E;
+
+    const int qi = qtile * QT + w * 32 + col;
+    auto wrap = [&](int t) { return t >= Lp ? t - Lp : t; };
+    const int qtok = wrap(wnd * WIN + qi + shift);
+    bf16x8 qh[4], ql[4];
+    {
+        const float *src = q + qbase + (size_t)qtok * ldq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 a = *(const float4 *)(src + 16 * c + 8 * h), b = *(const float4 *)(src + 16 * c + 8 * h + 4);
+            const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = f[j] * (0.125f * LOG2E);
+                const __bf16 hh = (__bf16)x;
+                qh[c][j] = hh;
+                ql[c][j] = (__bf16)(x - (float)hh);
+            }
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const int qreg = qi >> 8;
+
+    // wave w copies plane w of a tile (K hi, K lo, V hi, V lo): four 1 KiB DMA instructions
+    const __bf16 *kpl = (w & 1) ? klo : khi, *vpl = (w & 1) ? vtlo : vthi;
+    auto issue = [&](int t, int st) {
+        const int tok0 = wrap(wnd * WIN + t * PKT + shift);                 // a multiple of 32: the tile is 32 consecutive tokens
+        char *dst = stg + st * PST + w * 4096;
+        if (w < 2) {
+            const char *src = (const char *)(kpl + (seq_row + tok0 + (lane >> 3)) * (size_t)(NH * HD) + head * HD) + (lane & 7) * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((attn_glb_ptr_t)(src + (size_t)i * 8 * NH * HD * 2), (attn_lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+        } else {
+            const char *src = (const char *)(vpl + (((seq_row + tok0) >> 5) * NH + head) * (size_t)2048) + lane * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((attn_glb_ptr_t)(src + i * 1024), (attn_lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    __syncthreads();                                                        // the bias table
+    for (int t = 0; t < WIN / PKT; ++t) {
+        SCP_BARRIER_DMA(0);                                                 // tile t has landed; everybody is done with the other stage
+        if (t + 1 < WIN / PKT) issue(t + 1, (t + 1) & 1);
+        const char *S = stg + (t & 1) * PST;
+        const float madd = (masked && ((t * PKT) >> 8) != qreg) ? -100.f * LOG2E : 0.f;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ko = col * 128 + (((2 * c + h) ^ (col & 7)) << 4);
+            const bf16x8 ah = *(const bf16x8 *)(S + ko), al = *(const bf16x8 *)(S + 4096 + ko);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[c], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[c], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[c], s, 0, 0, 0);
+        }
+        const int j0 = t * PKT + 4 * h;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2);
+            s[r] = s[r] + tab[qi - j + (WIN - 1)];
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) + madd;
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float msub = m_new - madd;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - msub); ps += s[r]; }
+        ps += __shfl_xor(ps, 32);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+        if (__any(alpha != 1.f)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bf16x8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = s[8 * c + j];
+                const __bf16 hh = (__bf16)x;
+                ph[j] = hh;
+                pl[j] = (__bf16)(x - (float)hh);
+            }
+            // head dim d = col (o0) / col + 32 (o1), key chunk 2 c + h: super-row d >> 1, slot ((d & 1) * 4 + chunk) ^ ((d >> 1) & 7)
+            const int R0 = col >> 1, R1 = R0 + 16, sl = (col & 1) * 4 + 2 * c + h;
+            const int v0 = R0 * 128 + ((sl ^ (R0 & 7)) << 4), v1 = R1 * 128 + ((sl ^ (R1 & 7)) << 4);
+            const bf16x8 v0h = *(const bf16x8 *)(S + 8192 + v0), v0l = *(const bf16x8 *)(S + 12288 + v0);
+            const bf16x8 v1h = *(const bf16x8 *)(S + 8192 + v1), v1l = *(const bf16x8 *)(S + 12288 + v1);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0l, ph, o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0h, pl, o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0h, ph, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1l, ph, o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1h, pl, o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1h, ph, o1, 0, 0, 0);
+        }
+    }
+    const float inv = 1.0f / l_run;
+    if (ohi) {
+        const size_t o = (seq_row + (size_t)qtok) * (size_t)ldo + head * HD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 8 * g + 4 * h;
+            store_split4(ohi + o + d, olo + o + d, o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            store_split4(ohi + o + 32 + d, olo + o + 32 + d, o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+        return;
+    }
+    float *dst = out + base + (size_t)qtok * (NH * HD);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int d = 8 * g + 4 * h;
+        *(float4 *)(dst + d) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        *(float4 *)(dst + 32 + d) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+}
+
+// fp32 k, v [rows][ldkv] (4 heads x 64) -> the four planes of swin_attn_planes_kernel (rows % 32 == 0: whole 32-token blocks).  One
+// thread per (row, head, 8 head dims): K as one swizzled 16-byte chunk per plane, V^T as eight 2-byte elements per plane.
+__global__ __launch_bounds__(256) void kv_planes_kernel(const float *__restrict__ k, const float *__restrict__ v, int64_t ldkv, int64_t rows,
+                                                       __bf16 *__restrict__ khi, __bf16 *__restrict__ klo, __bf16 *__restrict__ vthi,
+                                                       __bf16 *__restrict__ vtlo) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= rows * 32) return;
+    const int64_t row = g >> 5;
+    const int head = (int)(g >> 3) & 3, ch = (int)g & 7;
+    const float *ks = k + row * ldkv + head * HD + 8 * ch, *vs = v + row * ldkv + head * HD + 8 * ch;
+    const float4 a = *(const float4 *)ks, b = *(const float4 *)(ks + 4), c = *(const float4 *)vs, d = *(const float4 *)(vs + 4);
+    const float kf[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, vf[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    bf16x8 kh, kl;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const __bf16 hh = (__bf16)kf[u]; kh[u] = hh; kl[u] = (__bf16)(kf[u] - (float)hh); }
+    const int64_t ko = row * (NH * HD) + head * HD + ((ch ^ (int)(row & 7)) << 3);
+    *(bf16x8 *)(khi + ko) = kh;
+    *(bf16x8 *)(klo + ko) = kl;
+    const int kk = (int)(row & 31), p = (kk & ~12) | ((kk & 4) << 1) | ((kk & 8) >> 1);       // bits 2 and 3 swapped
+    const int64_t vb = ((row >> 5) * NH + head) * (int64_t)2048;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int dd = 8 * ch + u, R = dd >> 1, sl = (dd & 1) * 4 + (p >> 3);
+        const int64_t vo = vb + R * 64 + ((sl ^ (R & 7)) << 3) + (p & 7);
+        const __bf16 hh = (__bf16)vf[u];
+        vthi[vo] = hh;
+        vtlo[vo] = (__bf16)(vf[u] - (float)hh);
+    }
+}
+
+extern "C" SCP_API int scp_swin_kv_planes(const float *k, const float *v, int64_t ldkv, int64_t rows, void *khi, void *klo, void *vthi, void *vtlo,
+                                          void *stream) {
+    if (!k || !v || !khi || !klo || !vthi || !vtlo || rows <= 0 || (rows & 31) || ldkv < NH * HD || (ldkv & 3) ||
+        (((uintptr_t)k | (uintptr_t)v | (uintptr_t)khi | (uintptr_t)klo | (uintptr_t)vthi | (uintptr_t)vtlo) & 15))
+        return SCP_EINVAL;
+    hipLaunchKernelGGL(kv_planes_kernel, dim3((unsigned)cdiv64(rows * 32, 256)), dim3(256), 0, (hipStream_t)stream, k, v, ldkv, rows, (__bf16 *)khi,
+                       (__bf16 *)klo, (__bf16 *)vthi, (__bf16 *)vtlo);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+// packed window attention on those planes (q fp32 [rows][ldq]); out fp32 [rows][256] or (ohi, olo) planes [rows][ldo]
+extern "C" SCP_API int scp_swin_attention_packed_planes(const float *q, const void *khi, const void *klo, const void *vthi, const void *vtlo,
+                                                        const float *bias_table, const int32_t *wtab, int32_t total_windows, int32_t shift, int32_t ldq,
+                                                        float *out, void *ohi, void *olo, int64_t ldo, void *stream) {
+    if (!q || !khi || !klo || !vthi || !vtlo || !bias_table || !wtab || (!out && !ohi) || total_windows <= 0 || (shift != 0 && shift != WIN / 2) ||
+        ldq < NH * HD || (ldq & 3) || (((uintptr_t)q | (uintptr_t)out | (uintptr_t)khi | (uintptr_t)klo | (uintptr_t)vthi | (uintptr_t)vtlo) & 15) ||
+        (ohi && (!olo || ldo < NH * HD || (ldo & 3) || (((uintptr_t)ohi | (uintptr_t)olo) & 7))))
+        return SCP_EINVAL;
+    hipLaunchKernelGGL(swin_attn_planes_kernel, dim3(total_windows * NH * (WIN / QT)), dim3(256), 0, (hipStream_t)stream, q, (const __bf16 *)khi,
+                       (const __bf16 *)klo, (const __bf16 *)vthi, (const __bf16 *)vtlo, bias_table, shift, ldq, out, wtab, (__bf16 *)ohi, (__bf16 *)olo, ldo);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
 static int g_attn_mode = -1;   // 0 = fp32 MFMA, 1 = bf16x3 (default); SCP_ATTN=f32 selects the former
 static inline bool attn_bf16x3() {
     const int c = scp_ctx_attention_mode();      // the calling thread's current scp_ctx decides; without one, the process default

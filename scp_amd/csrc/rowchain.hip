@@ -55,6 +55,7 @@ __device__ __forceinline__ void rc_dma16(const void *g, char *l) {
 typedef float rf32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 rbf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned ru32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned ru32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned rc_pack2(float a, float b) {
     const rf32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rbf16x2));
@@ -193,6 +194,10 @@ struct RcLnLinArgs {
     float eps;
     int probe;                              // timing probes (tools/mb_rowchain_probe.py, SCP_RC_PROBE; RESULTS ARE WRONG): 1 stores dropped, 2 no DMA, 8 no bounce / stores
     unsigned long long *dbg;                // diagnostic stamps (scp_rc_debug_buffer): per wave [barrier waits, steps, LayerNorm, drain, tiles]
+    // rc_ln_linear_kernel<., KV = true> (scp_swin_ln_qkv): the first nq steps (64 channels each) are the query, written to `out` as above;
+    // the next four are the key heads, the last four the value heads, written as bf16 hi / lo planes in the layout of the plane-fed
+    // attention (csrc/attn.hip: swin_attn_planes_kernel): planes = [4][Tp][256] bf16 = K hi, K lo, V^T hi, V^T lo; plane_bytes = Tp * 512
+    __bf16 *planes; int64_t plane_bytes; int nq;
 };
 
 #define RC_DS_WRITE(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(val), "n"(off) : "memory")
@@ -221,12 +226,16 @@ struct RcLnLinArgs {
 #ifndef RC_STORE_AUX
 #define RC_STORE_AUX 0              // cache policy of the output stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
-template <bool LOADX, int PROBE>
+// SWAP (the value steps of rc_ln_linear_kernel<., KV>): the operands change places - A = the wave's rows, B = the weight fragment (the
+// two fragment layouts are the same registers) - so the accumulator holds C[row][channel]: lane = CHANNEL, register r = row 8 (r >> 2) +
+// 4 h + (r & 3), which is the order V^T tiles are stored in; same products, same k order, same values.  NSWAP: the NEXT step is such a
+// step, its accumulators start from b[channel] (rows the window pads: b alone, others b + W beta; maskh = the rows' valid bits >> 4 h).
+template <bool LOADX, int PROBE, bool SWAP = false, bool NSWAP = false>
 __device__ __forceinline__ void rc_ll_step(const RcLane &L, const RcLnLinArgs &a, char *smem, int half, rf32x16 &c0, rf32x16 &c1,
                                            rf32x16 &p0, rf32x16 &p1, const rbf16x8 (&Xh)[16], const rbf16x8 (&Xl)[16], int g_next,
                                            __amdgpu_buffer_rsrc_t rs_prev, int voff, int ldo_bytes, int ch0_prev, const unsigned (&bw)[4],
                                            unsigned br, const float *xsrc, float (&v)[128], rbf16x8 (&A)[2][4], const float *tb_next, unsigned long long *st,
-                                           __amdgpu_buffer_rsrc_t wr_hi, __amdgpu_buffer_rsrc_t wr_lo) {
+                                           __amdgpu_buffer_rsrc_t wr_hi, __amdgpu_buffer_rsrc_t wr_lo, const float *sbn = nullptr, unsigned maskh = 0) {
     const unsigned ab = (unsigned)(uintptr_t)(rc_lds_ptr_t)(smem + half * (2 * RC_SLOT)) + L.rg * 8192;
     const unsigned ad0 = ab + L.frag, ad1 = ab + (L.frag ^ 32);
     const unsigned an0 = (unsigned)(uintptr_t)(rc_lds_ptr_t)(smem + (half ^ 1) * (2 * RC_SLOT)) + L.rg * 8192 + L.frag;   // k-step 0 of the next step
@@ -253,12 +262,14 @@ __device__ __forceinline__ void rc_ll_step(const RcLane &L, const RcLnLinArgs &a
             // k-step were requested one per gap of the slice before, in the order their first MFMA needs them: before each of the first
             // four MFMAs the oldest outstanding read is the one it needs - a whole slice old - and the three younger ones stay in flight
             if (gap < 4) { RC_FRAG_WAIT(); RC_SB; }
-            if (gap == 0) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][1], Xh[s], c0, 0, 0, 0);
-            if (gap == 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][3], Xh[s], c1, 0, 0, 0);
-            if (gap == 2) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0], Xl[s], c0, 0, 0, 0);
-            if (gap == 3) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][2], Xl[s], c1, 0, 0, 0);
-            if (gap == 4) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][0], Xh[s], c0, 0, 0, 0);
-            if (gap == 5) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s & 1][2], Xh[s], c1, 0, 0, 0);
+#define RC_LL_MFMA(c, wf, xf) c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, wf, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, c, 0, 0, 0)
+            if (gap == 0) RC_LL_MFMA(c0, A[s & 1][1], Xh[s]);
+            if (gap == 1) RC_LL_MFMA(c1, A[s & 1][3], Xh[s]);
+            if (gap == 2) RC_LL_MFMA(c0, A[s & 1][0], Xl[s]);
+            if (gap == 3) RC_LL_MFMA(c1, A[s & 1][2], Xl[s]);
+            if (gap == 4) RC_LL_MFMA(c0, A[s & 1][0], Xh[s]);
+            if (gap == 5) RC_LL_MFMA(c1, A[s & 1][2], Xh[s]);
+#undef RC_LL_MFMA
             RC_SB;
             // ---- what rides in the gap behind it ----------------------------------------------------------------------------------------
             if (gap < 4 && s < 15) {                                // a fragment of the next k-step, in the order of use: lo 0, lo 1, hi 0, hi 1
@@ -293,7 +304,13 @@ __device__ __forceinline__ void rc_ll_step(const RcLane &L, const RcLnLinArgs &a
                     for (int u = 0; u < 4; ++u) { v[8 * t + u] = q0[u]; v[8 * t + 4 + u] = q1[u]; }
                 }
             }
-            if (s == 14 && gap >= 4) {                              // the previous results are out: those registers become the next
+            if (NSWAP && s == 14 && gap >= 4) {                     // a value step comes next: lane = channel, register = row
+                const float bb = sbn[32 * (gap - 4)], bwv = sbn[32 * (gap - 4) + 1024];
+                rf32x16 &pp = (gap == 4) ? p0 : p1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pp[r] = ((maskh >> (8 * (r >> 2) + (r & 3))) & 1u) ? bwv : bb;
+            }
+            if (!NSWAP && s == 14 && gap >= 4) {                    // the previous results are out: those registers become the next
 #pragma unroll                                                      // step's accumulators and start from its bias
                 for (int q = 2 * (gap - 4); q < 2 * (gap - 4) + 2; ++q) {
                     const rf32x4 b0 = *(const rf32x4 *)(tb_next + 8 * q), b1 = *(const rf32x4 *)(tb_next + 32 + 8 * q);
@@ -308,7 +325,7 @@ __device__ __forceinline__ void rc_ll_step(const RcLane &L, const RcLnLinArgs &a
     if (st) { const unsigned long long t = __builtin_amdgcn_s_memtime(); st[4] += t - ts0; }
 }
 
-template <int PROBE>
+template <int PROBE, bool KV = false>
 __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const RcLane L = rc_lane();
@@ -330,6 +347,8 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
     const int ldo_bytes = (int)(a.ldo * 4);
     const int voff = (32 * L.w + (L.lane >> 3)) * ldo_bytes + (L.lane & 7) * 16;
     const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0, 0x00020000);   // every store out of range: dropped
+    const int pbytes = (int)a.plane_bytes;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void *)a.planes, 0, KV ? (int)(4 * a.plane_bytes) : 0, 0x00020000);
 
     const int wbytes = ((a.N + 255) & ~255) * 512;                  // one weight plane: [Npad][256] bf16
     const __amdgpu_buffer_rsrc_t wr_hi = __builtin_amdgcn_make_buffer_rsrc((void *)a.Whi, 0, wbytes, 0x00020000);
@@ -398,6 +417,7 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
 #pragma unroll
             for (int u = 0; u < 4; ++u) { acc[0][0][4 * q + u] = b0[u]; acc[0][1][4 * q + u] = b1[u]; }
         }
+        if (!KV) {
         for (int j = 0; j < nsteps; j += 2) {
             // step j -> acc[0], stores acc[1] (step j - 1); step j + 1 -> acc[1], stores acc[0]
             if (j + 2 == nsteps)
@@ -422,6 +442,101 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
 #pragma unroll
                 for (int u = 0; u < 4; ++u) o[q][u] = acc[1][blk][4 * q + u];
             rc_store_block(L, bounce, o, rs, ldo_bytes, voff, 64 * (nsteps - 1) + 32 * blk);
+        }
+        } else {
+        // ---- query | key | value (or key | value) with the keys and values leaving as attention planes --------------------------------------
+        // Roles come in runs of an even number of steps (nq in {0, 4}, four key heads, four value heads), so a pair of steps never
+        // straddles two roles.  Query steps store through the deferred epilogue of the step behind them as above; a key or value head is
+        // written out right behind its step - both planes through the bounce buffer back to back (a wave's LDS operations execute in order:
+        // no wait between the write of one plane, its read-back and the write of the next) - and the step behind it then stores nothing
+        // (rs_none).  Measured and dropped: the key / value epilogue dealt into the gaps of the next step like the query's (nine
+        // instantiations of the step in one kernel: the register allocator parks row fragments in AGPRs and copies them back - 230
+        // v_accvgpr moves and 70 scratch accesses in a value step - 1.14 against 0.93 ms per 590 848 rows).
+        const int nq = a.nq;
+        const unsigned kmask = (unsigned)__builtin_amdgcn_ballot_w64(keep != 0.f);      // valid bits of the wave's 32 rows (lanes 0 - 31)
+        const unsigned maskh = kmask >> (4 * L.h);
+        const float *sbl = sb + L.col;                               // + 64 j (+ 32): b of the lane's channel; + 1024: b + W beta
+        const int kvoff = (m0 + 32 * L.w + (L.lane >> 3)) * 512 + (L.lane & 7) * 16;     // key planes: row 8 it + (lane >> 3), chunk lane & 7
+        const int vblk = ((m0 >> 5) + L.w) * 4;                      // value planes: this wave's 32-token block, head 0
+        auto split_pair = [&](float x0, float x1, int plane) {
+            const unsigned hh = rc_pack2(x0, x1);
+            return plane ? rc_pack2(x0 - __builtin_bit_cast(float, hh << 16), x1 - __builtin_bit_cast(float, hh & 0xffff0000u)) : hh;
+        };
+        auto store_k = [&](const rf32x16 &c0, const rf32x16 &c1, int head) {
+            ri32x4 y[2][4];
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const rf32x16 &c = b ? c1 : c0;
+                        *(ru32x2 *)(bounce + L.col * 128 + (((4 * b + q) ^ (L.col & 7)) << 4) + 8 * L.h) =
+                            (ru32x2){split_pair(c[4 * q], c[4 * q + 1], plane), split_pair(c[4 * q + 2], c[4 * q + 3], plane)};
+                    }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) y[plane][it] = *(const ri32x4 *)(bounce + it * 1024 + L.lane * 16);
+            }
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    __builtin_amdgcn_raw_buffer_store_b128(y[plane][it], prs, kvoff, it * 8 * 512 + head * 128 + plane * pbytes, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        auto store_v = [&](const rf32x16 &c0, const rf32x16 &c1, int head) {
+            ri32x4 y[2][4];
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const rf32x16 &c = b ? c1 : c0;
+                        const int d = L.col + 32 * b, R = d >> 1, sl = (d & 1) * 4 + 2 * cc + L.h;
+                        *(ru32x4 *)(bounce + R * 128 + ((sl ^ (R & 7)) << 4)) =
+                            (ru32x4){split_pair(c[8 * cc], c[8 * cc + 1], plane), split_pair(c[8 * cc + 2], c[8 * cc + 3], plane),
+                                     split_pair(c[8 * cc + 4], c[8 * cc + 5], plane), split_pair(c[8 * cc + 6], c[8 * cc + 7], plane)};
+                    }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) y[plane][it] = *(const ri32x4 *)(bounce + it * 1024 + L.lane * 16);
+            }
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    __builtin_amdgcn_raw_buffer_store_b128(y[plane][it], prs, L.lane * 16, it * 1024 + (vblk + head) * 4096 + (2 + plane) * pbytes, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        auto role = [&](int j) { return j < nq ? 0 : (j < nq + 4 ? 1 : 2); };                     // 0 query, 1 key, 2 value
+        auto post = [&](int j, const rf32x16 &c0, const rf32x16 &c1) {
+            const int r = role(j);
+            if (r == 1) store_k(c0, c1, j - nq);
+            else if (r == 2) store_v(c0, c1, j - nq - 4);
+        };
+        for (int j = 0; j < nsteps; j += 2) {
+            // step j -> acc[0], step j + 1 -> acc[1]; a query step's results are stored by the step behind it
+            const bool val = role(j) == 2, nval = role(j + 2 < nsteps ? j + 2 : 0) == 2;
+            const __amdgpu_buffer_rsrc_t rsa = (j && role(j - 1) == 0) ? rs : rs_none, rsb = role(j) == 0 ? rs : rs_none;
+            const int gn = (j + 2 < nsteps) ? 2 * (j + 2) : 0;
+            const float *tbn = tb + 64 * ((j + 2 < nsteps) ? j + 2 : 0), *sbn1 = sbl + 64 * (j + 1), *sbn2 = sbl + 64 * ((j + 2 < nsteps) ? j + 2 : 0);
+#define RC_STEP_A(LX, SW) rc_ll_step<LX, PROBE, SW, SW>(L, a, smem, gstep & 1, acc[0][0], acc[0][1], acc[1][0], acc[1][1], Xh, Xl, 2 * (j + 1), rsa, voff, ldo_bytes, \
+                                                64 * (j - 1), bw, br0, xnext, v, A, tb + 64 * (j + 1), DBG ? tsl : nullptr, wr_hi, wr_lo, sbn1, maskh)
+#define RC_STEP_B(SW, NSW) rc_ll_step<false, PROBE, SW, NSW>(L, a, smem, gstep & 1, acc[1][0], acc[1][1], acc[0][0], acc[0][1], Xh, Xl, gn, rsb, voff, ldo_bytes, 64 * j, bw, \
+                                                     br0, xnext, v, A, tbn, DBG ? tsl : nullptr, wr_hi, wr_lo, sbn2, maskh)
+            if (!val) RC_STEP_A(false, false);
+            else if (j + 2 == nsteps) RC_STEP_A(true, true);
+            else RC_STEP_A(false, true);
+            ++gstep;
+            post(j, acc[0][0], acc[0][1]);
+            if (!val) { if (nval) RC_STEP_B(false, true); else RC_STEP_B(false, false); }
+            else { if (nval) RC_STEP_B(true, true); else RC_STEP_B(true, false); }
+            ++gstep;
+            post(j + 1, acc[1][0], acc[1][1]);
+#undef RC_STEP_A
+#undef RC_STEP_B
+        }
+        stamp(t_step);
         }
         stamp(t_drain);
         ++n_tiles;
@@ -923,12 +1038,38 @@ extern "C" SCP_API int scp_swin_ln_linear(const float *x, int64_t ldx, const flo
     RcLnLinArgs a;
     a.x = x; a.ldx = ldx; a.valid = valid; a.Whi = (const __bf16 *)Whi; a.Wlo = (const __bf16 *)Wlo; a.bias = bias; a.wbeta = wbeta;
     a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.eps = eps;
+    a.planes = nullptr; a.plane_bytes = 0; a.nq = 0;
     { static int pr = -1; if (pr < 0) { const char *e = getenv("SCP_RC_PROBE"); pr = e ? atoi(e) : 0; } a.probe = pr; }
     if (a.probe) { const char *e = getenv("SCP_RC_PROBE"); a.probe = e ? atoi(e) : 0; }
     a.dbg = g_rc_dbg;
     const int ntiles = (M + RC_ROWS - 1) / RC_ROWS;
     const int ncu = rc_num_cu();
     hipLaunchKernelGGL(rc_ln_linear_kernel<0>, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+// scp_swin_ln_linear for the query | key | value projection of a Swin block (N = 768) or the key | value projection of a cross layer
+// (N = 512) with the keys and values leaving as the bf16 hi / lo planes of the plane-fed window attention (scp_swin_attention_packed_planes):
+// q: fp32 [M][ldq] (N = 768 only), planes: [4][Tp][256] bf16 (K hi, K lo, V^T hi, V^T lo; Tp >= M rows, Tp % 32 == 0).  M % 128 == 0 (rows of
+// the packed layout come in 512s).  The planes hold the bits scp_swin_kv_planes makes of scp_swin_ln_linear's fp32 k and v.
+extern "C" SCP_API int scp_swin_ln_qkv(const float *x, int64_t ldx, const float *valid, const void *Whi, const void *Wlo, const float *bias,
+                                       const float *wbeta, float eps, float *q, int64_t ldq, void *planes, int64_t Tp, int32_t M, int32_t N, void *stream) {
+    if (!x || !Whi || !Wlo || !planes || M <= 0 || (M & 127) || (N != 768 && N != 512) || (N == 768 && (!q || ldq < 256 || (ldq & 3))) || ldx < 256 ||
+        (ldx & 3) || Tp < M || (Tp & 31) || (((uintptr_t)x | (uintptr_t)q | (uintptr_t)Whi | (uintptr_t)Wlo | (uintptr_t)planes) & 15) ||
+        (q && (int64_t)RC_ROWS * ldq * 4 > 0x7fffffffLL) || 4 * Tp * 512 > 0x7fffffffLL)
+        return SCP_EINVAL;
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void *)rc_ln_linear_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
+        configured = true;
+    }
+    RcLnLinArgs a;
+    a.x = x; a.ldx = ldx; a.valid = valid; a.Whi = (const __bf16 *)Whi; a.Wlo = (const __bf16 *)Wlo; a.bias = bias; a.wbeta = wbeta;
+    a.out = q; a.ldo = q ? ldq : 256; a.M = M; a.N = N; a.eps = eps; a.probe = 0; a.dbg = nullptr;
+    a.planes = (__bf16 *)planes; a.plane_bytes = Tp * 512; a.nq = N / 64 - 8;
+    const int ntiles = M / RC_ROWS, ncu = rc_num_cu();
+    hipLaunchKernelGGL((rc_ln_linear_kernel<0, true>), dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;
 }

@@ -144,6 +144,9 @@ FUSED_MLP = __import__('os').environ.get('SCP_MLP', 'fused') != 'split'   # SCP_
 # fused MLP); default: the row-chain kernels of csrc/rowchain.hip - LayerNorm + q|k|v in one launch, everything behind the attention in
 # another (11 KB of HBM traffic per row and block instead of 17 + 3.6 of re-reads)
 ROWCHAIN = __import__('os').environ.get('SCP_SWIN', 'rowchain') != 'split'
+# SCP_ATTN_KV=rows: keys / values go from the projection to the attention kernel as fp32 rows (round 3a - 3f); planes: as bf16 hi / lo
+# planes in the layout of the attention kernel's LDS tiles (bit-identical results)
+KV_PLANES = __import__('os').environ.get('SCP_ATTN_KV', 'planes') != 'rows'
 
 
 def _rowchain_weights(layer, cross):
@@ -173,6 +176,15 @@ def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None):
     w = _rowchain_weights(layer, cross)
     lnb = layer.layernorm_before
     v1 = None if valid is None else valid.reshape(-1)
+    if KV_PLANES and native.attention_bf16x3():
+        # keys and values leave the projection as the bf16 planes the attention kernel stages by LDS-DMA (identical bits to the fp32 hand-over)
+        if not cross:
+            q, kvp = native.swin_ln_qkv(x, w["kv"], w["b"], lnb.eps, v1)
+        else:
+            q = native.swin_ln_linear(query, w["q"], att.query.bias, lnb.eps, v1)
+            _, kvp = native.swin_ln_qkv(x, w["kv"], w["b"], lnb.eps, v1)
+        o = native.swin_attention_packed_planes(q, kvp, att.relative_position_bias_table, wtab, shift, split=True)
+        return native.swin_post_attn(o, x, w["post"], layer.layernorm_after.eps)
     if not cross:
         qkv = native.swin_ln_linear(x, w["kv"], w["b"], lnb.eps, v1)
         q, k, v = qkv[:, :256], qkv[:, 256:512], qkv[:, 512:]

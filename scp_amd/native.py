@@ -57,6 +57,9 @@ def lib():
     i32, i64 = C.c_int32, C.c_int64
     sig = {
         "scp_version": (C.c_int, []),
+        "scp_swin_ln_qkv": (C.c_int, [_vp, i64, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, _vp, i64, i32, i32, _vp]),
+        "scp_swin_kv_planes": (C.c_int, [_vp, _vp, i64, i64, _vp, _vp, _vp, _vp, _vp]),
+        "scp_swin_attention_packed_planes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, i32, i32, i32, _vp, _vp, _vp, i64, _vp]),
         "scp_split_rows_f16": (C.c_int, [_vp, i64, i32, i32, _vp, _vp, i64, _vp, _vp, _vp]),
         "scp_linear_split_f16": (C.c_int, [_vp, _vp, i64, _vp, _vp, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp]),
         "scp_last_hip_error": (C.c_int, []),
@@ -313,6 +316,41 @@ def swin_attention_packed(q, k, v, bias_table, wtab, shift, split=False):
     return out
 
 
+class KvPlanes:
+    """k, v fp32 [T, 256] views (T % 512 == 0 rows of the packed layout) as the bf16 hi / lo planes of the plane-fed window attention
+    (csrc/attn.hip: swin_attn_planes_kernel): K [T, 256] with swizzled 16-byte chunks, V^T per (32-token block, head) as the linear image
+    of the kernel's LDS tile.  `t`: bfloat16 [4, T, 256] = K hi, K lo, V^T hi, V^T lo."""
+
+    __slots__ = ("t",)
+
+    def __init__(self, k=None, v=None, t=None):
+        if t is None:
+            T = k.shape[0]
+            t = torch.empty((4, T, 256), dtype=torch.bfloat16, device=k.device)
+            _check(lib().scp_swin_kv_planes(k.data_ptr(), v.data_ptr(), k.stride(0), T, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                            t[3].data_ptr(), _stream()), "scp_swin_kv_planes")
+        self.t = t
+
+
+def swin_attention_packed_planes(q, kv, bias_table, wtab, shift, split=False):
+    """swin_attention_packed with K / V as KvPlanes: operands staged by LDS-DMA, no conversion in the kernel; identical bits."""
+    T = q.shape[0]
+    p = kv.t
+    if split:
+        o = SplitAct.empty(T, 256, q.device)
+        rc = lib().scp_swin_attention_packed_planes(q.data_ptr(), p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr(), p[3].data_ptr(),
+                                                    _dev(bias_table, torch.float32), _dev(wtab, torch.int32), T // 512, shift, q.stride(0), None,
+                                                    o.t[0].data_ptr(), o.t[1].data_ptr(), o.t.stride(1), _stream())
+        _check(rc, "scp_swin_attention_packed_planes")
+        return o
+    out = torch.empty((T, 256), dtype=torch.float32, device=q.device)
+    rc = lib().scp_swin_attention_packed_planes(q.data_ptr(), p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr(), p[3].data_ptr(),
+                                                _dev(bias_table, torch.float32), _dev(wtab, torch.int32), T // 512, shift, q.stride(0), _dev(out), None,
+                                                None, 0, _stream())
+    _check(rc, "scp_swin_attention_packed_planes")
+    return out
+
+
 def nn_sqdist(a, b):
     """a [na,3], b [nb,3] float64 device tensors -> float64 [na]: squared distance of every a to its nearest b (exhaustive)."""
     a = _dev_f64(a)
@@ -451,6 +489,12 @@ class use_profile:
         _TLS.profile = self.prev
         lib().scp_ctx_make_current(self.prev._h if self.prev is not None else None)
         return False
+
+
+def attention_bf16x3():
+    """Whether the window attention of the calling thread runs its bf16x3 form (its current profile, or the process default)."""
+    p = current_profile()
+    return (_MODES["attn"] == "bf16x3") if p is None else p.attention_bf16x3
 
 
 def numeric_profile(model_name, profile="current"):
@@ -862,6 +906,21 @@ def swin_ln_linear(x, fw, bias, eps=1e-5, valid=None, out=None):
                                   _opt(bias), _dev(fw.wbeta), float(eps), out.data_ptr(), out.stride(0), M, fw.N, _stream())
     _check(rc, "scp_swin_ln_linear")
     return out
+
+
+def swin_ln_qkv(x, fw, bias, eps=1e-5, valid=None):
+    """swin_ln_linear for a query | key | value (fw.N = 768) or key | value (512) projection whose keys and values leave as the planes of the
+    plane-fed window attention: -> (q fp32 [M, 256] or None, KvPlanes).  M % 512 == 0 (rows of the packed layout)."""
+    M = x.shape[0]
+    if x.shape[1] != 256 or fw.K != 256 or x.stride(1) != 1 or fw.N not in (512, 768) or (M & 127):
+        raise ScpError("swin_ln_qkv: 256-channel rows in multiples of 128, N = 768 or 512 expected")
+    q = torch.empty((M, 256), dtype=torch.float32, device=x.device) if fw.N == 768 else None
+    pl = torch.empty((4, M, 256), dtype=torch.bfloat16, device=x.device)
+    t = fw.planes
+    rc = lib().scp_swin_ln_qkv(x.data_ptr(), x.stride(0), None if valid is None else _dev(valid, torch.float32), t[0].data_ptr(), t[1].data_ptr(),
+                               _opt(bias), _dev(fw.wbeta), float(eps), None if q is None else q.data_ptr(), 256, pl.data_ptr(), M, M, fw.N, _stream())
+    _check(rc, "scp_swin_ln_qkv")
+    return q, KvPlanes(t=pl)
 
 
 def rc_perm16(n, device):

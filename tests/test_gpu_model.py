@@ -610,6 +610,26 @@ def test_packed_forward_equals_per_window_forward(dev, ehem):
     assert worst < 2e-4, worst
 
 
+def test_packed_forward_on_kv_planes_equals_forward_on_fp32_rows(dev, ehem):
+    """The packed forward with keys / values handed to the attention as planes (default) against SCP_ATTN_KV=rows: identical logits,
+    bit for bit (self- and cross-attention layers, shifted and unshifted windows, pad rows)."""
+    from scp_amd.models import packed
+    z = golden("logits_ehem_c1024")
+    data = torch.from_numpy(z["data"].astype(np.int64)).to(dev)
+    pos = torch.from_numpy(z["pos"]).to(dev)
+    lengths = [1, 7, 2, 300, 513, 1, 200]
+    ctx = data.reshape(1024, 12).to(torch.uint8)
+    p = pos.T.contiguous()
+    assert packed.KV_PLANES
+    ev, od = ehem.forward_packed(ctx, p, lengths)
+    try:
+        packed.KV_PLANES = False
+        ev2, od2 = ehem.forward_packed(ctx, p, lengths)
+    finally:
+        packed.KV_PLANES = True
+    assert torch.equal(ev, ev2) and torch.equal(od, od2)
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 255, 600), (7, 16, 32), (300, 600, 300), (1000, 300, 600), (4100, 255, 512), (513, 240, 80)])
 @pytest.mark.parametrize("act", [None, "relu"])
 def test_linear_f16x3_vs_float64(dev, M, N, K, act):
@@ -1055,6 +1075,53 @@ def test_swin_ln_linear_vs_float64(dev, M, N):
     assert (y2.double() - F.layer_norm(x.double(), (256,), gamma.double(), beta.double(), 1e-5) @ W.double().T).abs().max().item() < 1e-4
     k = max(1, M // 3)
     assert torch.equal(native.swin_ln_linear(x[:k].contiguous(), fw, b, 1e-5, valid[:k].contiguous()), y[:k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N", [(512, 768), (512, 512), (1536, 768), (70144, 768), (70144, 512)])
+def test_swin_ln_qkv_planes_are_the_split_of_the_fp32_projection(dev, M, N):
+    """scp_swin_ln_qkv (keys / values leave the LayerNorm + projection kernel as the attention's bf16 planes, value heads computed with the
+    MFMA operands swapped so that the accumulator IS a V^T tile): q and every plane bit-identical to scp_swin_ln_linear's fp32 output
+    converted by scp_swin_kv_planes - with a valid mask, several tiles per CU, and the key | value form of the cross layers."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn((M, 256), generator=g) * 1.5 + 0.3).to(dev)
+    gamma, beta = (1 + 0.1 * torch.randn(256, generator=g)).to(dev), (0.1 * torch.randn(256, generator=g)).to(dev)
+    valid = (torch.rand(M, generator=g) > 0.1).float().to(dev)
+    W, b = (torch.randn((N, 256), generator=g) * 0.05).to(dev), (torch.randn(N, generator=g) * 0.1).to(dev)
+    fw = native.LnFoldedWeight(W, gamma, beta)
+    for vm in (valid, None):
+        ref = native.swin_ln_linear(x, fw, b, 1e-5, vm)
+        nq = N - 512
+        want = native.KvPlanes(ref[:, nq:nq + 256], ref[:, nq + 256:])
+        q, kv = native.swin_ln_qkv(x, fw, b, 1e-5, vm)
+        assert (q is None) == (N == 512)
+        if q is not None:
+            assert torch.equal(q, ref[:, :256].contiguous())
+        assert torch.equal(kv.t.view(torch.int16), want.t.view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [0, 256])
+def test_plane_fed_attention_is_bit_identical_to_the_fp32_fed_kernel(dev, shift):
+    """scp_swin_attention_packed_planes (K / V tiles staged by LDS-DMA from pre-split planes, 32-key tiles, one barrier per tile) against
+    scp_swin_attention_packed: same products in the same order - identical output, fp32 and split form, sequences of 1 - 3 windows."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(shift + 3)
+    lens = [1, 2, 3, 1, 2]
+    T = sum(lens) * 512
+    qkv = (torch.randn((T, 768), generator=g) * 2.0).to(dev)
+    table = (torch.randn((1023, 4), generator=g) * 0.5).to(dev)
+    rows, base = [], 0
+    for n in lens:
+        rows += [[base, n * 512]] * n
+        base += n * 512
+    wtab = torch.tensor(rows, dtype=torch.int32, device=dev)
+    q, k, v = qkv[:, :256], qkv[:, 256:512], qkv[:, 512:]
+    kv = native.KvPlanes(k, v)
+    assert torch.equal(native.swin_attention_packed_planes(q, kv, table, wtab, shift), native.swin_attention_packed(q, k, v, table, wtab, shift))
+    a, b = native.swin_attention_packed_planes(q, kv, table, wtab, shift, split=True), native.swin_attention_packed(q, k, v, table, wtab, shift, split=True)
+    assert torch.equal(a.t.view(torch.int16), b.t.view(torch.int16))
 
 
 @pytest.mark.gpu

@@ -4,7 +4,8 @@
 The row-chain kernels read their weight fragments with inline-asm ds_read_b128 and wait for them with hand-counted s_waitcnt
 lgkmcnt(N).  The compiler regards an asm output as valid as soon as the statement ends: if it moves, copies or spills such a register
 before the wait, it moves stale bytes (seen once: a v_accvgpr_write right behind the read, errors of 1e-4 that came and went with
-unrelated edits).  This scan replays the LDS queue of the instruction stream - every ds_read_b128 into VGPRs enters it, every
+unrelated edits).  This scan replays the LDS queue of the instruction stream - every ds_read enters it with its destination, every ds_write without one
+(lgkmcnt counts both, in order), every
 s_waitcnt lgkmcnt(N) retires all but the N youngest entries - and reports every instruction that touches the destination of a read
 still in the queue.  tests/test_rowchain_isa.py runs it on every kernel of the file."""
 import re, sys
@@ -18,9 +19,12 @@ def regs(tok):
 pending = []   # list of (regset, line_no, order)
 bad = 0
 for i, l in enumerate(lines):
-    if l.startswith('ds_read_b128'):
-        dst = l.split()[1].rstrip(',')
+    if l.startswith('ds_read'):                                  # every LDS operation takes a place in the in-order lgkm queue:
+        dst = l.split()[1].rstrip(',')                           # reads with the registers they fill, writes with none
         pending.append((regs(dst), i))
+        continue
+    if l.startswith('ds_write'):
+        pending.append((set(), i))
         continue
     m = re.match(r's_waitcnt.*lgkmcnt\((\d+)\)', l)
     if m:
