@@ -92,6 +92,7 @@ def measure_dominant_kernel(enc, xyz_dev):
 
     o_lin, o_att, o_knn, o_mlp = native.linear_split, native.swin_attention_packed, native.knn_topk_packed, native.mlp_split_fused
     o_post, o_lnlin = native.swin_post_attn, native.swin_ln_linear
+    o_attp, o_lnqkv = native.swin_attention_packed_planes, native.swin_ln_qkv
 
     def post(o, x, pw, *args, **kw):
         s, e = ev(); s.record(); y = o_post(o, x, pw, *args, **kw); e.record()
@@ -101,6 +102,16 @@ def measure_dominant_kernel(enc, xyz_dev):
     def lnlin(x, fw, *args, **kw):
         s, e = ev(); s.record(); y = o_lnlin(x, fw, *args, **kw); e.record()
         recs["lnlin"].append((s, e, 2.0 * x.shape[0] * fw.N * 256))
+        return y
+
+    def lnqkv(x, fw, *args, **kw):                  # the same projection with the keys / values leaving as attention planes
+        s, e = ev(); s.record(); y = o_lnqkv(x, fw, *args, **kw); e.record()
+        recs["lnlin"].append((s, e, 2.0 * x.shape[0] * fw.N * 256))
+        return y
+
+    def attp(q, *args, **kw):                       # plane-fed form of the window attention: same flops
+        s, e = ev(); s.record(); y = o_attp(q, *args, **kw); e.record()
+        recs["attn"].append((s, e, q.shape[0] * 2.0 * 2.0 * 512 * 256))
         return y
 
     def lin(a, sw, *args, **kw):
@@ -126,12 +137,14 @@ def measure_dominant_kernel(enc, xyz_dev):
 
     native.linear_split, native.swin_attention_packed, native.knn_topk_packed, native.mlp_split_fused = lin, att, knn, mlp
     native.swin_post_attn, native.swin_ln_linear = post, lnlin
+    native.swin_attention_packed_planes, native.swin_ln_qkv = attp, lnqkv
     try:
         enc.encode(xyz_dev)
         torch.cuda.synchronize()
     finally:
         native.linear_split, native.swin_attention_packed, native.knn_topk_packed, native.mlp_split_fused = o_lin, o_att, o_knn, o_mlp
         native.swin_post_attn, native.swin_ln_linear = o_post, o_lnlin
+        native.swin_attention_packed_planes, native.swin_ln_qkv = o_attp, o_lnqkv
 
     def summ(rs):
         ms = sum(r[0].elapsed_time(r[1]) for r in rs)
@@ -403,10 +416,10 @@ def main():
         if ehem:
             # secondary kernels, same convention; the position search (3 features) is selection-bound, its MFMA share is negligible
             out["roofline_kernels"] = {
-                "rc_ln_linear_kernel": entry(dom["lnlin"], note="LayerNorm + q|k|v projection in one launch, rows resident as MFMA B fragments"),
+                "rc_ln_linear_kernel": entry(dom["lnlin"], note="LayerNorm + q|k|v projection in one launch, rows resident as MFMA B fragments; keys / values leave as the attention kernel's bf16 planes"),
                 "gemm_split_kernel": entry(dom["gemm"], note="the remaining dense layers (geometry MLPs, patch merges, concat layers, probability heads)"),
                 "mlp_fused_kernel": entry(dom["mlp"], note="fc1 + GELU + fc2 + residual of a Swin block in one launch, hidden activation in LDS (SCP_SWIN=split only)"),
-                "swin_attn_bf16x3_kernel": entry(dom["attn"]),
+                "swin_attn_planes_kernel": entry(dom["attn"], note="window attention, K / V tiles staged by LDS-DMA from pre-split planes (SCP_ATTN_KV=rows: swin_attn_bf16x3_kernel)"),
                 "knn_f16x3_wg256_kernel": entry(dom["knn_feat"], note="fused distance + top-20 selection, 256-query workgroups on the XCD-affine schedule; every phase of a wave is latency-bound (DESIGN.md 4.5), L2-miss traffic 2.0 GB per launch"),
                 "knn_mfma_kernel<2,16> (positions)": {"bound": "valu", "launches_per_frame": dom["knn_pos"]["launches"],
                                                       "avg_launch_us": dom["knn_pos"]["avg_launch_us"]}}
