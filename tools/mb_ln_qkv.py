@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""scp_swin_ln_qkv against scp_swin_ln_linear + scp_swin_kv_planes: q identical? planes identical?"""
+"""scp_swin_ln_qkv against scp_swin_ln_linear + scp_swin_kv_planes: q identical? planes identical? time per 590 848 rows?"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
