@@ -414,6 +414,14 @@ SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int64_t ldo_in,
                                const float *b1, const float *b2, float eps, float *out, int64_t ldc, int32_t M, void *stream);
 SCP_API int64_t scp_swin_post_attn_weight_bytes(void);
 
+/* SwinPatchMerging (swin_transformer.py:350-384) in one launch: out[m] = LayerNorm(cat(x[ia[m]], x[ib[m]])) . W^T for M merged rows (the
+ * reduction has no bias).  x: fp32 [n_src][ldx] (256 channels; an index equal to n_src stands for a row of zeros - the pad of an odd
+ * window); W: a buffer of scp_swin_post_attn_weight_bytes() bytes holding the tiled planes (scp_split_weight_bf16 + scp_tile_weight_bf16) of
+ * (W diag(gamma))[:, 0:256] at byte 0 and of (W diag(gamma))[:, 256:512] at byte 131072, their lo planes at the same offsets behind the
+ * first half of the buffer; wbeta = W beta [256]; out fp32 [M][ldo]. */
+SCP_API int scp_swin_merge(const float *x, int64_t ldx, int64_t n_src, const int64_t *ia, const int64_t *ib, const void *W, const float *wbeta,
+                           float eps, float *out, int64_t ldo, int32_t M, void *stream);
+
 /* Keys and values handed from the projection to the window attention as bf16 hi / lo PLANES in the layout of the attention kernel's own
  * LDS tiles (swin_transformer.py:443-501; round 3).  planes: [4][Tp][256] bf16 = K hi, K lo, V^T hi, V^T lo for Tp rows of the packed
  * layout (Tp % 32 == 0; windows of 512 rows):

@@ -1005,6 +1005,134 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
     SCP_WAIT_DMA(0);
 }
 
+// =================================================================================================================================
+// scp_swin_merge: SwinPatchMerging (swin_transformer.py:350-384) in one launch - gather the (even, odd) token of every pair, LayerNorm
+// over the 512 concatenated channels, 512 -> 256 reduction (no bias) - for M merged rows.  Replaces layernorm_rows(gather) + gemm_split.
+// A wave holds its 32 merged rows; the K = 512 product runs as two K = 256 halves over the SAME eight accumulator blocks Y: half 0
+// (the even tokens' channels) as fragments while the raw odd-token rows wait in registers, then those become the fragments of half 1.
+// Weights: W' = W diag(gamma) as two [256][256] matrices (columns 0 - 255 / 256 - 511), each tiled like the attention projection, in a
+// buffer with RC_W_PLANE bytes between the hi and the lo planes (hi: W'0 at 0, W'1 at 128 KiB); the accumulators start from W beta.
+struct RcMergeArgs {
+    const float *x; int64_t ldx; int64_t n_src;     // source rows [n_src][ldx], 256 channels; index n_src = a row of zeros
+    const int64_t *ia, *ib;                         // [M]: even / odd token of the pair
+    const void *W; const float *wbeta;              // see above; [256]
+    float *out; int64_t ldo; int M; float eps;
+};
+
+__global__ __launch_bounds__(256, 1) void rc_merge_kernel(const RcMergeArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const RcLane L = rc_lane();
+    const int ntiles = (a.M + RC_ROWS - 1) / RC_ROWS;
+    float *swb = (float *)(smem + RC_OFF_BIAS);
+    for (int i = threadIdx.x; i < 256; i += 256) swb[i] = a.wbeta ? a.wbeta[i] : 0.f;
+    __syncthreads();
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    char *bounce = smem + RC_OFF_BOUNCE + L.w * RC_BOUNCE;
+    const int ldo_bytes = (int)(a.ldo * 4);
+    const int voff = (32 * L.w + (L.lane >> 3)) * ldo_bytes + (L.lane & 7) * 16;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.W, 0, 2 * RC_W_PLANE, 0x00020000);
+    auto src = [&](int t) { RcSlotSrc r = {((t >> 3) & 1) * 131072 + (t & 7) * 16384, 1024}; return r; };   // slot t = 8 kh + r: rows [32 r, +32) of half kh
+    {   // the first step's slots
+        const RcSlotSrc s0 = src(0), s1 = src(1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) { rc_dma_piece(L, wr, s0, smem, q, plane); rc_dma_piece(L, wr, s1, smem + RC_SLOT, q, plane); }
+    }
+    rbf16x8 A[2][4];
+    {
+        SCP_BARRIER_DMA(0);
+        const RcFragAddr f = rc_frag_addr(L, smem);
+        RC_DS_READ4_WAIT(A[0][1], f.r0, 16384, A[0][3], f.r0, RC_SLOT + 16384, A[0][0], f.r0, 0, A[0][2], f.r0, RC_SLOT);
+    }
+    int gstep = 0;
+    auto load_half = [&](const int64_t *idx, int t, float (&v)[128]) {
+        const int r = t * RC_ROWS + 32 * L.w + L.col;
+        const int64_t i = idx[r < a.M ? r : a.M - 1];
+        const float k = i < a.n_src ? 1.f : 0.f;
+        const float *p = a.x + (i < a.n_src ? i : a.n_src - 1) * a.ldx + 8 * L.h;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const rf32x4 q0 = *(const rf32x4 *)(p + 16 * s), q1 = *(const rf32x4 *)(p + 16 * s + 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v[8 * s + u] = q0[u] * k; v[8 * s + 4 + u] = q1[u] * k; }
+        }
+    };
+    // (Measured and dropped: the next tile's even rows requested behind step 3, when their registers are free - 0.420 against 0.396 ms
+    // per 303 616 merged rows: the loads are older than step 4's weight pieces, so its barrier waits for them.)
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * RC_ROWS;
+        float va[128], vb[128];
+        load_half(a.ia, tile, va);
+        load_half(a.ib, tile, vb);
+        // LayerNorm statistics over the 512 channels (this lane's 256 + lane ^ 32's), two-pass like layernorm_rows_kernel
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 128; i += 4) sum += ((va[i] + va[i + 1]) + (va[i + 2] + va[i + 3])) + ((vb[i] + vb[i + 1]) + (vb[i + 2] + vb[i + 3]));
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / 512.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 128; ++i) { const float da = va[i] - mean, db = vb[i] - mean; sq += da * da + db * db; }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq * (1.0f / 512.0f) + a.eps);
+        rbf16x8 Xh[16], Xl[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float f[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = (va[8 * s + i] - mean) * rstd;
+            rc_split8(f, Xh[s], Xl[s]);
+        }
+        rf32x16 Y[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const rf32x4 bb = *(const rf32x4 *)(swb + 32 * b + 8 * q + 4 * L.h);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Y[b][4 * q + u] = bb[u];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // eight steps: half kh, output channels [64 g, +64) -> Y[2 g], Y[2 g + 1]; a step requests the next one's slots (t + 1, wrapping
+        // into the next tile's first step)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int g = t & 3, tn = (t + 1) & 7;
+            rc_gemm_step<false>(L, smem, gstep & 1, Y[2 * g], Y[2 * g + 1], Xh, Xl, A, wr, src(2 * (tn & 3) + 8 * (tn >> 2)), src(2 * (tn & 3) + 1 + 8 * (tn >> 2)));
+            ++gstep;
+            if (t == 3) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    float f[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) f[i] = (vb[8 * s + i] - mean) * rstd;
+                    rc_split8(f, Xh[s], Xl[s]);
+                }
+            }
+        }
+        // ---- Y -> fp32 rows ----------------------------------------------------------------------------------------------------------
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t rows_left = (int64_t)a.M - m0;
+        const int64_t span = (rows_left < RC_ROWS ? rows_left : RC_ROWS) * a.ldo * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)m0 * a.ldo, 0, (int)span, 0x00020000);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            rf32x4 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[q][u] = Y[b][4 * q + u];
+            rc_store_block(L, bounce, o, rs, ldo_bytes, voff, 32 * b);
+        }
+    }
+    SCP_WAIT_DMA(0);
+}
+
+extern "C" SCP_API int scp_swin_merge(const float *x, int64_t ldx, int64_t n_src, const int64_t *ia, const int64_t *ib, const void *W, const float *wbeta,
+                                      float eps, float *out, int64_t ldo, int32_t M, void *stream);
+
 static unsigned long long *g_rc_dbg = nullptr;   // diagnostic only (tools/mb_rowchain_probe.py): [workgroup][wave][8] cycle sums
 extern "C" SCP_API int scp_rc_debug_buffer(unsigned long long *dev_buf) { g_rc_dbg = dev_buf; return SCP_OK; }
 
@@ -1105,3 +1233,25 @@ extern "C" SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int6
 
 // size in bytes of the weight buffer of scp_swin_post_attn (six tiled planes, see RcPostArgs.W)
 extern "C" SCP_API int64_t scp_swin_post_attn_weight_bytes(void) { return 2 * (int64_t)RC_W_PLANE; }
+
+// out[m] = LayerNorm_noaffine(cat(x[ia[m]], x[ib[m]])) . W'^T + wbeta: SwinPatchMerging for M merged rows (see rc_merge_kernel).
+// x: fp32 [n_src][ldx] (256 channels; an index equal to n_src stands for a row of zeros); W: scp_swin_post_attn_weight_bytes() bytes, the
+// tiled planes (scp_split_weight_bf16 + scp_tile_weight_bf16) of (W diag(gamma))[:, :256] at byte 0 and of (W diag(gamma))[:, 256:] at byte
+// 131072, their lo planes at the same offsets behind the first half of the buffer; wbeta = W beta [256]; out fp32 [M][ldo].
+extern "C" SCP_API int scp_swin_merge(const float *x, int64_t ldx, int64_t n_src, const int64_t *ia, const int64_t *ib, const void *W, const float *wbeta,
+                                      float eps, float *out, int64_t ldo, int32_t M, void *stream) {
+    if (!x || !ia || !ib || !W || !out || M <= 0 || n_src <= 0 || ldx < 256 || (ldx & 3) || ldo < 256 || (ldo & 3) ||
+        (((uintptr_t)x | (uintptr_t)out | (uintptr_t)W) & 15) || (int64_t)RC_ROWS * ldo * 4 > 0x7fffffffLL)
+        return SCP_EINVAL;
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void *)rc_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
+        configured = true;
+    }
+    RcMergeArgs a;
+    a.x = x; a.ldx = ldx; a.n_src = n_src; a.ia = ia; a.ib = ib; a.W = W; a.wbeta = wbeta; a.out = out; a.ldo = ldo; a.M = M; a.eps = eps;
+    const int ntiles = (M + RC_ROWS - 1) / RC_ROWS, ncu = rc_num_cu();
+    hipLaunchKernelGGL(rc_merge_kernel, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}

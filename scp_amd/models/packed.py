@@ -147,6 +147,8 @@ ROWCHAIN = __import__('os').environ.get('SCP_SWIN', 'rowchain') != 'split'
 # SCP_ATTN_KV=rows: keys / values go from the projection to the attention kernel as fp32 rows (round 3a - 3f); planes: as bf16 hi / lo
 # planes in the layout of the attention kernel's LDS tiles (bit-identical results)
 KV_PLANES = __import__('os').environ.get('SCP_ATTN_KV', 'planes') != 'rows'
+# SCP_MERGE=split: patch merging as gather + LayerNorm, then a split GEMM (round 2 - 3g; other last bits)
+MERGE_RC = __import__('os').environ.get('SCP_MERGE', 'rowchain') != 'split'
 
 
 def _rowchain_weights(layer, cross):
@@ -231,8 +233,13 @@ def _swin_layer(layer, x, valid, wtab, shift, query=None):
 
 
 def _merge(m, x, maps):
-    """SwinPatchMerging: gather (even, odd) token of every pair + LayerNorm(512) in one kernel, then the 512 -> 256 reduction."""
+    """SwinPatchMerging: gather (even, odd) token of every pair + LayerNorm(512) + the 512 -> 256 reduction in one row-chain launch
+    (SCP_SWIN=split: gather + LayerNorm in one kernel, then the reduction as a split GEMM)."""
     ev, od = maps          # index == x.shape[0] stands for the zero row an odd-length window is padded with
+    if ROWCHAIN and MERGE_RC and x.shape[1] == 256 and m.reduction.weight.shape == (256, 512) and m.reduction.bias is None:
+        mw = derived(m, "rowchain_merge", [m.reduction.weight, m.norm.weight, m.norm.bias],
+                     lambda: native.MergeWeights(m.reduction.weight, m.norm.weight, m.norm.bias))
+        return native.swin_merge(x, ev, od, mw, m.norm.eps)
     y = native.layernorm_rows(x, m.norm.weight, m.norm.bias, m.norm.eps, ia=ev, ib=od, split=True)
     return linear_s(y, m.reduction.weight, None)
 

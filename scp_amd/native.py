@@ -57,6 +57,7 @@ def lib():
     i32, i64 = C.c_int32, C.c_int64
     sig = {
         "scp_version": (C.c_int, []),
+        "scp_swin_merge": (C.c_int, [_vp, i64, i64, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, _vp]),
         "scp_swin_ln_qkv": (C.c_int, [_vp, i64, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, _vp, i64, i32, i32, _vp]),
         "scp_swin_kv_planes": (C.c_int, [_vp, _vp, i64, i64, _vp, _vp, _vp, _vp, _vp]),
         "scp_swin_attention_packed_planes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, i32, i32, i32, _vp, _vp, _vp, i64, _vp]),
@@ -510,8 +511,9 @@ def numeric_profile(model_name, profile="current"):
         profile = current_profile()
     knn = _MODES["knn"] if profile is None else ("f16x3" if profile.knn_f16x3 else "f32")
     attn = _MODES["attn"] if profile is None else ("bf16x3" if profile.attention_bf16x3 else "f32")
-    return (f"ehem/2:gemm={ops.MODE},knn={knn},attn={attn},concat={'hier' if packed.HIER else 'direct'},"
-            f"swin={'rowchain' if packed.ROWCHAIN else 'split'}")
+    # ehem/3: patch merging on the row-chain kernel (LayerNorm affine folded into the reduction: other last bits than ehem/2)
+    return (f"ehem/3:gemm={ops.MODE},knn={knn},attn={attn},concat={'hier' if packed.HIER else 'direct'},"
+            f"swin={'rowchain' if packed.ROWCHAIN else 'split'}" + ("" if (packed.MERGE_RC or not packed.ROWCHAIN) else ",merge=split"))
 
 
 def edge_gather_max(u, v, idx, scale, shift, out=None):
@@ -921,6 +923,39 @@ def swin_ln_qkv(x, fw, bias, eps=1e-5, valid=None):
                                _opt(bias), _dev(fw.wbeta), float(eps), None if q is None else q.data_ptr(), 256, pl.data_ptr(), M, M, fw.N, _stream())
     _check(rc, "scp_swin_ln_qkv")
     return q, KvPlanes(t=pl)
+
+
+class MergeWeights:
+    """SwinPatchMerging's LayerNorm(512) + reduction [256, 512] in the form scp_swin_merge streams (built once per layer): W' = W
+    diag(gamma) as two [256, 256] halves, tiled planes at bytes 0 / 131072 of a scp_swin_post_attn_weight_bytes() buffer (lo planes behind
+    its first half), and wbeta = W beta."""
+
+    def __init__(self, w, gamma, beta):
+        w64 = w.detach().double()
+        wf = (w64 * gamma.detach().double()[None, :]).float()
+        self.wbeta = (w64 @ beta.detach().double()).float().contiguous()
+        nbytes = lib().scp_swin_post_attn_weight_bytes()
+        buf = torch.zeros((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+        half = nbytes // 4                                           # bf16 elements per plane region
+        for kh in range(2):
+            hi, lo = _tiled_planes_always(SplitWeight(wf[:, 256 * kh:256 * (kh + 1)].contiguous()))
+            buf[kh * 65536:(kh + 1) * 65536] = hi.reshape(-1)[:65536]
+            buf[half + kh * 65536:half + (kh + 1) * 65536] = lo.reshape(-1)[:65536]
+        self.packed = buf
+        note_cache_fill()
+
+
+def swin_merge(x, ia, ib, mw, eps=1e-5):
+    """LayerNorm(cat(x[ia], x[ib])) . W^T for the M = len(ia) merged rows of a patch-merging layer in one launch (csrc/rowchain.hip);
+    an index equal to x.shape[0] stands for a row of zeros.  x fp32 [n, 256] rows (unit channel stride) -> fp32 [M, 256]."""
+    M = ia.shape[0]
+    if x.shape[1] != 256 or x.stride(1) != 1:
+        raise ScpError("swin_merge: 256-channel rows expected")
+    out = torch.empty((M, 256), dtype=torch.float32, device=x.device)
+    rc = lib().scp_swin_merge(x.data_ptr(), x.stride(0), x.shape[0], _dev(ia, torch.int64), _dev(ib, torch.int64), mw.packed.data_ptr(), _dev(mw.wbeta),
+                              float(eps), out.data_ptr(), out.stride(0), M, _stream())
+    _check(rc, "scp_swin_merge")
+    return out
 
 
 def rc_perm16(n, device):

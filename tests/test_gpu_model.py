@@ -1078,6 +1078,38 @@ def test_swin_ln_linear_vs_float64(dev, M, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_src", [1, 2, 255, 1000, 70001])
+def test_swin_merge_vs_float64_and_the_launches_it_replaces(dev, n_src):
+    """scp_swin_merge: gather of the (even, odd) tokens + LayerNorm(512) + 512 -> 256 reduction in one row-chain launch (the K = 512
+    product as two K = 256 halves over the same accumulators), against float64 and against layernorm_rows(gather) + the split GEMM;
+    zero rows (index == n_src) in either slot, ragged M, and a row's result does not depend on the launch it is in."""
+    from scp_amd import native
+    from scp_amd.ops import linear_s
+    g = torch.Generator().manual_seed(n_src)
+    x = (torch.randn((n_src, 256), generator=g) * 1.3 + 0.2).to(dev)
+    M = (n_src + 1) // 2
+    ev = torch.arange(0, 2 * M, 2)
+    od = ev + 1
+    od[od >= n_src] = n_src
+    if M > 6:
+        ev[5] = n_src
+    ev, od = ev.to(dev), od.to(dev)
+    gamma, beta = (1 + 0.1 * torch.randn(512, generator=g)).to(dev), (0.1 * torch.randn(512, generator=g)).to(dev)
+    W = (torch.randn((256, 512), generator=g) * 0.04).to(dev)
+    mw = native.MergeWeights(W, gamma, beta)
+    y = native.swin_merge(x, ev, od, mw)
+    y0 = linear_s(native.layernorm_rows(x, gamma, beta, 1e-5, ia=ev, ib=od, split=True), W, None)
+    xz = torch.cat((x, torch.zeros((1, 256), device=dev))).double()
+    ref = F.layer_norm(torch.cat((xz[ev], xz[od]), 1), (512,), gamma.double(), beta.double(), 1e-5) @ W.double().T
+    err, err0 = (y.double() - ref).abs().max().item(), (y0.double() - ref).abs().max().item()
+    print(f"n_src={n_src}: max err vs float64 {err:.2e} (two launches {err0:.2e})")
+    assert err < 1e-4 and err < 3 * err0 + 1e-5
+    if M > 200:
+        lo, hi = M // 3, M // 3 + 131
+        assert torch.equal(native.swin_merge(x, ev[lo:hi].contiguous(), od[lo:hi].contiguous(), mw), y[lo:hi])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,N", [(512, 768), (512, 512), (1536, 768), (70144, 768), (70144, 512)])
 def test_swin_ln_qkv_planes_are_the_split_of_the_fp32_projection(dev, M, N):
     """scp_swin_ln_qkv (keys / values leave the LayerNorm + projection kernel as the attention's bf16 planes, value heads computed with the
