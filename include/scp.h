@@ -422,6 +422,17 @@ SCP_API int64_t scp_swin_post_attn_weight_bytes(void);
 SCP_API int scp_swin_merge(const float *x, int64_t ldx, int64_t n_src, const int64_t *ia, const int64_t *ib, const void *W, const float *wbeta,
                            float eps, float *out, int64_t ldo, int32_t M, void *stream);
 
+/* The two edge MLPs of the geometry feature generator (dgcnn.py:121-151: edge_mlp1 448 -> 256 -> 256 -> 256 on cat(pos1, pos2, pos3), edge_mlp2
+ * 512 -> 256 -> 256 -> 128 on cat(pos3, edge_mlp1(...)), LeakyReLU(0.01) between the layers) for M points in one launch: six dense layers
+ * chained through the MFMA accumulators.  pos1 / pos2 / pos3: fp32 [M][64 | 128 | 256] (row strides ld1 / ld2 / ld3); W: a buffer of
+ * scp_swin_post_attn_weight_bytes() bytes with eight tiled [256][256] matrices (hi planes at m * 131072 bytes, lo planes at the same
+ * offsets behind the first half of the buffer): 0 / 1 = edge_mlp1 layer 1, input columns [0, 256) / [256, 448) + 64 zero columns;
+ * 2, 3 = its layers 2, 3; 4 / 5 = edge_mlp2 layer 1, input columns [256, 512) / [0, 256); 6, 7 = its layers 2, 3 (7: 128 rows); the
+ * input columns of matrices 2, 3, 4, 6, 7 in accumulator order (inside every group of 16: columns 4 - 7 and 8 - 11 exchanged);
+ * bias: the six bias vectors back to back (1408 floats); out: fp32 [M][ldo], 128 columns written. */
+SCP_API int scp_geo_edge_mlps(const float *pos1, int64_t ld1, const float *pos2, int64_t ld2, const float *pos3, int64_t ld3, const void *W,
+                              const float *bias, float *out, int64_t ldo, int32_t M, void *stream);
+
 /* Keys and values handed from the projection to the window attention as bf16 hi / lo PLANES in the layout of the attention kernel's own
  * LDS tiles (swin_transformer.py:443-501; round 3).  planes: [4][Tp][256] bf16 = K hi, K lo, V^T hi, V^T lo for Tp rows of the packed
  * layout (Tp % 32 == 0; windows of 512 rows):

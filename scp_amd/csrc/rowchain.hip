@@ -1133,6 +1133,142 @@ __global__ __launch_bounds__(256, 1) void rc_merge_kernel(const RcMergeArgs a) {
 extern "C" SCP_API int scp_swin_merge(const float *x, int64_t ldx, int64_t n_src, const int64_t *ia, const int64_t *ib, const void *W, const float *wbeta,
                                       float eps, float *out, int64_t ldo, int32_t M, void *stream);
 
+// =================================================================================================================================
+// scp_geo_edge_mlps: the two edge MLPs of the geometry feature generator (dgcnn.py:121-151; ehem.py geo_feat_generator.edge_mlp1 / edge_mlp2)
+// for M points in one launch:   e1 = mlp1(cat(pos1, pos2, pos3))  (448 -> 256 -> 256 -> 256)
+//                               out = mlp2(cat(pos3, e1))          (512 -> 256 -> 256 -> 128)       LeakyReLU(0.01) between the layers
+// Six dense layers, 30 steps of rc_gemm_step per 128-row tile; every activation between two layers stays in the accumulators and
+// becomes the next layer's B fragments (columns of the next weight in accumulator order, rc_perm16), e1 never exists in memory.
+// Replaces six split-GEMM launches and four fp32 -> plane conversion launches.  Weights: eight tiled [256][256] matrices (hi planes at
+// m * 128 KiB, lo planes RC_W_PLANE bytes behind): 0 / 1 = mlp1 layer 1 columns [0, 256) / [256, 448) (zero padded); 2, 3 = mlp1 layers
+// 2, 3 (perm16 columns); 4 = mlp2 layer 1 columns [256, 512) (e1: perm16); 5 = its columns [0, 256) (pos3); 6 = mlp2 layer 2 (perm16);
+// 7 = mlp2 layer 3 (128 rows, perm16 columns).  bias: b11 | b12 | b13 | b21 | b22 (256 each) | b23 (128).
+struct RcEdgeArgs {
+    const float *p1, *p2, *p3; int64_t ld1, ld2, ld3;
+    const void *W; const float *bias;
+    float *out; int64_t ldo; int M;
+};
+
+__device__ __forceinline__ float rc_leaky(float y) { return y > 0.f ? y : 0.01f * y; }
+
+__global__ __launch_bounds__(256, 1) void rc_edge_mlp_kernel(const RcEdgeArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const RcLane L = rc_lane();
+    const int ntiles = (a.M + RC_ROWS - 1) / RC_ROWS;
+    float *sb = (float *)(smem + RC_OFF_BIAS);
+    for (int i = threadIdx.x; i < 5 * 256 + 128; i += 256) sb[i] = a.bias[i];
+    __syncthreads();
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    char *bounce = smem + RC_OFF_BOUNCE + L.w * RC_BOUNCE;
+    const int ldo_bytes = (int)(a.ldo * 4);
+    const int voff = (32 * L.w + (L.lane >> 3)) * ldo_bytes + (L.lane & 7) * 16;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.W, 0, 2 * RC_W_PLANE, 0x00020000);
+    // step t = 4 m + g (m < 7), 28 + g (m = 7, g < 2): rows [64 g, +64) of matrix m; the step behind the last is the next tile's first
+    // (the two k halves of a first layer alternate per 64 output channels, so that an accumulator pair is finished before the next starts)
+    auto src = [&](int t, int k) {
+        int m, g;
+        if (t < 8) { m = t & 1; g = t >> 1; }
+        else if (t < 16) { m = t >> 2; g = t & 3; }
+        else if (t < 24) { m = 4 + (t & 1); g = (t - 16) >> 1; }
+        else if (t < 28) { m = 6; g = t & 3; }
+        else { m = 7; g = t - 28; }
+        RcSlotSrc r = {m * 131072 + (2 * g + k) * 16384, 1024};
+        return r;
+    };
+    {
+        const RcSlotSrc s0 = src(0, 0), s1 = src(0, 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) { rc_dma_piece(L, wr, s0, smem, q, plane); rc_dma_piece(L, wr, s1, smem + RC_SLOT, q, plane); }
+    }
+    rbf16x8 A[2][4];
+    {
+        SCP_BARRIER_DMA(0);
+        const RcFragAddr f = rc_frag_addr(L, smem);
+        RC_DS_READ4_WAIT(A[0][1], f.r0, 16384, A[0][3], f.r0, RC_SLOT + 16384, A[0][0], f.r0, 0, A[0][2], f.r0, RC_SLOT);
+    }
+    int gstep = 0, t = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * RC_ROWS;
+        const int row = m0 + 32 * L.w + L.col;
+        const int64_t rowc = row < a.M ? row : a.M - 1;
+        const float *q1 = a.p1 + rowc * a.ld1 + 8 * L.h, *q2 = a.p2 + rowc * a.ld2 + 8 * L.h, *q3 = a.p3 + rowc * a.ld3 + 8 * L.h;
+        rbf16x8 Xh[16], Xl[16], Zh[16], Zl[16];
+        rf32x16 Y[8];
+        auto frag_of = [&](const float *p, rbf16x8 &hi, rbf16x8 &lo) {          // 8 consecutive channels of this lane's row
+            const rf32x4 v0 = *(const rf32x4 *)p, v1 = *(const rf32x4 *)(p + 4);
+            const float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            rc_split8(f, hi, lo);
+        };
+        auto to_frags = [&](rbf16x8 (&Fh)[16], rbf16x8 (&Fl)[16], bool act) {   // Y (accumulator layout) -> B fragments of the next layer
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    float fr[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) fr[i] = act ? rc_leaky(Y[b][8 * tt + i]) : Y[b][8 * tt + i];
+                    rc_split8(fr, Fh[2 * b + tt], Fl[2 * b + tt]);
+                }
+        };
+        // One pair of accumulator blocks at a time: start from the bias, one step per k half, write the pair into Y (written, never read,
+        // through the run-time switch: read that way the compiler keeps Y in scratch memory).  ONE copy of a step's code per use.
+#define RC_STEP(Fh, Fl) { const int tn = t + 1 < 30 ? t + 1 : 0; rc_gemm_step<false>(L, smem, gstep & 1, c0, c1, Fh, Fl, A, wr, src(tn, 0), src(tn, 1)); ++gstep; t = tn; }
+#define RC_LAYER(LAYER, NG, STEPS)                                                                                                             \
+        for (int g = 0; g < (NG); ++g) {                                                                                                       \
+            rf32x16 c0, c1;                                                                                                                    \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                                    \
+                const rf32x4 b0 = *(const rf32x4 *)(sb + 256 * (LAYER) + 64 * g + 8 * q + 4 * L.h), b1 = *(const rf32x4 *)(sb + 256 * (LAYER) + 64 * g + 32 + 8 * q + 4 * L.h); \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) { c0[4 * q + u] = b0[u]; c1[4 * q + u] = b1[u]; }                                 \
+            }                                                                                                                                  \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                                 \
+            STEPS                                                                                                                              \
+            switch (g) { case 0: Y[0] = c0; Y[1] = c1; break; case 1: Y[2] = c0; Y[3] = c1; break; case 2: Y[4] = c0; Y[5] = c1; break; default: Y[6] = c0; Y[7] = c1; break; } \
+        }
+        // ---- mlp1 layer 1: cat(pos1 (64), pos2 (128), pos3 (256)) as k halves [0, 256) and [256, 448) + 64 zero columns ----------------------------
+#pragma unroll
+        for (int s = 0; s < 16; ++s) frag_of(s < 4 ? q1 + 16 * s : (s < 12 ? q2 + 16 * (s - 4) : q3 + 16 * (s - 12)), Xh[s], Xl[s]);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (s < 12) frag_of(q3 + 64 + 16 * s, Zh[s], Zl[s]);
+            else { Zh[s] = __builtin_bit_cast(rbf16x8, (ru32x4){0u, 0u, 0u, 0u}); Zl[s] = Zh[s]; }
+        }
+        RC_LAYER(0, 4, RC_STEP(Xh, Xl) RC_STEP(Zh, Zl))
+        to_frags(Xh, Xl, true);
+        RC_LAYER(1, 4, RC_STEP(Xh, Xl))                                          // mlp1 layer 2
+        to_frags(Xh, Xl, true);
+        RC_LAYER(2, 4, RC_STEP(Xh, Xl))                                          // mlp1 layer 3 -> e1
+        // ---- mlp2 layer 1: cat(pos3, e1): e1 straight from the accumulators, pos3 read again ------------------------------------------------------
+        to_frags(Xh, Xl, false);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) frag_of(q3 + 16 * s, Zh[s], Zl[s]);
+        RC_LAYER(3, 4, RC_STEP(Xh, Xl) RC_STEP(Zh, Zl))
+        to_frags(Xh, Xl, true);
+        RC_LAYER(4, 4, RC_STEP(Xh, Xl))                                          // mlp2 layer 2
+        to_frags(Xh, Xl, true);
+        RC_LAYER(5, 2, RC_STEP(Xh, Xl))                                          // mlp2 layer 3: 128 outputs
+#undef RC_LAYER
+#undef RC_STEP
+        // ---- Y[0 .. 3] -> fp32 rows ------------------------------------------------------------------------------------------------------------
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t rows_left = (int64_t)a.M - m0;
+        const int64_t span = (rows_left < RC_ROWS ? rows_left : RC_ROWS) * a.ldo * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)m0 * a.ldo, 0, (int)span, 0x00020000);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            rf32x4 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[q][u] = Y[b][4 * q + u];
+            rc_store_block(L, bounce, o, rs, ldo_bytes, voff, 32 * b);
+        }
+    }
+    SCP_WAIT_DMA(0);
+}
+
 static unsigned long long *g_rc_dbg = nullptr;   // diagnostic only (tools/mb_rowchain_probe.py): [workgroup][wave][8] cycle sums
 extern "C" SCP_API int scp_rc_debug_buffer(unsigned long long *dev_buf) { g_rc_dbg = dev_buf; return SCP_OK; }
 
@@ -1233,6 +1369,27 @@ extern "C" SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int6
 
 // size in bytes of the weight buffer of scp_swin_post_attn (six tiled planes, see RcPostArgs.W)
 extern "C" SCP_API int64_t scp_swin_post_attn_weight_bytes(void) { return 2 * (int64_t)RC_W_PLANE; }
+
+// out = edge_mlp2(cat(pos3, edge_mlp1(cat(pos1, pos2, pos3)))) for M points (see rc_edge_mlp_kernel): pos1 / pos2 / pos3 fp32 [M][64 | 128 | 256]
+// with row strides ld1 / ld2 / ld3; W: scp_swin_post_attn_weight_bytes() bytes, the eight tiled matrices described there; bias [1408];
+// out fp32 [M][ldo] (128 columns written).
+extern "C" SCP_API int scp_geo_edge_mlps(const float *pos1, int64_t ld1, const float *pos2, int64_t ld2, const float *pos3, int64_t ld3, const void *W,
+                                         const float *bias, float *out, int64_t ldo, int32_t M, void *stream) {
+    if (!pos1 || !pos2 || !pos3 || !W || !bias || !out || M <= 0 || ld1 < 64 || ld2 < 128 || ld3 < 256 || ((ld1 | ld2 | ld3) & 3) || ldo < 128 || (ldo & 3) ||
+        (((uintptr_t)pos1 | (uintptr_t)pos2 | (uintptr_t)pos3 | (uintptr_t)out | (uintptr_t)W) & 15) || (int64_t)RC_ROWS * ldo * 4 > 0x7fffffffLL)
+        return SCP_EINVAL;
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void *)rc_edge_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
+        configured = true;
+    }
+    RcEdgeArgs a;
+    a.p1 = pos1; a.p2 = pos2; a.p3 = pos3; a.ld1 = ld1; a.ld2 = ld2; a.ld3 = ld3; a.W = W; a.bias = bias; a.out = out; a.ldo = ldo; a.M = M;
+    const int ntiles = (M + RC_ROWS - 1) / RC_ROWS, ncu = rc_num_cu();
+    hipLaunchKernelGGL(rc_edge_mlp_kernel, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
 
 // out[m] = LayerNorm_noaffine(cat(x[ia[m]], x[ib[m]])) . W'^T + wbeta: SwinPatchMerging for M merged rows (see rc_merge_kernel).
 // x: fp32 [n_src][ldx] (256 channels; an index equal to n_src stands for a row of zeros); W: scp_swin_post_attn_weight_bytes() bytes, the

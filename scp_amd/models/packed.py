@@ -149,6 +149,8 @@ ROWCHAIN = __import__('os').environ.get('SCP_SWIN', 'rowchain') != 'split'
 KV_PLANES = __import__('os').environ.get('SCP_ATTN_KV', 'planes') != 'rows'
 # SCP_MERGE=split: patch merging as gather + LayerNorm, then a split GEMM (round 2 - 3g; other last bits)
 MERGE_RC = __import__('os').environ.get('SCP_MERGE', 'rowchain') != 'split'
+# SCP_EDGE=split: the geometry generator's two edge MLPs as six split GEMMs (round 1 - 3h; other last bits)
+EDGE_RC = __import__('os').environ.get('SCP_EDGE', 'rowchain') != 'split'
 
 
 def _rowchain_weights(layer, cross):
@@ -346,10 +348,17 @@ def ehem_phase1_packed(model, ctx, pos, plan, table=None):
     nx = g.mlp3[4].weight.shape[0]
     feat = torch.empty((P0, nx + g.edge_mlp2[4].weight.shape[0]), dtype=torch.float32, device=dev)
     leaky_mlp3_s(g.mlp3, native.split_rows(x), out=feat[:, :nx])
-    e_in = native.SplitAct.empty(P0, pos3.shape[1] + g.edge_mlp1[4].weight.shape[0], dev)     # cat(pos3, edge_mlp1(...))
-    native.split_rows(pos3, out=e_in.cols(0, pos3.shape[1]))
-    leaky_mlp3_s(g.edge_mlp1, split_cat((pos1, pos2, pos3)), want="split", out_split=e_in.cols(pos3.shape[1], e_in.K))
-    leaky_mlp3_s(g.edge_mlp2, e_in, out=feat[:, nx:])
+    if ROWCHAIN and EDGE_RC and (pos1.shape[1], pos2.shape[1], pos3.shape[1]) == (64, 128, 256) and feat.shape[1] - nx == 128:
+        # both edge MLPs in one row-chain launch: six layers chained through the accumulators, edge_mlp1's output never leaves the registers
+        ew = derived(g, "rowchain_edge", [l.weight for l in (g.edge_mlp1[0], g.edge_mlp1[2], g.edge_mlp1[4], g.edge_mlp2[0], g.edge_mlp2[2], g.edge_mlp2[4])] +
+                     [l.bias for l in (g.edge_mlp1[0], g.edge_mlp1[2], g.edge_mlp1[4], g.edge_mlp2[0], g.edge_mlp2[2], g.edge_mlp2[4])],
+                     lambda: native.EdgeMlpWeights(g.edge_mlp1, g.edge_mlp2))
+        native.geo_edge_mlps(pos1, pos2, pos3, ew, feat[:, nx:])
+    else:
+        e_in = native.SplitAct.empty(P0, pos3.shape[1] + g.edge_mlp1[4].weight.shape[0], dev)     # cat(pos3, edge_mlp1(...))
+        native.split_rows(pos3, out=e_in.cols(0, pos3.shape[1]))
+        leaky_mlp3_s(g.edge_mlp1, split_cat((pos1, pos2, pos3)), want="split", out_split=e_in.cols(pos3.shape[1], e_in.K))
+        leaky_mlp3_s(g.edge_mlp2, e_in, out=feat[:, nx:])
     hs = _encoder(model.swin_self_transformer, feat, d["self_valid"], d["self_tab"], d["self_merge"])
     feat_a = _mlp_over_concat(model.ancient_mlp, hs, d["self_parent"]) if HIER else leaky_mlp3_s(model.ancient_mlp, _concat(hs, d["self_concat"]))
     Q0 = d["a1map"].shape[0]

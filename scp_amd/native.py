@@ -57,6 +57,7 @@ def lib():
     i32, i64 = C.c_int32, C.c_int64
     sig = {
         "scp_version": (C.c_int, []),
+        "scp_geo_edge_mlps": (C.c_int, [_vp, i64, _vp, i64, _vp, i64, _vp, _vp, _vp, i64, i32, _vp]),
         "scp_swin_merge": (C.c_int, [_vp, i64, i64, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, _vp]),
         "scp_swin_ln_qkv": (C.c_int, [_vp, i64, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, _vp, i64, i32, i32, _vp]),
         "scp_swin_kv_planes": (C.c_int, [_vp, _vp, i64, i64, _vp, _vp, _vp, _vp, _vp]),
@@ -511,9 +512,10 @@ def numeric_profile(model_name, profile="current"):
         profile = current_profile()
     knn = _MODES["knn"] if profile is None else ("f16x3" if profile.knn_f16x3 else "f32")
     attn = _MODES["attn"] if profile is None else ("bf16x3" if profile.attention_bf16x3 else "f32")
-    # ehem/3: patch merging on the row-chain kernel (LayerNorm affine folded into the reduction: other last bits than ehem/2)
+    # ehem/3: patch merging and the geometry generator's edge MLPs on row-chain kernels (other last bits than ehem/2)
     return (f"ehem/3:gemm={ops.MODE},knn={knn},attn={attn},concat={'hier' if packed.HIER else 'direct'},"
-            f"swin={'rowchain' if packed.ROWCHAIN else 'split'}" + ("" if (packed.MERGE_RC or not packed.ROWCHAIN) else ",merge=split"))
+            f"swin={'rowchain' if packed.ROWCHAIN else 'split'}" + ("" if (packed.MERGE_RC or not packed.ROWCHAIN) else ",merge=split") +
+            ("" if (packed.EDGE_RC or not packed.ROWCHAIN) else ",edge=split"))
 
 
 def edge_gather_max(u, v, idx, scale, shift, out=None):
@@ -923,6 +925,46 @@ def swin_ln_qkv(x, fw, bias, eps=1e-5, valid=None):
                                _opt(bias), _dev(fw.wbeta), float(eps), None if q is None else q.data_ptr(), 256, pl.data_ptr(), M, M, fw.N, _stream())
     _check(rc, "scp_swin_ln_qkv")
     return q, KvPlanes(t=pl)
+
+
+class EdgeMlpWeights:
+    """The two edge MLPs of the geometry feature generator (Sequential(Linear, LeakyReLU, Linear, LeakyReLU, Linear) each: 448 -> 256 -> 256
+    -> 256 and 512 -> 256 -> 256 -> 128) in the form scp_geo_edge_mlps streams: eight tiled [256, 256] matrices in a
+    scp_swin_post_attn_weight_bytes() buffer (see csrc/rowchain.hip: rc_edge_mlp_kernel) and the six biases back to back."""
+
+    def __init__(self, mlp1, mlp2):
+        w11, w12, w13 = (mlp1[i].weight.detach().float() for i in (0, 2, 4))
+        w21, w22, w23 = (mlp2[i].weight.detach().float() for i in (0, 2, 4))
+        if tuple(w11.shape) != (256, 448) or tuple(w12.shape) != (256, 256) or tuple(w13.shape) != (256, 256) or tuple(w21.shape) != (256, 512) or \
+                tuple(w22.shape) != (256, 256) or tuple(w23.shape) != (128, 256):
+            raise ScpError("EdgeMlpWeights: unexpected layer shapes")
+        dev = w11.device
+        P = rc_perm16(256, dev)
+        z = torch.zeros((256, 64), dtype=torch.float32, device=dev)
+        mats = [w11[:, :256], torch.cat((w11[:, 256:], z), 1), w12[:, P], w13[:, P], w21[:, 256:][:, P], w21[:, :256], w22[:, P],
+                torch.cat((w23[:, P], torch.zeros((128, 256), dtype=torch.float32, device=dev)), 0)]
+        nbytes = lib().scp_swin_post_attn_weight_bytes()
+        buf = torch.zeros((nbytes // 2,), dtype=torch.bfloat16, device=dev)
+        half = nbytes // 4
+        for m, w in enumerate(mats):
+            hi, lo = _tiled_planes_always(SplitWeight(w.contiguous()))
+            buf[m * 65536:(m + 1) * 65536] = hi.reshape(-1)[:65536]
+            buf[half + m * 65536:half + (m + 1) * 65536] = lo.reshape(-1)[:65536]
+        self.packed = buf
+        self.bias = torch.cat([mlp1[i].bias.detach().float() for i in (0, 2, 4)] + [mlp2[i].bias.detach().float() for i in (0, 2, 4)]).contiguous()
+        note_cache_fill()
+
+
+def geo_edge_mlps(pos1, pos2, pos3, ew, out):
+    """out[:, :128] = edge_mlp2(cat(pos3, edge_mlp1(cat(pos1, pos2, pos3)))) in one launch; pos1 / pos2 / pos3 fp32 [M, 64 | 128 | 256] (unit channel
+    stride), out fp32 [M, >= 128] (may be a column slice of a wider buffer)."""
+    M = pos1.shape[0]
+    if pos1.shape[1] != 64 or pos2.shape[1] != 128 or pos3.shape[1] != 256 or pos1.stride(1) != 1 or pos2.stride(1) != 1 or pos3.stride(1) != 1 or out.stride(1) != 1:
+        raise ScpError("geo_edge_mlps: [M, 64], [M, 128], [M, 256] rows expected")
+    rc = lib().scp_geo_edge_mlps(pos1.data_ptr(), pos1.stride(0), pos2.data_ptr(), pos2.stride(0), pos3.data_ptr(), pos3.stride(0), ew.packed.data_ptr(),
+                                 ew.bias.data_ptr(), out.data_ptr(), out.stride(0), M, _stream())
+    _check(rc, "scp_geo_edge_mlps")
+    return out
 
 
 class MergeWeights:

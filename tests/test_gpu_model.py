@@ -1078,6 +1078,39 @@ def test_swin_ln_linear_vs_float64(dev, M, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 129, 1000, 70001])
+def test_geo_edge_mlps_vs_float64_and_the_launches_they_replace(dev, M):
+    """scp_geo_edge_mlps: edge_mlp2(cat(pos3, edge_mlp1(cat(pos1, pos2, pos3)))) - six dense layers chained through the accumulators in one
+    launch - against float64 and against the six split GEMMs; output into a column slice; a row's result does not depend on the launch."""
+    import torch.nn as nn
+    from scp_amd import native
+    from scp_amd.ops import leaky_mlp3_s, split_cat
+    torch.manual_seed(M)
+    mk = lambda a, b, c, d: nn.Sequential(nn.Linear(a, b), nn.LeakyReLU(0.01), nn.Linear(b, c), nn.LeakyReLU(0.01), nn.Linear(c, d)).to(dev)
+    m1, m2 = mk(448, 256, 256, 256), mk(512, 256, 256, 128)
+    g = torch.Generator().manual_seed(M)
+    p1, p2, p3 = (torch.randn((M, c), generator=g).to(dev) for c in (64, 128, 256))
+    ew = native.EdgeMlpWeights(m1, m2)
+    out = torch.full((M, 256), 7.0, device=dev)
+    native.geo_edge_mlps(p1, p2, p3, ew, out[:, 128:])
+    assert (out[:, :128] == 7.0).all()
+    e_in = native.SplitAct.empty(M, 512, dev)
+    native.split_rows(p3, out=e_in.cols(0, 256))
+    leaky_mlp3_s(m1, split_cat((p1, p2, p3)), want="split", out_split=e_in.cols(256, 512))
+    old = leaky_mlp3_s(m2, e_in)
+    with torch.no_grad():
+        ref = m2.double()(torch.cat((p3.double(), m1.double()(torch.cat((p1, p2, p3), 1).double())), 1))
+    err, err0 = (out[:, 128:].double() - ref).abs().max().item(), (old.double() - ref).abs().max().item()
+    print(f"M={M}: max err vs float64 {err:.2e} (six launches {err0:.2e})")
+    assert err < 2e-5 and err < 3 * err0 + 2e-6
+    if M > 300:
+        lo, hi = M // 3, M // 3 + 131
+        o2 = torch.empty((hi - lo, 128), device=dev)
+        native.geo_edge_mlps(p1[lo:hi], p2[lo:hi], p3[lo:hi], ew, o2)
+        assert torch.equal(o2, out[lo:hi, 128:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_src", [1, 2, 255, 1000, 70001])
 def test_swin_merge_vs_float64_and_the_launches_it_replaces(dev, n_src):
     """scp_swin_merge: gather of the (even, odd) tokens + LayerNorm(512) + 512 -> 256 reduction in one row-chain launch (the K = 512
