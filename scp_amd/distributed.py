@@ -98,6 +98,13 @@ def pin_rank_threads(local, local_world, numa=True):
     rank, or with SCP_PIN=0.  Returns the CPU list of this rank or None."""
     if os.environ.get("SCP_PIN", "1") == "0" or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
+    try:
+        return _pin_rank_threads(local, local_world, numa)
+    except Exception:               # pinning is an optimisation: an unexpected sysfs layout or a refused affinity call never costs a rank
+        return None
+
+
+def _pin_rank_threads(local, local_world, numa):
     allowed = set(os.sched_getaffinity(0))
     peers, slot, pool = local_world, local, allowed
     if numa:
