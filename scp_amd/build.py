@@ -17,6 +17,8 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # (HIP's __fmul_rn / __fadd_rn are plain operators and do NOT stop the contraction).
 EXTRA = {"geom.hip": ["-ffp-contract=off"], "knn.hip": ["-ffp-contract=off"], "cdf.hip": ["-ffp-contract=off"],
          "edge.hip": ["-ffp-contract=off"], "metrics.hip": ["-ffp-contract=off"]}
+if os.environ.get("SCP_ATTN_DEFS"):    # experiment builds of csrc/attn.hip (e.g. SCP_ATTN_DEFS="-DPNS=3")
+    EXTRA["attn.hip"] = os.environ["SCP_ATTN_DEFS"].split()
 if os.environ.get("SCP_RC_DEFS"):      # experiment builds of csrc/rowchain.hip (e.g. SCP_RC_DEFS="-DRC_WAIT0")
     EXTRA["rowchain.hip"] = os.environ["SCP_RC_DEFS"].split()
 

@@ -400,12 +400,15 @@ typedef __attribute__((address_space(3))) void *attn_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *attn_glb_ptr_t;
 #define PKT 32          // keys per tile
 #define PST 16384       // bytes per stage: K hi | K lo | V hi | V lo, 4 KiB each
+#ifndef PNS
+#define PNS 2            // stages (tiles requested PNS - 1 iterations ahead).  3 (52 KiB of LDS: three workgroups per CU instead of four): 1 282 against 1 227 us per 1 152 windows
+#endif
 
 __global__ __launch_bounds__(256, 3) void swin_attn_planes_kernel(const float *__restrict__ q, const __bf16 *__restrict__ khi, const __bf16 *__restrict__ klo,
                                                                  const __bf16 *__restrict__ vthi, const __bf16 *__restrict__ vtlo,
                                                                  const float *__restrict__ table, int shift, int ldq, float *__restrict__ out,
                                                                  const int *__restrict__ wtab, __bf16 *__restrict__ ohi, __bf16 *__restrict__ olo, int64_t ldo) {
-    __shared__ __attribute__((aligned(1024))) char stg[2 * PST];
+    __shared__ __attribute__((aligned(1024))) char stg[PNS * PST];
     __shared__ float tab[2 * WIN - 1];
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -465,11 +468,13 @@ __global__ __launch_bounds__(256, 3) void swin_attn_planes_kernel(const float *_
         }
     };
     issue(0, 0);
+    if (PNS > 2) issue(1, 1);
     __syncthreads();                                                        // the bias table
     for (int t = 0; t < WIN / PKT; ++t) {
-        SCP_BARRIER_DMA(0);                                                 // tile t has landed; everybody is done with the other stage
-        if (t + 1 < WIN / PKT) issue(t + 1, (t + 1) & 1);
-        const char *S = stg + (t & 1) * PST;
+        // tile t has landed (with three stages the 4 pieces of tile t + 1 stay in flight); everybody is done with the stage refilled next
+        if (PNS > 2 && t + 1 < WIN / PKT) SCP_BARRIER_DMA(4); else SCP_BARRIER_DMA(0);
+        if (t + PNS - 1 < WIN / PKT) issue(t + PNS - 1, (t + PNS - 1) % PNS);
+        const char *S = stg + (t % PNS) * PST;
         const float madd = (masked && ((t * PKT) >> 8) != qreg) ? -100.f * LOG2E : 0.f;
         f32x16 s;
 #pragma unroll
