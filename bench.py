@@ -5,6 +5,7 @@
     python bench.py --gpus N ...            (starts N ranks itself: a child `python -m torch.distributed.run`, before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
     python bench.py --all-configs            (the five BASELINE.json configurations, one JSON line each, into profiles/ with --out-dir)
+    python bench.py --decode                 (the decoder on the same configuration: frames/s, stage split)
 
 One step = one synthetic 120 000-point frame through the whole hot path on one GPU: quantiser (3 shells) -> octree
 serialisation -> context tables -> EHEM over every <= 8192-node window -> softmax/integer CDF -> range coder.  The frame
@@ -12,6 +13,14 @@ is resident in HBM before the timed region; the (c_low, c_high) pairs (4 B/node)
 on the host inside the timed region, as in a real encode.  Frames are independent: rank r encodes its own frames
 (weak scaling), the only collective is the end-of-run all-reduce of the 5 summary scalars (RCCL).
 Prints ONE JSON line on rank 0.
+
+How the roofline numbers of the line are measured (round 4): `native.launch_profile` switches on the launch brackets of the C ABI
+(include/scp_debug.h: scp_prof_*): inside libscp_hip.so every hot entry point records a hipEvent immediately before and
+immediately after its hipLaunchKernelGGL, on the stream the kernel is launched on - no Python, no allocation between the two
+records.  One untimed frame warms the measuring stream's allocator pool, three frames are measured, every launch keeps its MINIMUM
+over the three, and the line carries a self-check (`roofline.valid`): the event-timed kernels of a frame must sum to no more than the
+wall time of the same frame's model stage.  `profiles/r4*_frame_kernel_stats.csv` (rocprofv3 --kernel-trace --stats of the same work)
+must agree with `avg_launch_us` within a few percent.
 """
 import argparse
 import json
@@ -29,12 +38,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0
+PMC_PROFILE = "r4_pmc_traffic.json"     # profiles/: HBM bytes per launch / per frame from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=None, help="timed frames per rank (default 24; 3 with --decode)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="ehem-L16-m", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
@@ -42,11 +52,17 @@ def parse():
     ap.add_argument("--depth", type=int, default=4, help="frames in flight (encode_async handles not yet finished); 4 measured 1.2 % above 3, 5 no better")
     ap.add_argument("--batch", type=int, default=None, help="frames per stage-G / packed-forward / CDF launch (FrameEncoder.encode_batch_async); "
                     "default: 4 for the level-12 EHEM configuration (a 115 k-node frame is 22 windows), 1 elsewhere")
-    ap.add_argument("--host-transform", action="store_true", help="strict-identity mode: numpy float32 transform + quantiser on the host (inside the timed region)")
+    ap.add_argument("--host-transform", action="store_true", help="strict-identity mode as the HEADLINE: numpy float32 transform + quantiser on a "
+                    "prefetch thread one frame ahead (the default line reports it beside the device transform as `strict_identity`)")
+    ap.add_argument("--no-strict-leg", action="store_true", help="skip the second timed loop in strict-identity mode")
+    ap.add_argument("--decode", action="store_true", help="time the decoder (FrameDecoder) on the configuration's frame instead of the encoder")
     ap.add_argument("--all-configs", action="store_true", help="run every configuration of CONFIGS in turn (child processes), one JSON line each")
     ap.add_argument("--out-dir", default=None, help="with --all-configs: also write <out-dir>/<tag>_bench_<config>.json")
-    ap.add_argument("--tag", default="r3", help="file-name prefix used with --out-dir")
-    return ap.parse_args()
+    ap.add_argument("--tag", default="r4", help="file-name prefix used with --out-dir")
+    a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 3 if a.decode else 24
+    return a
 
 
 def spawn_ranks(n, argv):
@@ -80,125 +96,166 @@ def run_all_configs(args, argv):
     return rc
 
 
-def measure_dominant_kernel(enc, xyz_dev):
-    """Live HIP-event timing over one frame, on the stream the kernels are launched on (torch's current stream, which is where
-    the C ABI launches them): the dominant kernel (gemm_split_kernel, all tile / epilogue variants) and, for the secondary
-    roofline entries, the window attention and the feature-space kNN searches.  ALGORITHMIC flops only."""
+# ------------------------------------------------------------------------------------------------ algorithmic work
+def _swin_layer_flops(L):
+    Lp = -(-L // 512) * 512
+    return Lp * 524288 + L * 1048576 + Lp * 524288          # q|k|v + proj, MLP, attention (QK^T + PV over 512-token windows)
+
+
+def ehem_window_flops(c, attention_only=False):
+    """Algorithmic flop of EHEM.forward on one window of c nodes (ehem.py:88-136): the formula of the survey, on the
+    window's real length.  c = 8192 gives 310.2 GFLOP, of which 40.0 are the attention products."""
+    c = c + (c & 1)
+    att = tot = 0
+    L = c
+    for s, depth in enumerate((4, 4, 4, 4, 2)):             # self encoder
+        Lp = -(-L // 512) * 512
+        tot += depth * _swin_layer_flops(L)
+        att += depth * Lp * 524288
+        if s < 4:
+            tot += 2 * (-(-L // 2)) * 512 * 256
+            L = -(-L // 2)
+    L = c // 2
+    for s, depth in enumerate((2, 2, 1, 1)):                # cross encoder on the odd / even halves
+        Lp = -(-L // 512) * 512
+        tot += depth * _swin_layer_flops(L)
+        att += depth * Lp * 524288
+        if s < 3:
+            tot += 2 * 2 * (-(-L // 2)) * 512 * 256          # both streams are merged
+            L = -(-L // 2)
+    tot += 2 * c * c * (3 + 144 + 192)                                                                  # three kNN searches
+    tot += 2 * 20 * c * (6 * 64 + 288 * 128 + 384 * 256)                                                # edge convolutions
+    tot += c * 2 * (80 * 80 + 80 * 64 + 64 * 64 + 64 * 128 + 2 * 128 * 128 + 448 * 256 + 2 * 256 * 256 + 512 * 256 + 256 * 256 + 256 * 128)
+    tot += c * 2 * (1280 * 1024 + 1024 * 512 + 512 * 256)                                               # ancient_mlp
+    tot += (c // 2) * 2 * (2 * 256 * 256 + 256 * 255 + 256 * 256 + 256 * 240 + 240 * 240 + 3 * 16 * 16 + 1280 * 768 + 768 * 512 + 512 * 255)
+    return att if attention_only else tot
+
+
+def octattn_window_flops(c, attention_only=False):
+    """per layer 5 projections, 3 score / AV products per head (non-causal count), the FFN of both streams; 3 layers + head."""
+    att = 3 * 4 * (2 * c * c * 150) * 3
+    if attention_only:
+        return att
+    return 3 * (5 * 2 * c * 600 * 600 + 2 * 2 * (2 * c * 600 * 300)) + att + 2 * c * (600 * 600 + 600 * 255)
+
+
+def frame_flops(cfg, level_sizes, n_nodes):
+    if cfg["model"] == "EHEM":
+        from scp_amd.encoder import EncodePlan
+        ws = EncodePlan(level_sizes, 8192).windows
+        return float(sum(ehem_window_flops(w[1]) for w in ws)), float(sum(ehem_window_flops(w[1], True) for w in ws))
+    total = n_nodes + 1023
+    full, tail = total // 1024, total % 1024
+    return (float(full * octattn_window_flops(1024) + (octattn_window_flops(tail) if tail else 0)),
+            float(full * octattn_window_flops(1024, True) + (octattn_window_flops(tail, True) if tail else 0)))
+
+
+# ------------------------------------------------------------------------------------------------ live kernel measurement
+KERNEL_OF = {   # launch-bracket tag -> (kernel name as rocprofv3 prints it, bound, note)
+    "post_attn": ("rc_post_attn_kernel", "mfma", "attention projection + residual + LayerNorm + fc1 + GELU + fc2 + residual of a Swin block, one launch"),
+    "ln_linear": ("rc_ln_linear_kernel", "mfma", "LayerNorm + q|k|v projection in one launch, rows resident as MFMA B fragments; keys / values leave as the attention kernel's bf16 planes"),
+    "attention": ("swin_attn_planes_kernel", "mfma", "window attention, K / V tiles staged by LDS-DMA from pre-split planes"),
+    "knn_feat": ("knn_f16x3_wg256_kernel", "mfma", "fused distance + top-20 selection on 144 / 192 features, 256-query workgroups on the XCD-affine schedule"),
+    "knn_pos": ("knn_mfma_kernel<2,16> (positions)", "valu", "exact fp32 chain on 3 features with tile skipping: selection-bound"),
+    "gemm_split": ("gemm_split_kernel", "mfma", "the remaining dense layers (geometry MLPs, concat layers, probability heads; OctAttention: every layer on planes)"),
+    "edge_mlp": ("rc_edge_mlp_kernel", "mfma", "both edge MLPs of the geometry generator, six layers chained through the accumulators"),
+    "merge": ("rc_merge_kernel", "mfma", "patch merging: gather + LayerNorm(512) + reduction"),
+    "gemm_f32": ("gemm_f32_kernel", "mfma_f32", "exact k-ordered fp32 layers feeding a kNN search"),
+    "gemm_rows": ("gemm_bf16x3_kernel", "mfma", "dense layers reading fp32 rows (split in the tile)"),
+    "oa_attention": ("oa_attn_f16x3_kernel", "mfma", "dual-stream causal attention, non-causal flop count (SURVEY.md 8d)"),
+    "edge_gather": ("edge_gather_max_kernel", "hbm", "neighbour gather + max + BN + LeakyReLU"),
+    "cdf": ("cdf_kernel", "hbm", "softmax + serial fp32 cumsum -> (c_low, c_high)"),
+    "split_rows": ("split_rows_kernel", "hbm", "fp32 rows -> hi / lo planes"),
+    "layernorm": ("layernorm_*_kernel", "hbm", "LayerNorm passes left outside the row-chain kernels"),
+    "other": ("(operand preparation)", "hbm", "oa_prep / oa_absmax"),
+}
+
+
+def measure_kernels(run, frames=3):
+    """run() encodes ONE frame synchronously on the current stream.  -> [(tag, ms, work)] in launch order, ms = the launch's minimum over
+    `frames` measured runs (after one untimed run that warms this stream's allocator pool and every lazily built weight cache)."""
     from scp_amd import native
-    recs = {"gemm": [], "attn": [], "knn": [], "mlp": [], "post": [], "lnlin": []}
+    run()
+    torch.cuda.synchronize()
+    recs = []
+    for _ in range(frames):
+        with native.launch_profile() as p:
+            run()
+            torch.cuda.synchronize()
+        recs.append(p.records())
+    tags = [r[0] for r in recs[0]]
+    same = all([r[0] for r in rr] == tags for rr in recs)
+    if not same or any(r[1] < 0 for rr in recs for r in rr):
+        raise RuntimeError("launch brackets: the measured frames did not issue the same launches")
+    ms = np.min(np.asarray([[r[1] for r in rr] for rr in recs], np.float64), 0)
+    return [(t, float(m), r[2]) for t, m, r in zip(tags, ms, recs[0])]
 
-    def ev():
-        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    o_lin, o_att, o_knn, o_mlp = native.linear_split, native.swin_attention_packed, native.knn_topk_packed, native.mlp_split_fused
-    o_post, o_lnlin = native.swin_post_attn, native.swin_ln_linear
-    o_attp, o_lnqkv = native.swin_attention_packed_planes, native.swin_ln_qkv
-
-    def post(o, x, pw, *args, **kw):
-        s, e = ev(); s.record(); y = o_post(o, x, pw, *args, **kw); e.record()
-        recs["post"].append((s, e, 2.0 * x.shape[0] * (256 * 256 + 2 * 256 * 1024)))     # proj + fc1 + fc2
-        return y
-
-    def lnlin(x, fw, *args, **kw):
-        s, e = ev(); s.record(); y = o_lnlin(x, fw, *args, **kw); e.record()
-        recs["lnlin"].append((s, e, 2.0 * x.shape[0] * fw.N * 256))
-        return y
-
-    def lnqkv(x, fw, *args, **kw):                  # the same projection with the keys / values leaving as attention planes
-        s, e = ev(); s.record(); y = o_lnqkv(x, fw, *args, **kw); e.record()
-        recs["lnlin"].append((s, e, 2.0 * x.shape[0] * fw.N * 256))
-        return y
-
-    def attp(q, *args, **kw):                       # plane-fed form of the window attention: same flops
-        s, e = ev(); s.record(); y = o_attp(q, *args, **kw); e.record()
-        recs["attn"].append((s, e, q.shape[0] * 2.0 * 2.0 * 512 * 256))
-        return y
-
-    def lin(a, sw, *args, **kw):
-        s, e = ev(); s.record(); y = o_lin(a, sw, *args, **kw); e.record()
-        recs["gemm"].append((s, e, 2.0 * a.M * sw.N * sw.K))
-        return y
-
-    def att(q, *args, **kw):
-        s, e = ev(); s.record(); y = o_att(q, *args, **kw); e.record()
-        recs["attn"].append((s, e, q.shape[0] * 2.0 * 2.0 * 512 * 256))      # per row: QK^T and PV over 512 keys x 256 channels
-        return y
-
-    def knn(x, ktab):
-        s, e = ev(); s.record(); y = o_knn(x, ktab); e.record()
-        n = ktab[:, 1].double()
-        recs["knn"].append((s, e, float((n * 512).sum().item()) * 2.0 * max(4, x.shape[1]), x.shape[1]))   # sum over 512-row chunks of n * 512 pairs
-        return y
-
-    def mlp(a, *args, **kw):
-        s, e = ev(); s.record(); y = o_mlp(a, *args, **kw); e.record()
-        recs["mlp"].append((s, e, 2.0 * a.M * 256 * 1024 * 2))              # fc1 + fc2
-        return y
-
-    native.linear_split, native.swin_attention_packed, native.knn_topk_packed, native.mlp_split_fused = lin, att, knn, mlp
-    native.swin_post_attn, native.swin_ln_linear = post, lnlin
-    native.swin_attention_packed_planes, native.swin_ln_qkv = attp, lnqkv
-    try:
-        enc.encode(xyz_dev)
-        torch.cuda.synchronize()
-    finally:
-        native.linear_split, native.swin_attention_packed, native.knn_topk_packed, native.mlp_split_fused = o_lin, o_att, o_knn, o_mlp
-        native.swin_post_attn, native.swin_ln_linear = o_post, o_lnlin
-        native.swin_attention_packed_planes, native.swin_ln_qkv = o_attp, o_lnqkv
-
-    def summ(rs):
-        ms = sum(r[0].elapsed_time(r[1]) for r in rs)
-        fl = sum(r[2] for r in rs)
-        return dict(launches=len(rs), avg_launch_us=1e3 * ms / max(1, len(rs)), flops_per_launch=fl / max(1, len(rs)),
-                    tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, total_ms=ms)
-    # dominant kernel: the post-attention row-chain kernel when the Swin blocks run on it (default), else the split GEMM of rounds 1 - 2
-    out = summ(recs["post"]) if recs["post"] else summ(recs["gemm"])
-    out["dominant"] = "post" if recs["post"] else "gemm"
-    out["gemm"] = summ(recs["gemm"])
-    out["lnlin"] = summ(recs["lnlin"])
-    out["attn"] = summ(recs["attn"])
-    out["mlp"] = summ(recs["mlp"])
-    out["knn_feat"] = summ([r for r in recs["knn"] if r[3] > 4])
-    out["knn_pos"] = summ([r for r in recs["knn"] if r[3] <= 4])
+def knn_pairs(enc, level_sizes):
+    """Pair count of every packed kNN launch of a frame, in launch order (one per chunk of <= max_tokens tokens): the sum over 512-row
+    chunks of n x 512 for the window they belong to (n = the window's even-padded length)."""
+    from scp_amd.encoder import EncodePlan
+    plan = EncodePlan(level_sizes, enc.context_size)
+    out = []
+    ws, i = plan.windows, 0
+    while i < len(ws):
+        j, tok, pairs = i, 0, 0
+        while j < len(ws) and (tok == 0 or tok + ws[j][1] <= enc.max_tokens):
+            n = ws[j][1] + (ws[j][1] & 1)
+            pairs += (-(-n // 512)) * 512 * n
+            tok += ws[j][1]
+            j += 1
+        out.append(float(pairs))
+        i = j
     return out
 
 
-def measure_dominant_kernel_octattn(enc, xyz_dev):
-    """Same for the OctAttention path: its dense layers (f16x3 split GEMM) and the dual-stream causal attention."""
-    from scp_amd import native
-    recs = {"gemm": [], "attn": []}
-
-    def ev():
-        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
-    o_lin, o_att = native.linear_f16x3, native.octattn_attention
-
-    def lin(x, sw, *args, **kw):
-        s, e = ev(); s.record(); y = o_lin(x, sw, *args, **kw); e.record()
-        recs["gemm"].append((s, e, 2.0 * (x.numel() // sw.K) * sw.N * sw.K))
-        return y
-
-    def att(q_u, *args, **kw):
-        s, e = ev(); s.record(); y = o_att(q_u, *args, **kw); e.record()
-        B, c, D = q_u.shape
-        recs["attn"].append((s, e, B * 3.0 * 2.0 * c * c * D))       # SURVEY.md 8d: heads x (2 c^2 150) x 3 score / AV products per layer
-        return y
-
-    native.linear_f16x3, native.octattn_attention = lin, att
-    try:
-        enc.encode(xyz_dev)
-        torch.cuda.synchronize()
-    finally:
-        native.linear_f16x3, native.octattn_attention = o_lin, o_att
-
-    def summ(rs):
-        ms = sum(r[0].elapsed_time(r[1]) for r in rs)
-        fl = sum(r[2] for r in rs)
-        return dict(launches=len(rs), avg_launch_us=1e3 * ms / max(1, len(rs)), flops_per_launch=fl / max(1, len(rs)),
-                    tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, total_ms=ms)
-    out = summ(recs["gemm"])
-    out["attn"] = summ(recs["attn"])
+def summarise(records, pairs=None):
+    """per tag: launches, total ms, algorithmic work, average launch, achieved rate"""
+    out = {}
+    kn = {"knn_feat": 0, "knn_pos": 0}
+    for tag, ms, work in records:
+        if tag in kn and pairs is not None:
+            per_chunk = 2 if tag == "knn_feat" else 1              # launches of this tag per chunk (144 + 192 features | positions)
+            work = 2.0 * work * pairs[min(kn[tag] // per_chunk, len(pairs) - 1)]
+            kn[tag] += 1
+        d = out.setdefault(tag, dict(launches=0, total_ms=0.0, work=0.0))
+        d["launches"] += 1
+        d["total_ms"] += ms
+        d["work"] += work
+    for tag, d in out.items():
+        d["avg_launch_us"] = 1e3 * d["total_ms"] / d["launches"]
+        d["work_per_launch"] = d["work"] / d["launches"]
+        d["rate"] = d["work"] / (d["total_ms"] * 1e-3) if d["total_ms"] > 0 else 0.0       # flop/s or B/s
     return out
+
+
+def roofline_entry(tag, d):
+    name, bound, note = KERNEL_OF.get(tag, (tag, "hbm", ""))
+    peak3 = BF16_MFMA_PEAK_TFLOPS / 3.0
+    e = dict(kernel=name, bound="mfma" if bound.startswith("mfma") else bound, launches_per_frame=d["launches"], avg_launch_us=d["avg_launch_us"],
+             total_ms_per_frame=d["total_ms"], note=note)
+    if bound == "mfma":
+        e.update(achieved=d["rate"] / 1e12, peak=peak3, unit="TFLOP/s", frac=d["rate"] / 1e12 / peak3, flops_per_launch=d["work_per_launch"])
+    elif bound == "mfma_f32":
+        e.update(achieved=d["rate"] / 1e12, peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=d["rate"] / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                 flops_per_launch=d["work_per_launch"])
+    elif bound == "hbm":
+        e.update(achieved=d["rate"] / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=d["rate"] / 1e9 / HBM_PEAK_GBS, bytes_per_launch=d["work_per_launch"])
+    return e
+
+
+def pmc_traffic(config):
+    """(HBM bytes per launch of the dominant kernel, HBM bytes per frame, source) from the committed PMC passes - only for the
+    configuration they were collected on."""
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as f:
+            z = json.load(f)
+        if z.get("config") != config:
+            return None, None, None
+        return z.get("dominant_hbm_bytes_per_launch"), z.get("frame_hbm_bytes"), f"profiles/{PMC_PROFILE} (separate rocprofv3 --pmc passes over this configuration's frame; not measured by this run)"
+    except Exception:
+        return None, None, None
 
 
 def cpu_baseline(cfg, xyz, full=False):
@@ -221,7 +278,7 @@ def cpu_baseline(cfg, xyz, full=False):
         sd = fill_weights(OctAttention(octattn_cfg()), 0).state_dict()
         r = cpu_encode.encode_frame_octattn(xyz, sd, cfg["level"], mode=cfg["mode"], full_window_runs=runs)
     what = (f"one whole frame, all {r['windows']} windows run" if full else
-            f"one frame: quantiser/octree/records/context of the whole frame, all {r['partial_windows']} partial windows, "
+            f"SAMPLED: one frame: quantiser/octree/records/context of the whole frame, all {r['partial_windows']} partial windows, "
             f"{r['full_windows_run']} of the {r['full_windows']} full windows (first = warm-up, the fastest of the rest x {r['full_windows']}), "
             f"CDF + range coder on the {r['rows_coded']} rows produced, scaled to {r['n_nodes']} nodes")
     return dict(value=1.0 / r["total_s"], unit="frames/s", cores=threads, kind="port", sample=what, seconds_per_frame=r["total_s"],
@@ -244,6 +301,83 @@ CONFIGS = {
     "octattn-L14-cylin": dict(model="OctAttention", level=14, mullevel=False, mode="cylin",
                               workload="SCP-OctAttention KITTI-like synthetic 120k-pt frames, --cylin lidar_level=14 (BASELINE.json configs[4])"),
 }
+
+
+class IntsAhead:
+    """Strict-identity front end of the bench loop: enc.host_ints (the reference's numpy float32 transform + quantiser,
+    data_preprocess.py:42-70,171-214) of frame i + 1 ... i + ahead on ONE worker thread while frame i is enqueued - what cli.py does with
+    `Prefetch(post=enc.host_ints)`.  All of it inside the timed region."""
+
+    def __init__(self, enc, frames_host, lo, hi, ahead=2):
+        from concurrent.futures import ThreadPoolExecutor
+        self.enc, self.frames, self.hi, self.ahead = enc, frames_host, hi, ahead
+        self.pool = ThreadPoolExecutor(max_workers=1)
+        self.futs, self.next = {}, lo
+
+    def get(self, i):
+        while self.next < self.hi and self.next <= i + self.ahead:
+            self.futs[self.next] = self.pool.submit(self.enc.host_ints, self.frames[self.next])
+            self.next += 1
+        return self.futs.pop(i).result()
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+
+def differing_points(enc, cfg, dev):
+    """Seed-0 frame: points whose quantised integers differ from the REFERENCE's (tests/golden/frame_ints.npz, produced by running the
+    reference's proc_pc here): host transform (must be 0) and device transform, per shell."""
+    name = {"spher": "q_spher_L", "cylin": "q_cylin_L", "cart": "q_cart_L"}[cfg["mode"]]
+    path = os.path.join(ROOT, "tests", "golden", "frame_ints.npz")
+    if cfg.get("type") == "ford" or not os.path.exists(path):
+        return None
+    z = np.load(path)
+    from scp_amd.synth import synth_frame
+    xyz = synth_frame(0)
+    keys = [f"{name}{lv}" for _, lv in enc.shells()]
+    if any(k not in z.files for k in keys):
+        return None
+    hq, _ = enc.host_ints(xyz)
+    host = [int((np.asarray(q) != z[k]).any(1).sum()) for q, k in zip(hq, keys)]
+    dq = enc.quantize(torch.from_numpy(xyz).to(dev))[0] if not enc.host_transform else None
+    devc = None if dq is None else [int((q.cpu().numpy() != z[k]).any(1).sum()) for q, k in zip(dq, keys)]
+    return dict(host_transform=host, device_transform=devc, reference="tests/golden/frame_ints.npz (the reference's proc_pc run on this frame)")
+
+
+def run_decode(args, cfg, enc, model, dev, frame_host):
+    """`--decode`: FrameDecoder on the stream of the configuration's frame (decode_ehem_mullevel.py:56-189)."""
+    from scp_amd.decoder import FrameDecoder
+    res = enc.encode(frame_host)
+    nodes = enc.geom.nodes(("occ",))["occ"]
+    want = [nodes[i.node_base:i.node_base + i.n_nodes].cpu().numpy() for i in enc.geom.info]
+    dec = FrameDecoder(model, cfg["level"], mullevel=cfg["mullevel"], polar=cfg["mode"] != "cart", device=dev)
+    ok = True
+    for i in range(args.warmup):
+        shells = dec.decode(res["bytes"], res["n_levels"], res["pos_mm"])
+    torch.cuda.synchronize()
+    cpu0, t0 = time.process_time(), time.perf_counter()
+    for i in range(args.steps):
+        shells = dec.decode(res["bytes"], res["n_levels"], res["pos_mm"])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps
+    for (codes, _), w in zip(shells, want):
+        got = torch.cat(codes).cpu().numpy()
+        ok = ok and len(got) == len(w) and (np.array_equal(got[:-1], w[:-1]) if cfg["mullevel"] else np.array_equal(got, w))
+    from scp_amd.encoder import EncodePlan
+    ws = EncodePlan(res["level_sizes"], 8192).windows
+    with_phase2 = sum(1 for w in ws if w[1] > 1)
+    stats = getattr(dec, "stats", None)
+    out = {"metric": f"KITTI frames/sec decode (SCP-EHEM, level {cfg['level']}{' multi-level' if cfg['mullevel'] else ''})", "value": args.steps / dt,
+           "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32 (same kernels and numeric profile as the encoder)", "data": "synthetic",
+           "config": {"workload": cfg["workload"] + ", seeded random weights; DECODER", "nodes_per_frame": int(res["n_nodes"]), "windows_per_frame": len(ws),
+                      "levels": len(res["level_sizes"]), "phase1_launch_sequences_per_frame": len(res["level_sizes"]),
+                      "phase2_launch_sequences_per_frame": with_phase2},
+           "decoded_occupancy_equals_encoded": bool(ok), "host_cpu_ms_per_frame": cpu_ms, "stream_bytes": len(res["bytes"])}
+    if stats:
+        out["stage_ms"] = {k: round(1e3 * v / (args.steps + args.warmup), 3) for k, v in stats.items()}
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -283,7 +417,7 @@ def main():
     if ehem:
         model = fill_weights(EHEM(ehem_cfg()), 0).to(dev)
         enc = FrameEncoder(model, cfg.get("type", "kitti"), cfg["level"], spher=cfg["mode"] == "spher", cylin=cfg["mode"] == "cylin",
-                           mullevel=cfg["mullevel"], device=dev, host_transform=True if args.host_transform else None)
+                           mullevel=cfg["mullevel"], device=dev, host_transform=False)
     else:
         model = fill_weights(OctAttention(octattn_cfg()), 0).to(dev)
         enc = OctAttnFrameEncoder(model, "kitti", cfg["level"], spher=cfg["mode"] == "spher", cylin=cfg["mode"] == "cylin", device=dev,
@@ -294,6 +428,10 @@ def main():
     from scp_amd.synth import ford_like
     if cfg.get("type") == "ford":
         frames_host = [ford_like(f) for f in frames_host]
+    if args.decode:
+        if not ehem or world > 1:
+            raise SystemExit("--decode: the EHEM configurations, one GPU")
+        return run_decode(args, cfg, enc, model, dev, frames_host[0])
     frames = [torch.from_numpy(f).to(dev) for f in frames_host]      # resident in HBM before the timed region
     torch.cuda.synchronize()
 
@@ -305,34 +443,54 @@ def main():
     batch = args.batch if args.batch is not None else (4 if args.config == "ehem-L12-s" else 1)
     if batch > 1 and not ehem:
         raise SystemExit("--batch is an EHEM option")
+
+    def timed_loop(strict):
+        """`--steps` frames through the pipelined encoder; strict: the reference's host transform one frame ahead on a worker thread.
+        -> (dt of this rank before the barrier, dt after it, host CPU ms per frame, results)"""
+        ahead = IntsAhead(enc, frames_host, args.warmup, total) if strict else None
+        barrier()
+        cpu0 = time.process_time()                      # CPU seconds of this rank, all threads (launch thread, coder worker, reader)
+        t0 = time.perf_counter()
+        # frame i is range-coded on a worker thread while frames i+1 .. i+depth run on the GPU; a handle pins its ~590 MB logits table,
+        # so at most `depth` frames are in flight (memory stays O(depth), not O(steps))
+        pending, results = [], []
+        if batch > 1 and not strict:      # `batch` frames per launch sequence, two batches in flight (the range coder of one under the kernels of the next)
+            for i in range(args.warmup, total, batch):
+                pending.append(enc.encode_batch_async(frames[i:min(total, i + batch)]))
+                if len(pending) > 1:
+                    results += enc.finish_batch(pending.pop(0))
+            for h in pending:
+                results += enc.finish_batch(h)
+        else:
+            for i in range(args.warmup, total):
+                pending.append(enc.encode_async(frames[i], ints=ahead.get(i)) if strict else enc.encode_async(frames[i]))
+                if len(pending) > args.depth:
+                    results.append(enc.finish(pending.pop(0)))
+            results += [enc.finish(h) for h in pending]
+        torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0               # this rank's own time for its frames (before the barrier)
+        cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps
+        barrier()
+        dt = time.perf_counter() - t0
+        if ahead:
+            ahead.close()
+        return dt_own, dt, cpu_ms, results
+
     for i in range(args.warmup):
         enc.finish(enc.encode_async(frames[i]))
     if batch > 1:
         enc.finish_batch(enc.encode_batch_async(frames[:batch]))
-    barrier()
-    cpu0 = time.process_time()                      # CPU seconds of this rank, all threads (launch thread, coder worker, reader)
-    t0 = time.perf_counter()
-    # frame i is range-coded on a worker thread while frames i+1 .. i+depth run on the GPU; a handle pins its ~590 MB logits table,
-    # so at most `depth` frames are in flight (memory stays O(depth), not O(steps))
-    pending, results = [], []
-    if batch > 1:      # `batch` frames per launch sequence, two batches in flight (the range coder of one under the kernels of the next)
-        for i in range(args.warmup, total, batch):
-            pending.append(enc.encode_batch_async(frames[i:min(total, i + batch)]))
-            if len(pending) > 1:
-                results += enc.finish_batch(pending.pop(0))
-        for h in pending:
-            results += enc.finish_batch(h)
-    else:
-        for i in range(args.warmup, total):
-            pending.append(enc.encode_async(frames[i]))
-            if len(pending) > args.depth:
-                results.append(enc.finish(pending.pop(0)))
-        results += [enc.finish(h) for h in pending]
-    torch.cuda.synchronize()
-    dt_own = time.perf_counter() - t0               # this rank's own time for its frames (before the barrier)
-    cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps
-    barrier()
-    dt = time.perf_counter() - t0
+    headline_strict = bool(args.host_transform) and ehem
+    dt_own, dt, cpu_ms, results = timed_loop(headline_strict)
+    strict = None
+    if ehem and world == 1 and not args.no_strict_leg and not headline_strict:
+        # the same frames once more with the reference's own float -> integer step (numpy, on a worker thread one frame ahead): what the
+        # strict-identity mode costs when it is overlapped the way cli.py overlaps it.  Per-frame launches (no --batch form).
+        s_own, s_dt, s_cpu, s_res = timed_loop(True)
+        strict = dict(fps=args.steps / s_dt, ms_per_step=1e3 * s_dt / args.steps, host_cpu_ms_per_frame=s_cpu,
+                      ratio_to_device_transform=(args.steps / s_dt) / (args.steps / dt), bpp_mean=float(np.mean([r["bpp"] for r in s_res])),
+                      note="enc.host_ints (numpy float32 transform + quantiser of data_preprocess.py:42-70,171-214) on one worker thread one to two "
+                           "frames ahead, inside the timed region; everything after the integers on the device as in the headline")
     rank_stats = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -359,19 +517,27 @@ def main():
         peak3 = BF16_MFMA_PEAK_TFLOPS / 3.0
         bytes_G = 12 * P + 25 * n_nodes            # SURVEY.md §8d algorithmic bytes of stage G
         bytes_C = n_nodes * (255 * 4 + 4)
-        traffic = traffic_src = None
+        level_sizes = results[-1]["level_sizes"]
+        # ---- live kernel measurement on the caller's stream (single stream: a bracket never spans another lane's kernel)
+        recs = measure_kernels(lambda: enc.encode(frames[-1]))
+        per_tag = summarise(recs, knn_pairs(enc, level_sizes) if ehem else None)
+        # per-stage wall times of the same frame with a device sync after every stage: the faster of two runs
         if ehem:
-            dom = measure_dominant_kernel(enc, frames[-1])
-            st = enc.encode(frames[-1], timing=True)["times"]     # per-stage wall times with a device sync after every stage
-            key = "rc_post_attn_kernel" if dom["dominant"] == "post" else "gemm_split_all_variants"
-            for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1z_pmc_traffic.json"):   # HBM bytes per launch from the committed PMC passes
-                try:
-                    with open(os.path.join(ROOT, "profiles", name)) as f:
-                        traffic = json.load(f)[key]["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/" + name + " (separate rocprofv3 --pmc passes over the same frame; not measured by this run)"
-                    break
-                except Exception:
-                    pass
+            st = min((enc.encode(frames[-1], timing=True)["times"] for _ in range(2)), key=lambda t: t["total"])
+        else:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); enc.encode(frames[-1]); torch.cuda.synchronize()
+            st = {"total": time.perf_counter() - t0}
+        model_tags = [t for t in per_tag if t not in ("cdf", "geom")]
+        kernel_ms = sum(per_tag[t]["total_ms"] for t in model_tags)
+        ref_ms = 1e3 * (st["model"] if ehem else st["total"])
+        valid = kernel_ms <= 1.02 * ref_ms
+        dom_tag = max((t for t in per_tag if KERNEL_OF.get(t, ("", ""))[1] == "mfma"), key=lambda t: per_tag[t]["total_ms"])
+        dom = roofline_entry(dom_tag, per_tag[dom_tag])
+        traffic, frame_bytes, traffic_src = pmc_traffic(args.config)
+        fl_total, fl_att = frame_flops(cfg, level_sizes, n_nodes)
+        ms_step = 1e3 * dt / args.steps
+        if ehem:
             metric = "KITTI frames/sec encode (SCP-EHEM, level 16) + bpp match vs ref"
             if args.config == "ehem-F17-m":
                 metric = "Ford-like frames/sec encode (SCP-EHEM, level 17 multi-level) + bpp match vs ref"
@@ -379,58 +545,58 @@ def main():
                 metric = f"KITTI frames/sec encode (SCP-EHEM, level {cfg['level']} same-level) + bpp match vs ref"
             dtype = ("f32 (dense layers and attention as bf16x3 split on bf16 MFMA, feature kNN as f16x3 split on f16 MFMA, fp32 accumulate; "
                      "position kNN / CDF in fp32)")
-            kernel = ("rc_post_attn_kernel (attention projection + residual + LayerNorm + fc1 + GELU + fc2 + residual of a Swin block in one launch, "
-                      "accumulators chained through registers: 3x v_mfma_f32_32x32x16_bf16 per fp32-class product)" if dom["dominant"] == "post" else
-                      "gemm_split_kernel (dense layers, both operands pre-split: 3x v_mfma_f32_32x32x16_bf16 per fp32-class product)")
-            windows = len(EncodePlan(results[-1]["level_sizes"], 8192).windows)
+            windows = len(EncodePlan(level_sizes, 8192).windows)
         else:
-            dom = measure_dominant_kernel_octattn(enc, frames[-1])
-            st = {"total": enc.encode(frames[-1])["times"]["total"]}
             metric = f"KITTI frames/sec encode (SCP-OctAttention, level {cfg['level']} --{cfg['mode']})"
             dtype = "f32 (dense layers and attention as f16x3 split on f16 MFMA with power-of-two row scales, fp32 accumulate; CDF in fp32)"
-            kernel = "gemm_bf16x3_kernel<ACT, F16=true> (OctAttention dense layers: 3x v_mfma_f32_32x32x16_f16 per fp32-class product)"
             windows = -(-(n_nodes + 1023) // 1024)
         out = {
             "metric": metric,
             "value": world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": cfg["workload"] + ", seeded random weights", "nodes_per_frame": int(n_nodes), "windows_per_frame": windows,
-                       "frames_per_gpu": args.steps, "frames_in_flight": args.depth if batch == 1 else 2 * batch, "frames_per_launch_sequence": batch, "transform": "host-numpy (strict identity)" if enc.host_transform else "device", "parallelism": f"frame-sharded x{world}",
-                       "rank_cores": len(pinned) if pinned else None},
+                       "frames_per_gpu": args.steps, "frames_in_flight": args.depth if batch == 1 else 2 * batch, "frames_per_launch_sequence": batch,
+                       "transform": "host-numpy on a prefetch thread (strict identity)" if (headline_strict or enc.host_transform) else "device",
+                       "parallelism": f"frame-sharded x{world}", "rank_cores": len(pinned) if pinned else None},
             "rccl_world": dist.get_world_size() if world > 1 else 1, "dist_backend": backend if world > 1 else None,
             "host_cpu_ms_per_frame": cpu_ms,
             "bpp_mean": float(summ[0] / summ[4]),
             "stage_ms": {k: round(1e3 * v, 3) for k, v in st.items()},
-            # dominant kernel: the x3-split dense layer.  `achieved` counts ALGORITHMIC flops (2*M*N*K of the fp32 product it
-            # replaces); the kernel spends three 16-bit MFMAs per product, so its own ceiling is a third of the dense 16-bit peak.
-            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": dom["tflops"], "peak": peak3, "unit": "TFLOP/s", "frac": dom["tflops"] / peak3,
+            # dominant kernel = the MFMA-bound kernel with the most time per frame.  `achieved` counts ALGORITHMIC flops (2*M*N*K of the fp32
+            # product it replaces); a split kernel spends three 16-bit MFMAs per product, so its own ceiling is a third of the dense 16-bit peak.
+            "roofline": {"bound": "mfma", "kernel": dom["kernel"] + ": " + dom["note"] + " (3x v_mfma_f32_32x32x16 per fp32-class product)",
+                         "achieved": dom["achieved"], "peak": peak3, "unit": "TFLOP/s", "frac": dom["frac"],
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "valid": bool(valid), "kernel_ms_sum": kernel_ms, "kernel_ms_bound": ref_ms,
+                         "validity_rule": "event-timed kernels of one frame (per-launch minimum over 3 frames) must sum to <= 1.02 x the synchronised wall "
+                                          "time of the same frame's model stage; false = do not use these fractions",
+                         "method": "hipEvents recorded inside libscp_hip.so around each launch (include/scp_debug.h), allocator-warm stream, per-launch minimum of 3 frames",
                          "peak_note": "2500 TFLOP/s dense 16-bit MFMA / 3 products; the fp32 MFMA peak this replaces is 157.3.  With all 256 CUs multiplying the clock settles at 1.85 GHz (tools/src/mb_power.cpp): 1.95 PFLOP/s sustained, 650 per fp32-class product",
-                         "launches_per_frame": dom["launches"], "avg_launch_us": dom["avg_launch_us"], "flops_per_launch": dom["flops_per_launch"]},
+                         "launches_per_frame": dom["launches_per_frame"], "avg_launch_us": dom["avg_launch_us"], "flops_per_launch": dom["flops_per_launch"]},
+            # the whole frame against both roofs: algorithmic flop of what the reference's window loop computes (encode_mullevel.py:106-133;
+            # SURVEY.md 8d formulas on the frame's real window lengths) / the bench's own ms_per_step
+            "roofline_frame": {"flops": fl_total, "attention_flops": fl_att, "achieved_tflops": fl_total / (ms_step * 1e-3) / 1e12 / world,
+                               "peak_tflops": peak3, "frac_mfma": fl_total / (ms_step * 1e-3) / 1e12 / world / peak3,
+                               "hbm_bytes": frame_bytes, "achieved_gbs": None if frame_bytes is None else frame_bytes / (ms_step * 1e-3) / 1e9 / world,
+                               "frac_hbm": None if frame_bytes is None else frame_bytes / (ms_step * 1e-3) / 1e9 / world / HBM_PEAK_GBS,
+                               "note": "per GPU; flops priced against 2500 / 3 TFLOP/s as if every product were a three-MFMA split; hbm_bytes from " + (traffic_src or "no PMC pass for this configuration")},
+            "roofline_kernels": {KERNEL_OF.get(t, (t,))[0]: roofline_entry(t, per_tag[t]) for t in sorted(per_tag, key=lambda t: -per_tag[t]["total_ms"])},
+            "launches_bracketed_per_frame": len(recs),
         }
-
-        def entry(d, **kw):
-            return dict(bound="mfma", achieved=d["tflops"], peak=peak3, unit="TFLOP/s", frac=d["tflops"] / peak3, launches_per_frame=d["launches"],
-                        avg_launch_us=d["avg_launch_us"], **kw)
         if ehem:
-            # secondary kernels, same convention; the position search (3 features) is selection-bound, its MFMA share is negligible
-            out["roofline_kernels"] = {
-                "rc_ln_linear_kernel": entry(dom["lnlin"], note="LayerNorm + q|k|v projection in one launch, rows resident as MFMA B fragments; keys / values leave as the attention kernel's bf16 planes"),
-                "gemm_split_kernel": entry(dom["gemm"], note="the remaining dense layers (geometry MLPs, patch merges, concat layers, probability heads)"),
-                "mlp_fused_kernel": entry(dom["mlp"], note="fc1 + GELU + fc2 + residual of a Swin block in one launch, hidden activation in LDS (SCP_SWIN=split only)"),
-                "swin_attn_planes_kernel": entry(dom["attn"], note="window attention, K / V tiles staged by LDS-DMA from pre-split planes (SCP_ATTN_KV=rows: swin_attn_bf16x3_kernel)"),
-                "knn_f16x3_wg256_kernel": entry(dom["knn_feat"], note="fused distance + top-20 selection, 256-query workgroups on the XCD-affine schedule; every phase of a wave is latency-bound (DESIGN.md 4.5), L2-miss traffic 2.0 GB per launch"),
-                "knn_mfma_kernel<2,16> (positions)": {"bound": "valu", "launches_per_frame": dom["knn_pos"]["launches"],
-                                                      "avg_launch_us": dom["knn_pos"]["avg_launch_us"]}}
-            out["roofline_kernels"] = {k: v for k, v in out["roofline_kernels"].items() if v.get("launches_per_frame", 1)}   # kernels this configuration never launched
             out["roofline_stages"] = {
                 "G": {"bound": "hbm", "achieved": bytes_G / st["geom"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": bytes_G / st["geom"] / 1e9 / HBM_PEAK_GBS, "bytes": bytes_G, "note": "host wall time of the whole stage incl. its small D2H syncs"},
                 "C": {"bound": "hbm", "achieved": bytes_C / st["cdf"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": bytes_C / st["cdf"] / 1e9 / HBM_PEAK_GBS, "bytes": bytes_C, "note": "includes the 4 B/node D2H copy"}}
-        else:
-            out["roofline_kernels"] = {"oa_attn_f16x3_kernel": entry(dom["attn"], note="dual-stream causal attention, non-causal flop count (SURVEY.md 8d)")}
+            if strict is not None:
+                out["strict_identity"] = strict
+                out["strict_identity_fps"] = strict["fps"]
+            try:
+                out["transform_parity"] = differing_points(enc, cfg, dev)
+            except Exception as e:
+                out["transform_parity"] = {"error": str(e)}
         if rank_stats:
             fps = [r["fps"] for r in rank_stats]
             cpu = [r["host_cpu_ms_per_frame"] for r in rank_stats]

@@ -36,8 +36,11 @@ extern "C" {
  *        row-chain entry points) reads its weight planes in the TILED layout of scp_tile_weight_bf16; planes straight out of
  *        scp_split_weight_bf16 / scp_split_weight_f16 (the version-100 contract) give SCP_OK and wrong products.  Pass every plane
  *        through scp_tile_weight_bf16 once, or load the library with SCP_WTILE=0 in the environment for the row-major contract;
- *        the process-wide numeric-profile setters and the debug hooks moved to scp_debug.h, scp_ctx replaces the setters. */
-#define SCP_ABI_VERSION 200
+ *        the process-wide numeric-profile setters and the debug hooks moved to scp_debug.h, scp_ctx replaces the setters.
+ *   210  scp_mlp_split_fused is gone (round 4: the Swin blocks run on scp_swin_ln_linear / scp_swin_post_attn, which supersede it; two
+ *        scp_linear_split calls give its bits); scp_geom_build takes float xyz through scp_geom_build_xyz as well (stage G in one
+ *        launch sequence); scp_debug.h gained the launch brackets scp_prof_*. */
+#define SCP_ABI_VERSION 210
 SCP_API int scp_version(void);
 SCP_API int scp_last_hip_error(void);
 /* number of HIP devices visible / name of device 0 (for bench reports) */
@@ -245,7 +248,7 @@ SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, int64_t lda, 
  * columns K..Kpad zero) written by the producing kernel (scp_split_rows, scp_layernorm_rows_split, the attention kernels, or this
  * function's own split output), so operand tiles go global -> LDS by LDS-DMA with no conversion.  Outputs: C fp32 [M][ldc]
  * and/or planes Ohi/Olo [M][ldo] (columns N..round32(N) zero filled).  Weight planes must be padded to Npad % 256 == 0 and are
- * expected in the TILED layout of scp_tile_weight_bf16 (all scp_linear_split* entry points and scp_mlp_split_fused; the environment
+ * expected in the TILED layout of scp_tile_weight_bf16 (all scp_linear_split* entry points and the row-chain entry points; the environment
  * variable SCP_WTILE=0 switches the library to row-major [Npad][Kpad] planes, for A/B measurements).
  * cfg: 0 automatic, 1 = 256 x 256 tile, 2 = 256 x 128 tile.  Results are bit-identical to scp_linear_bf16x3 on the same values.
  *   scp_split_rows: fp32 rows -> planes, optionally gathered: out[r] = split(src[idx ? idx[r] : r]); idx == n_src -> zero row */
@@ -253,13 +256,6 @@ SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_t lda, cons
                      const float *bias, const float *residual, int64_t ldr, float *C, int64_t ldc, void *Ohi, void *Olo, int64_t ldo,
                      int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream);
 
-/* The MLP of a Swin block in one launch: C = GELU(X . W1^T + b1) . W2^T + b2 + residual with X as bf16 hi/lo planes [M][ldx]
- * (256 columns), W1 planes [1024][256], W2 planes [256][1024] (scp_split_weight_bf16), fp32 C [M][ldc].  The 1024-wide hidden
- * activation stays in LDS (intermediate.dense + GELU + output.dense + residual, swin_transformer.py:559-571); bit-identical to
- * scp_linear_split (act 2, split output) followed by scp_linear_split (residual). */
-SCP_API int scp_mlp_split_fused(const void *Xhi, const void *Xlo, int64_t ldx, const void *W1hi, const void *W1lo, const void *W2hi,
-                                const void *W2lo, const float *b1, const float *b2, const float *residual, int64_t ldr, float *C,
-                                int64_t ldc, int32_t M, void *stream);
 /* scp_linear_split with a GATHERED residual added BEFORE the activation: out[m] = act(A[m].W^T + bias + residual[res_map[m]])
  * (res_map may be NULL = identity).  Used to evaluate a layer over concat_states (ehem.py:75-86) as one product per Swin stage. */
 SCP_API int scp_linear_split_gather(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,

@@ -24,15 +24,47 @@ SCP_API int scp_set_knn_workgroup(int32_t shape);
 /* with a device buffer of (blocks * 8 * 4) u64 set, the K = 192 search of shape 256 runs its cycle-stamped build and writes per
  * wave [cycles at barrier + DMA issue, in the MFMA block, in the selection, tiles]; NULL (default) = the product kernel */
 SCP_API int scp_knn_debug_buffer(unsigned long long *dev_buf);
-/* the same for scp_mlp_split_fused: (workgroups * 8 * 8) u64, per wave [cycles at barriers, phase-1 products, GELU + split, phase-2
- * products, epilogue, row tiles, -, -] */
-SCP_API int scp_mlp_debug_buffer(unsigned long long *dev_buf);
 /* the same for the row-chain kernels (scp_swin_ln_linear / scp_swin_post_attn): (workgroups * 4 * 8) u64, per wave the cycle sums of
  * the kernel's phases and its tile count (tools/mb_rowchain_probe.py, tools/mb_postattn.py) */
 SCP_API int scp_rc_debug_buffer(unsigned long long *dev_buf);
 /* persistent workgroups of the row-chain launches (0 = one per CU of the device): for launches on a stream created with a CU mask
  * (tools/mb_cumask.py), whose CU set is smaller than the device's */
 SCP_API int scp_rc_set_grid(int32_t workgroups);
+
+/* ---- launch brackets: HIP events recorded INSIDE the C ABI, directly around a kernel launch, on the stream it is launched on ----
+ * While enabled, every bracketed entry point records one hipEvent immediately before and one immediately after its main kernel
+ * launch (no host code of the caller lies between the two records: what the pair measures is the kernel, plus the few microseconds
+ * between the two host-side enqueues when the stream's queue is empty).  bench.py builds its live `roofline` from these records; the
+ * rocprofv3 --kernel-trace summary of the same command must agree (profiles/).  A record carries the ALGORITHMIC work of the launch
+ * as DESIGN.md prices it: flop for the MFMA-bound kernels (2 M N K of the fp32 product a split kernel stands for), bytes for the
+ * HBM-bound ones; the kNN searches record their feature count C (the pair count - the sum over 512-row chunks of n x 512 - lives in a
+ * device table only the caller can price: flop = 2 C pairs).
+ * Not thread-safe against concurrent enable / read; launches of any thread are recorded while enabled.  At most 65536 records. */
+enum {
+    SCP_PROF_POST_ATTN = 1,    /* rc_post_attn_kernel: 2 M (256*256 + 2*256*1024) flop                                  */
+    SCP_PROF_LN_LINEAR = 2,    /* rc_ln_linear_kernel (incl. <KV>): 2 M 256 N flop                                      */
+    SCP_PROF_ATTENTION = 3,    /* swin_attn_*_kernel: rows x 2 x 2 x 512 x 256 flop (QK^T and PV over the window)       */
+    SCP_PROF_KNN_FEAT = 4,     /* knn_f16x3_* / knn_mfma_kernel<72|96>: work = C (flop = 2 C x pairs)                   */
+    SCP_PROF_KNN_POS = 5,      /* knn_mfma_kernel<2,16>: work = 4 (padded feature count)                               */
+    SCP_PROF_GEMM_SPLIT = 6,   /* gemm_split_kernel, all variants: 2 M N K flop                                         */
+    SCP_PROF_EDGE_MLP = 7,     /* rc_edge_mlp_kernel: 2 M (448*256 + 2*256*256 + 512*256 + 256*256 + 256*128) flop      */
+    SCP_PROF_MERGE = 8,        /* rc_merge_kernel: 2 M 512 256 flop                                                     */
+    SCP_PROF_EDGE_GATHER = 9,  /* edge_gather_max_kernel: n k C' 4 bytes                                                */
+    SCP_PROF_CDF = 10,         /* cdf_kernel: n (4 nsym + 4) bytes                                                      */
+    SCP_PROF_GEMM_F32 = 11,    /* gemm_f32_kernel: 2 M N K flop                                                         */
+    SCP_PROF_GEMM_ROWS = 12,   /* gemm_bf16x3_kernel (fp32 activation rows; F16 form too): 2 M N K flop                 */
+    SCP_PROF_SPLIT_ROWS = 13,  /* split_rows_kernel / split_rows_f16: 8 bytes per element                               */
+    SCP_PROF_LAYERNORM = 14,   /* layernorm_rows / layernorm_add kernels: 8 bytes per element (+ planes)                */
+    SCP_PROF_OA_ATTENTION = 15,/* oa_attn_f16x3_kernel: B x 3 x 2 c^2 D flop; its preparation: OTHER     */
+    SCP_PROF_GEOM = 16,        /* scp_quantize / scp_geom_build / context kernels: the call's algorithmic bytes         */
+    SCP_PROF_OTHER = 17,
+    SCP_PROF_NTAGS = 18
+};
+SCP_API int scp_prof_enable(int32_t on);     /* 1: drop old records and start recording; 0: stop (records stay readable)   */
+SCP_API int scp_prof_count(void);            /* records taken since the last enable(1)                                     */
+/* waits for every recorded launch, then writes up to cap records in launch order: tag, milliseconds between the two events, work;
+ * returns the number written or a negative SCP_E* code */
+SCP_API int scp_prof_read(int32_t cap, int32_t *tags, float *ms, double *work);
 
 #ifdef __cplusplus
 }

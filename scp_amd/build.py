@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libscp_hip.so")
 SOURCES = ["api.cpp", "geom.hip", "sort_u64.hip", "cdf.hip", "rangecoder.cpp", "legacy_octree.cpp",
-           "knn.hip", "edge.hip", "attn.hip", "octattn.hip", "octattn_f16.hip", "gemm.hip", "gemm_split.hip", "mlp_fused.hip", "rowchain.hip", "fused.hip", "metrics.hip", "plan.hip"]
+           "knn.hip", "edge.hip", "attn.hip", "octattn.hip", "octattn_f16.hip", "gemm.hip", "gemm_split.hip", "rowchain.hip", "fused.hip", "metrics.hip", "plan.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fvisibility=hidden", "-x", "hip"]
@@ -44,12 +44,21 @@ def build(force=False, verbose=False):
         stamp, line = o + ".cmd", " ".join(cmd)
         same_cmd = os.path.exists(stamp) and open(stamp).read() == line
         if force or not same_cmd or _stale(o, [s] + hdrs):
-            with open(stamp, "w") as f:
-                f.write(line)
+            # the stamp names the command an object was BUILT with: it is removed (with the object) before the compile starts and
+            # written only once hipcc has succeeded, so an interrupted or failed probe build can never be linked by the next plain build
+            for stale in (stamp, o):
+                if os.path.exists(stale):
+                    os.remove(stale)
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            procs.append((s, subprocess.Popen(cmd)))
-    bad = [s for s, p in procs if p.wait() != 0]
+            procs.append((s, subprocess.Popen(cmd), stamp, line))
+    bad = []
+    for s, p, stamp, line in procs:
+        if p.wait() != 0:
+            bad.append(s)
+            continue
+        with open(stamp, "w") as f:
+            f.write(line)
     if bad:
         raise RuntimeError("hipcc failed for: " + ", ".join(bad))
     if force or procs or _stale(LIB, objs):

@@ -1,6 +1,8 @@
 // Library-level entry points of libscp_hip.so.
 #include <string.h>
+#include <mutex>
 #include <new>
+#include <vector>
 #include "scp_internal.h"
 
 int g_scp_last_hip_error = 0;
@@ -60,3 +62,66 @@ extern "C" int scp_ctx_get(const scp_ctx *c, int32_t key) {
 extern "C" int scp_ctx_make_current(const scp_ctx *c) { t_ctx = c; return SCP_OK; }
 int scp_ctx_knn_mode() { return t_ctx ? t_ctx->knn_f16x3 : -1; }
 int scp_ctx_attention_mode() { return t_ctx ? t_ctx->attn_bf16x3 : -1; }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Launch brackets (scp_debug.h): two hipEvents per bracketed launch, recorded inside the C ABI around the hipLaunchKernelGGL itself.
+int g_scp_prof_on = 0;
+namespace {
+struct ProfRec { int tag; double work; hipEvent_t e0, e1; bool ended; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+void ScpProfScope::begin(int tag, double work) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_scp_prof_on || g_prof.size() >= 65536) return;
+    ProfRec r{tag, work, prof_event(), prof_event(), false};
+    if (!r.e0 || !r.e1 || hipEventRecord(r.e0, st) != hipSuccess) {
+        if (r.e0) g_prof_pool.push_back(r.e0);
+        if (r.e1) g_prof_pool.push_back(r.e1);
+        return;
+    }
+    slot = (int)g_prof.size();
+    g_prof.push_back(r);
+}
+void ScpProfScope::end() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot < (int)g_prof.size() && !g_prof[slot].ended && hipEventRecord(g_prof[slot].e1, st) == hipSuccess) g_prof[slot].ended = true;
+}
+
+extern "C" int scp_prof_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (on) {
+        for (auto &r : g_prof) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+        g_prof.clear();
+    }
+    g_scp_prof_on = on ? 1 : 0;
+    return SCP_OK;
+}
+extern "C" int scp_prof_count(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    return (int)g_prof.size();
+}
+extern "C" int scp_prof_read(int32_t cap, int32_t *tags, float *ms, double *work) {
+    if (cap < 0 || (cap > 0 && (!tags || !ms || !work))) return SCP_EINVAL;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (auto &r : g_prof) {
+        if (n >= cap) break;
+        float t = -1.f;
+        if (r.ended) {
+            HIP_TRY(hipEventSynchronize(r.e1));
+            HIP_TRY(hipEventElapsedTime(&t, r.e0, r.e1));
+        }
+        tags[n] = r.tag; ms[n] = t; work[n] = r.work;
+        ++n;
+    }
+    return n;
+}

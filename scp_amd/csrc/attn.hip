@@ -601,6 +601,7 @@ extern "C" SCP_API int scp_swin_attention_packed_planes(const float *q, const vo
         ldq < NH * HD || (ldq & 3) || (((uintptr_t)q | (uintptr_t)out | (uintptr_t)khi | (uintptr_t)klo | (uintptr_t)vthi | (uintptr_t)vtlo) & 15) ||
         (ohi && (!olo || ldo < NH * HD || (ldo & 3) || (((uintptr_t)ohi | (uintptr_t)olo) & 7))))
         return SCP_EINVAL;
+    SCP_PROF(SCP_PROF_ATTENTION, stream, (double)total_windows * WIN * 2.0 * 2.0 * WIN * NH * HD);
     hipLaunchKernelGGL(swin_attn_planes_kernel, dim3(total_windows * NH * (WIN / QT)), dim3(256), 0, (hipStream_t)stream, q, (const __bf16 *)khi,
                        (const __bf16 *)klo, (const __bf16 *)vthi, (const __bf16 *)vtlo, bias_table, shift, ldq, out, wtab, (__bf16 *)ohi, (__bf16 *)olo, ldo);
     LAUNCH_CHECK();
@@ -623,6 +624,7 @@ static int attn_packed(const float *q, const float *k, const float *v, const flo
         ldkv < NH * HD || (ldq & 3) || (ldkv & 3) || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) ||
         (ohi && (!olo || ldo < NH * HD || (ldo & 3) || (((uintptr_t)ohi | (uintptr_t)olo) & 7))))
         return SCP_EINVAL;
+    SCP_PROF(SCP_PROF_ATTENTION, stream, (double)total_windows * WIN * 2.0 * 2.0 * WIN * NH * HD);
     if (attn_bf16x3())
         hipLaunchKernelGGL(swin_attn_bf16x3_kernel, dim3(total_windows * NH * (WIN / QT)), dim3(256), 0, (hipStream_t)stream, q, k, v, bias_table,
                            0, shift, ldq, ldkv, out, wtab, ohi, olo, ldo);
@@ -653,6 +655,7 @@ extern "C" int scp_swin_attention(const float *q, const float *k, const float *v
         ldq < NH * HD || ldkv < NH * HD || (ldq & 3) || (ldkv & 3) || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15))
         return SCP_EINVAL;
     const int nblk = B * (Lp / WIN) * NH * (WIN / QT);
+    SCP_PROF(SCP_PROF_ATTENTION, stream, (double)B * Lp * 2.0 * 2.0 * WIN * NH * HD);
     if (attn_bf16x3())
         hipLaunchKernelGGL(swin_attn_bf16x3_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, q, k, v, bias_table, Lp, shift, ldq, ldkv, out,
                            (const int *)nullptr, (__bf16 *)nullptr, (__bf16 *)nullptr, (int64_t)0);

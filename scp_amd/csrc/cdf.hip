@@ -115,6 +115,7 @@ static int launch(bool from_logits, const float *in, int64_t ld, int64_t n, int3
     if (lohi && !sym) return SCP_EINVAL;
     const int nb = (int)cdiv64(n, ROWS);
     hipStream_t st = (hipStream_t)stream;
+    SCP_PROF(SCP_PROF_CDF, st, (double)n * (4.0 * nsym + 4.0));
     if (from_logits) hipLaunchKernelGGL(cdf_kernel<true>, dim3(nb), dim3(256), 0, st, in, ld, n, nsym, sym, pmf, lohi, cdf_full);
     else hipLaunchKernelGGL(cdf_kernel<false>, dim3(nb), dim3(256), 0, st, in, ld, n, nsym, sym, pmf, lohi, cdf_full);
     LAUNCH_CHECK();

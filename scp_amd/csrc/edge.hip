@@ -59,6 +59,7 @@ extern "C" SCP_API int scp_edge_gather_max_ld(const float *u, int64_t ldu, const
         (out_stride & 3) || ldu < Cout || ldv < Cout || (ldu & 3) || (ldv & 3) || (((uintptr_t)out | (uintptr_t)u | (uintptr_t)v) & 15))
         return SCP_EINVAL;
     const int64_t total = (int64_t)B * n * (Cout / 4);
+    SCP_PROF(SCP_PROF_EDGE_GATHER, stream, 4.0 * B * n * (double)k * Cout);
     hipLaunchKernelGGL(edge_gather_max_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, u, v, idx, scale,
                        shift, n, Cout, k, out, out_stride, total, ldu, ldv);
     LAUNCH_CHECK();

@@ -90,6 +90,7 @@ static int ln_rows(const float *x, int64_t ldx, int64_t n_src_rows, const int64_
     if (rows == 0) return SCP_OK;
     const unsigned nb = (unsigned)cdiv64(rows, 16);   // 4 wavefronts x 4 rows per workgroup
     hipStream_t st = (hipStream_t)stream;
+    SCP_PROF(SCP_PROF_LAYERNORM, st, 8.0 * rows * C);
     if (C == 256) hipLaunchKernelGGL(layernorm_rows_kernel<1>, dim3(nb), dim3(256), 0, st, x, ldx, n_src_rows, ia, ia, gamma, beta, valid, eps, out, ldo, rows, ohi, olo);
     else hipLaunchKernelGGL(layernorm_rows_kernel<2>, dim3(nb), dim3(256), 0, st, x, ldx, n_src_rows, ia, ib, gamma, beta, valid, eps, out, ldo, rows, ohi, olo);
     LAUNCH_CHECK();
@@ -196,6 +197,7 @@ extern "C" SCP_API int scp_layernorm_add(const float *a, const float *b, int64_t
     if (rows == 0) return SCP_OK;
     const unsigned nb = (unsigned)cdiv64(rows, 4);
     hipStream_t st = (hipStream_t)stream;
+    SCP_PROF(SCP_PROF_LAYERNORM, st, (b ? 12.0 : 8.0) * rows * C);
     if (C <= 256) hipLaunchKernelGGL(layernorm_add_kernel<1>, dim3(nb), dim3(256), 0, st, a, b, rows, C, gamma, beta, eps, out);
     else if (C <= 512) hipLaunchKernelGGL(layernorm_add_kernel<2>, dim3(nb), dim3(256), 0, st, a, b, rows, C, gamma, beta, eps, out);
     else if (C <= 768) hipLaunchKernelGGL(layernorm_add_kernel<3>, dim3(nb), dim3(256), 0, st, a, b, rows, C, gamma, beta, eps, out);
@@ -216,6 +218,7 @@ extern "C" SCP_API int scp_layernorm_add_split_f16(const float *a, const float *
     if (rows == 0) return SCP_OK;
     const unsigned nb = (unsigned)cdiv64(rows, 4);
     hipStream_t st = (hipStream_t)stream;
+    SCP_PROF(SCP_PROF_LAYERNORM, st, (b ? 16.0 : 12.0) * rows * C);
 #define GOP(NP_) hipLaunchKernelGGL((layernorm_add_kernel<NP_, true>), dim3(nb), dim3(256), 0, st, a, b, rows, C, gamma, beta, eps, out, (_Float16 *)hi, \
                                     (_Float16 *)lo, ldp, scale, inv_scale)
     if (Cp <= 256) GOP(1); else if (Cp <= 512) GOP(2); else if (Cp <= 768) GOP(3); else GOP(4);

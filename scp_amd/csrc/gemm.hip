@@ -288,6 +288,7 @@ extern "C" SCP_API int scp_linear_bf16x3(const float *A, int64_t lda, const void
         ((uintptr_t)A & 15) || lda < K || ldc < N || (residual && ldr < N))
         return SCP_EINVAL;
     const dim3 grid((unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM)));
+    SCP_PROF(SCP_PROF_GEMM_ROWS, stream, 2.0 * M * (double)N * K);
 #define GO(ACT) hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT, false>), grid, dim3(512), 0, (hipStream_t)stream, A, lda, (const __bf16 *)Whi, \
                               (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K, nullptr, nullptr, nullptr, gemm_wtiled())
     switch (act) { case ACT_LEAKY: GO(ACT_LEAKY); break; case ACT_GELU: GO(ACT_GELU); break; case ACT_RELU: GO(ACT_RELU); break; default: GO(ACT_NONE); }
@@ -409,6 +410,7 @@ extern "C" SCP_API int scp_split_rows_f16(const float *A, int64_t lda, int32_t M
         ((uintptr_t)A & 15) || (((uintptr_t)hi | (uintptr_t)lo) & 15))
         return SCP_EINVAL;
     const dim3 grid((unsigned)((M + 15) / 16));
+    SCP_PROF(SCP_PROF_SPLIT_ROWS, stream, 8.0 * M * (double)K);
 #define GOR(N_) hipLaunchKernelGGL((split_rows_f16_kernel<N_>), grid, dim3(256), 0, (hipStream_t)stream, A, lda, M, K, Kp, (_Float16 *)hi, (_Float16 *)lo, \
                                    ldp, scale, inv_scale)
     if (Kp <= 256) GOR(1); else if (Kp <= 512) GOR(2); else if (Kp <= 768) GOR(3); else GOR(4);
@@ -434,6 +436,7 @@ static int linear_f16x3_launch(const float *A, int64_t lda, const void *Whi, con
         return SCP_EINVAL;
     if (compute_scales) hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, A, lda, M, K, sc, isc);
     const dim3 grid((unsigned)(((N + BN - 1) / BN) * ((M + BM - 1) / BM)));
+    SCP_PROF(SCP_PROF_GEMM_ROWS, stream, 2.0 * M * (double)N * K);
 #define GO(ACT) hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT, true>), grid, dim3(512), 0, (hipStream_t)stream, A, lda, (const __bf16 *)Whi, \
                               (const __bf16 *)Wlo, Kpad, bias, residual, ldr, C, ldc, M, N, K, sc, isc, w_inv_scale, gemm_wtiled())
     switch (act) { case ACT_LEAKY: GO(ACT_LEAKY); break; case ACT_GELU: GO(ACT_GELU); break; case ACT_RELU: GO(ACT_RELU); break; default: GO(ACT_NONE); }
@@ -576,6 +579,7 @@ extern "C" SCP_API int scp_linear_f32(const float *A, int64_t lda, const float *
                                       int32_t K, int32_t act, void *stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N || act < 0 || act > 3) return SCP_EINVAL;
     const dim3 grid((unsigned)(((N + FBN - 1) / FBN) * ((M + FBM - 1) / FBM)));
+    SCP_PROF(SCP_PROF_GEMM_F32, stream, 2.0 * M * (double)N * K);
 #define GOF(ACT) hipLaunchKernelGGL(gemm_f32_kernel<ACT>, grid, dim3(256), 0, (hipStream_t)stream, A, lda, W, bias, C, ldc, M, N, K)
     switch (act) { case ACT_LEAKY: GOF(ACT_LEAKY); break; case ACT_GELU: GOF(ACT_GELU); break; case ACT_RELU: GOF(ACT_RELU); break; default: GOF(ACT_NONE); }
 #undef GOF

@@ -421,6 +421,7 @@ extern "C" SCP_API int scp_split_rows(const float *src, int64_t ld_src, int64_t 
     int Cp = (C + 31) & ~31;          // zero fill up to the next multiple of 32 (the consumer's K padding) when the row has room
     if (Cp > ldo) Cp = C;
     const int64_t total = rows * (Cp / 4);
+    SCP_PROF(SCP_PROF_SPLIT_ROWS, stream, 8.0 * rows * C);
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, n_src, idx, C / 4,
                        Cp / 4, (__bf16 *)hi, (__bf16 *)lo, ldo, total);
     LAUNCH_CHECK();
@@ -430,7 +431,7 @@ extern "C" SCP_API int scp_split_rows(const float *src, int64_t ld_src, int64_t 
 static int g_num_cu = 0;
 
 template <int WM, int WN, int TM, bool EXT>
-static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st) {
+static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st, double work) {
     constexpr int BM = WM * TM * 32, BN = WN * 64;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int BOUNCE = WM * WN * 8192;
@@ -446,6 +447,7 @@ static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st) {
     const int64_t ntiles = cdiv64(ga.M, BM) * cdiv64(ga.N, BN);
     const int64_t slots = (int64_t)g_num_cu * (WM * WN == 4 ? 2 : 1);
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    SCP_PROF(SCP_PROF_GEMM_SPLIT, st, work);
 #define GOS(ACT) hipLaunchKernelGGL((gemm_split_kernel<WM, WN, TM, ACT, EXT>), dim3(grid), dim3(WM * WN * 64), LDS, st, ga)
     switch (act) { case ACT_LEAKY: GOS(ACT_LEAKY); break; case ACT_GELU: GOS(ACT_GELU); break; case ACT_RELU: GOS(ACT_RELU); break; default: GOS(ACT_NONE); }
 #undef GOS
@@ -496,9 +498,10 @@ static int linear_split_impl(const void *Ahi, const void *Alo, int64_t lda, cons
     // cfg 0 = automatic: the 256 x 128 tile where a 256-wide one would leave the chip's last round mostly empty or N <= 128
     if (cfg == 0) cfg = (N <= 128) ? 2 : 1;
     const bool ext = ga.res_map || ga.res_first || ga.out_map;
-    if (cfg == 2) return ext ? launch_cfg<4, 2, 2, true>(ga, act, st) : launch_cfg<4, 2, 2, false>(ga, act, st);
-    if (cfg == 3) return ext ? SCP_EINVAL : launch_cfg<2, 2, 2, false>(ga, act, st);   // 128 x 128, 4 waves, two workgroups per CU
-    return ext ? launch_cfg<2, 4, 4, true>(ga, act, st) : launch_cfg<2, 4, 4, false>(ga, act, st);
+    const double work = 2.0 * M * (double)N * K;
+    if (cfg == 2) return ext ? launch_cfg<4, 2, 2, true>(ga, act, st, work) : launch_cfg<4, 2, 2, false>(ga, act, st, work);
+    if (cfg == 3) return ext ? SCP_EINVAL : launch_cfg<2, 2, 2, false>(ga, act, st, work);   // 128 x 128, 4 waves, two workgroups per CU
+    return ext ? launch_cfg<2, 4, 4, true>(ga, act, st, work) : launch_cfg<2, 4, 4, false>(ga, act, st, work);
 }
 
 extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
@@ -543,6 +546,7 @@ extern "C" SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, in
     const int64_t ntiles = cdiv64(M, 128) * cdiv64(N, 128);
     const int64_t slots = 2 * (int64_t)g_num_cu;
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    SCP_PROF(SCP_PROF_GEMM_SPLIT, stream, 2.0 * M * (double)N * K);
     if (act == ACT_RELU) hipLaunchKernelGGL((gemm_split_kernel<2, 2, 2, ACT_RELU, false, true>), dim3(grid), dim3(256), LDS, (hipStream_t)stream, ga);
     else hipLaunchKernelGGL((gemm_split_kernel<2, 2, 2, ACT_NONE, false, true>), dim3(grid), dim3(256), LDS, (hipStream_t)stream, ga);
     LAUNCH_CHECK();

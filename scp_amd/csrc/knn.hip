@@ -1060,6 +1060,7 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
             // knn_wg(): 256 = groups of 3 (K = 192) / 4 (K = 144) tiles, front-to-back order; 257: groups of 2; 258: one tile per barrier;
             // +16: outward order instead
             const int shape = knn_wg() & 15, order = (knn_wg() >> 4) & 7;
+            SCP_PROF(SCP_PROF_KNN_FEAT, st, (double)C);
 #define KNN_LAUNCH(KK, GG) hipLaunchKernelGGL((knn_f16x3_wg256_kernel<KK, GG>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx, \
                                               (const float *)isc, (const KnnWg *)tab, idx, thr0, order)
             if (C == 144) { if (shape == 2) KNN_LAUNCH(144, 1); else if (shape == 1) KNN_LAUNCH(144, 2); else KNN_LAUNCH(144, 4); }
@@ -1071,6 +1072,7 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
             LAUNCH_CHECK();
             return SCP_OK;
         }
+        SCP_PROF(SCP_PROF_KNN_FEAT, st, (double)C);
         if (C == 144) hipLaunchKernelGGL(knn_f16x3_kernel<144>, grid, dim3(256), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, n, k, idx, ctab, thr0);
         else hipLaunchKernelGGL(knn_f16x3_kernel<192>, grid, dim3(256), 0, st, (const _Float16 *)pl, (const float *)xx, (const float *)isc, n, k, idx, ctab, thr0);
         LAUNCH_CHECK();
@@ -1084,10 +1086,14 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
         float *bb = (float *)((char *)aux + (size_t)npts * 16);
         const int bn = ctab ? (int)npts : n, bB = ctab ? 1 : (int)grid.y;
         hipLaunchKernelGGL(bbox32_kernel, dim3((unsigned)cdiv64((int64_t)((bn + 31) / 32) * bB, 256)), dim3(256), 0, st, (const float *)aux, bn, bB, bb);
+        SCP_PROF(SCP_PROF_KNN_POS, st, 4.0);
         hipLaunchKernelGGL((knn_mfma_kernel<2, 16, true>), grid, dim3(256), 0, st, (const float *)aux, (const float *)xx, n, 4, k, idx, ctab, thr0,
                            (const float *)bb);
-    } else if (C == 144) hipLaunchKernelGGL((knn_mfma_kernel<72, 1>), grid, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, ctab, thr0);
-    else hipLaunchKernelGGL((knn_mfma_kernel<96, 1>), grid, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, ctab, thr0);
+    } else {
+        SCP_PROF(SCP_PROF_KNN_FEAT, st, (double)C);
+        if (C == 144) hipLaunchKernelGGL((knn_mfma_kernel<72, 1>), grid, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, ctab, thr0);
+        else hipLaunchKernelGGL((knn_mfma_kernel<96, 1>), grid, dim3(256), 0, st, x, (const float *)xx, n, C, k, idx, ctab, thr0);
+    }
     LAUNCH_CHECK();
     return SCP_OK;
 }

@@ -348,8 +348,12 @@ extern "C" SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(vmax, 0, 4, st) != hipSuccess) return SCP_EHIP;
     const int64_t n4 = (int64_t)B * c * H * FHD / 4;                 // 600 floats per token: a multiple of 4
-    hipLaunchKernelGGL(oa_absmax_kernel, dim3((unsigned)(n4 < 256 * 1024 ? (n4 + 255) / 256 : 1024)), dim3(256), 0, st, v, n4, vmax);
-    hipLaunchKernelGGL(oa_prep_kernel, dim3(B * nt, H), dim3(256), 0, st, q_u, k, k_u, v, c, H, nt, vmax, qp, isq, diag, kimg, vimg);
+    {
+        SCP_PROF(SCP_PROF_OTHER, st, 0.0);             // operand preparation (planes, scales, diagonal terms)
+        hipLaunchKernelGGL(oa_absmax_kernel, dim3((unsigned)(n4 < 256 * 1024 ? (n4 + 255) / 256 : 1024)), dim3(256), 0, st, v, n4, vmax);
+        hipLaunchKernelGGL(oa_prep_kernel, dim3(B * nt, H), dim3(256), 0, st, q_u, k, k_u, v, c, H, nt, vmax, qp, isq, diag, kimg, vimg);
+    }
+    SCP_PROF(SCP_PROF_OA_ATTENTION, st, (double)B * 3.0 * 2.0 * c * (double)c * H * FHD);
     hipLaunchKernelGGL(oa_attn_f16x3_kernel, dim3(B * H * ((c + 127) / 128)), dim3(256), 0, st, v, v_u, c, H, nt, vmax, qp, isq, diag,
                        kimg, vimg, out, out_u);
     LAUNCH_CHECK();

@@ -1308,6 +1308,7 @@ extern "C" SCP_API int scp_swin_ln_linear(const float *x, int64_t ldx, const flo
     a.dbg = g_rc_dbg;
     const int ntiles = (M + RC_ROWS - 1) / RC_ROWS;
     const int ncu = rc_num_cu();
+    SCP_PROF(SCP_PROF_LN_LINEAR, stream, 2.0 * M * 256.0 * N);
     hipLaunchKernelGGL(rc_ln_linear_kernel<0>, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;
@@ -1333,6 +1334,7 @@ extern "C" SCP_API int scp_swin_ln_qkv(const float *x, int64_t ldx, const float 
     a.out = q; a.ldo = q ? ldq : 256; a.M = M; a.N = N; a.eps = eps; a.probe = 0; a.dbg = nullptr;
     a.planes = (__bf16 *)planes; a.plane_bytes = Tp * 512; a.nq = N / 64 - 8;
     const int ntiles = M / RC_ROWS, ncu = rc_num_cu();
+    SCP_PROF(SCP_PROF_LN_LINEAR, stream, 2.0 * M * 256.0 * N);
     hipLaunchKernelGGL((rc_ln_linear_kernel<0, true>), dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;
@@ -1362,6 +1364,7 @@ extern "C" SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int6
     { const char *e = getenv("SCP_RC_DUMP"); a.dbg_mode = e ? atoi(e) : 0; }
     const int ntiles = (M + RC_ROWS - 1) / RC_ROWS;
     const int ncu = rc_num_cu();
+    SCP_PROF(SCP_PROF_POST_ATTN, stream, 2.0 * M * (256.0 * 256.0 + 2.0 * 256.0 * 1024.0));
     hipLaunchKernelGGL(rc_post_attn_kernel, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;
@@ -1386,6 +1389,7 @@ extern "C" SCP_API int scp_geo_edge_mlps(const float *pos1, int64_t ld1, const f
     RcEdgeArgs a;
     a.p1 = pos1; a.p2 = pos2; a.p3 = pos3; a.ld1 = ld1; a.ld2 = ld2; a.ld3 = ld3; a.W = W; a.bias = bias; a.out = out; a.ldo = ldo; a.M = M;
     const int ntiles = (M + RC_ROWS - 1) / RC_ROWS, ncu = rc_num_cu();
+    SCP_PROF(SCP_PROF_EDGE_MLP, stream, 2.0 * M * (448.0 * 256 + 2.0 * 256 * 256 + 512.0 * 256 + 256.0 * 256 + 256.0 * 128));
     hipLaunchKernelGGL(rc_edge_mlp_kernel, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;
@@ -1408,6 +1412,7 @@ extern "C" SCP_API int scp_swin_merge(const float *x, int64_t ldx, int64_t n_src
     RcMergeArgs a;
     a.x = x; a.ldx = ldx; a.n_src = n_src; a.ia = ia; a.ib = ib; a.W = W; a.wbeta = wbeta; a.out = out; a.ldo = ldo; a.M = M; a.eps = eps;
     const int ntiles = (M + RC_ROWS - 1) / RC_ROWS, ncu = rc_num_cu();
+    SCP_PROF(SCP_PROF_MERGE, stream, 2.0 * M * 512.0 * 256.0);
     hipLaunchKernelGGL(rc_merge_kernel, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/scp.h"
+#include "../../include/scp_debug.h"
 
 #define SCP_WAVE 64
 
@@ -19,6 +20,19 @@ extern int g_scp_last_hip_error;
     } while (0)
 
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+// scp_debug.h launch brackets (api.cpp): `SCP_PROF(tag, stream, work);` right in front of a launch records a hipEvent on the stream now
+// and another when the enclosing scope ends (i.e. after the launch).  One relaxed load when profiling is off.
+extern int g_scp_prof_on;
+struct ScpProfScope {
+    int slot;
+    hipStream_t st;
+    ScpProfScope(int tag, hipStream_t s, double work) : slot(-1), st(s) { if (__builtin_expect(g_scp_prof_on, 0)) begin(tag, work); }
+    ~ScpProfScope() { if (__builtin_expect(slot >= 0, 0)) end(); }
+    void begin(int tag, double work);
+    void end();
+};
+#define SCP_PROF(tag, stream, work) ScpProfScope _scp_prof((tag), (hipStream_t)(stream), (double)(work))
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -6,7 +6,6 @@ The dual-stream causal attention of attention_model.py:58-95 runs in one HIP ker
 the reference, forward() is a pure function (it does not edit `data` in place, Appendix B-13).
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -16,8 +15,8 @@ from .. import native
 from .. import ops as _ops
 from ..ops import linear as _linear
 
-# SCP_OA_DENSE=rows: the dense layers read fp32 rows and convert them in every tile (round 2; A/B bracket, identical bits)
-PLANES = os.environ.get("SCP_OA_DENSE", "planes") != "rows"
+# False (tests only): the dense layers read fp32 rows and convert them in every tile (the round-2 form: identical bits)
+PLANES = True
 
 
 def linear(x, w, b=None, act=None, residual=None, scales=None):
@@ -117,7 +116,7 @@ class OctAttention(nn.Module):
         # Every dense layer that reads an embedding tensor reads PRE-SPLIT f16 planes (native.SplitActF16: one pass per tensor writes the
         # row scales and both planes; key / value / query / linear1 / decoder0 then stream them by LDS-DMA - csrc/gemm_split.hip, F16
         # instantiation - instead of converting fp32 rows in every tile).  Bit-identical to the fp32-row kernel (SCP_OA_DENSE=rows).
-        planes = PLANES and _ops.MODE == "bf16x3"
+        planes = PLANES
         n = B * c
 
         def lin(a, x, w, b, act=None, residual=None, rows=None, scales=None):
@@ -133,7 +132,7 @@ class OctAttention(nn.Module):
             if planes:
                 if pa is None:                         # the embedding stage's output: one standalone pass
                     pa = native.SplitActF16(E2 if E2.is_contiguous() else E2.contiguous())
-            elif E.is_contiguous() and _ops.MODE == "bf16x3":
+            elif E.is_contiguous():
                 # the three projections read the same rows: one pass for their power-of-two row scales (the query takes the unknown stream's half)
                 rs = native.RowScales(E2)
                 rsq = rs.rows(n, 2 * n)

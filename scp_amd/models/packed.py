@@ -137,22 +137,6 @@ class PackedPlan:
             even_out=_out_map(Q0, ne, coded), odd_out=_out_map(Q0, no, coded + ne))
 
 
-FUSED_MLP = __import__('os').environ.get('SCP_MLP', 'fused') != 'split'   # SCP_MLP=split: fc1 and fc2 as two launches
-
-
-# SCP_SWIN=split: the Swin blocks as the separate launches of rounds 1 - 2 (LayerNorm, q|k|v GEMM, attention, projection GEMM, LayerNorm,
-# fused MLP); default: the row-chain kernels of csrc/rowchain.hip - LayerNorm + q|k|v in one launch, everything behind the attention in
-# another (11 KB of HBM traffic per row and block instead of 17 + 3.6 of re-reads)
-ROWCHAIN = __import__('os').environ.get('SCP_SWIN', 'rowchain') != 'split'
-# SCP_ATTN_KV=rows: keys / values go from the projection to the attention kernel as fp32 rows (round 3a - 3f); planes: as bf16 hi / lo
-# planes in the layout of the attention kernel's LDS tiles (bit-identical results)
-KV_PLANES = __import__('os').environ.get('SCP_ATTN_KV', 'planes') != 'rows'
-# SCP_MERGE=split: patch merging as gather + LayerNorm, then a split GEMM (round 2 - 3g; other last bits)
-MERGE_RC = __import__('os').environ.get('SCP_MERGE', 'rowchain') != 'split'
-# SCP_EDGE=split: the geometry generator's two edge MLPs as six split GEMMs (round 1 - 3h; other last bits)
-EDGE_RC = __import__('os').environ.get('SCP_EDGE', 'rowchain') != 'split'
-
-
 def _rowchain_weights(layer, cross):
     """Derived weights of a block for the row-chain kernels (rebuilt when a parameter changes): LayerNorm-folded q|k|v (or k|v and q for a
     cross layer) and the packed post-attention buffer."""
@@ -180,7 +164,7 @@ def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None):
     w = _rowchain_weights(layer, cross)
     lnb = layer.layernorm_before
     v1 = None if valid is None else valid.reshape(-1)
-    if KV_PLANES and native.attention_bf16x3():
+    if native.attention_bf16x3():
         # keys and values leave the projection as the bf16 planes the attention kernel stages by LDS-DMA (identical bits to the fp32 hand-over)
         if not cross:
             q, kvp = native.swin_ln_qkv(x, w["kv"], w["b"], lnb.eps, v1)
@@ -189,6 +173,7 @@ def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None):
             _, kvp = native.swin_ln_qkv(x, w["kv"], w["b"], lnb.eps, v1)
         o = native.swin_attention_packed_planes(q, kvp, att.relative_position_bias_table, wtab, shift, split=True)
         return native.swin_post_attn(o, x, w["post"], layer.layernorm_after.eps)
+    # numeric profile "attention = fp32 MFMA" (scp_ctx): the fp32-fed attention kernel takes q, k, v as rows
     if not cross:
         qkv = native.swin_ln_linear(x, w["kv"], w["b"], lnb.eps, v1)
         q, k, v = qkv[:, :256], qkv[:, 256:512], qkv[:, 512:]
@@ -202,48 +187,21 @@ def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None):
 
 def _swin_layer(layer, x, valid, wtab, shift, query=None):
     """swin_transformer.py:654-706 on a packed layout (rows beyond a window's length are don't-care, except that the
-    LayerNorm output is zeroed there - the reference zero-pads AFTER LayerNorm)."""
+    LayerNorm output is zeroed there - the reference zero-pads AFTER LayerNorm): two row-chain launches around the attention kernel."""
     fc1, fc2 = layer.intermediate.dense, layer.output.dense
-    if ROWCHAIN and x.shape[1] == 256 and fc1.weight.shape == (1024, 256) and fc2.weight.shape == (256, 1024):
-        return _swin_layer_rowchain(layer, x, valid, wtab, shift, query)
-    att = layer.attention.self
-    cross = query is not None
-    W, b = qkv_fused(layer, cross)
-    lnb = layer.layernorm_before
-    # every GEMM operand is produced in the split (bf16 hi/lo) format by the kernel before it: LN -> qkv, attention -> proj,
-    # LN -> fc1 -> fc2; the residual stream x stays fp32
-    h = native.layernorm_rows(x, lnb.weight, lnb.bias, lnb.eps, valid=valid, split=True)
-    if not cross:
-        qkv = linear_s(h, W, b)
-        q, k, v = qkv[:, :256], qkv[:, 256:512], qkv[:, 512:]
-    else:
-        hq = native.layernorm_rows(query, lnb.weight, lnb.bias, lnb.eps, valid=valid, split=True)
-        q = linear_s(hq, att.query.weight, att.query.bias)
-        kv = linear_s(h, W, b)
-        k, v = kv[:, :256], kv[:, 256:]
-    o = native.swin_attention_packed(q, k, v, att.relative_position_bias_table, wtab, shift, split=True)
-    x = linear_s(o, layer.attention.output.dense.weight, layer.attention.output.dense.bias, residual=x)
-    lna = layer.layernorm_after
-    h2 = native.layernorm_rows(x, lna.weight, lna.bias, lna.eps, split=True)
-    fc1, fc2 = layer.intermediate.dense, layer.output.dense
-    if FUSED_MLP and fc1.weight.shape == (1024, 256) and fc2.weight.shape == (256, 1024):
-        # intermediate.dense + GELU + output.dense + residual in one kernel: the 1024-wide hidden activation stays in LDS
-        # (csrc/mlp_fused.hip; bit-identical to the two launches below)
-        return native.mlp_split_fused(h2, _split(fc1.weight), fc1.bias, _split(fc2.weight), fc2.bias, residual=x)
-    y = linear_s(h2, fc1.weight, fc1.bias, act="gelu", want="split")
-    return linear_s(y, fc2.weight, fc2.bias, residual=x)
+    if x.shape[1] != 256 or fc1.weight.shape != (1024, 256) or fc2.weight.shape != (256, 1024):
+        raise native.ScpError("EHEM's Swin blocks are 256 wide with a 1024-wide MLP (configs/model/ehem.yaml); other widths are not built")
+    return _swin_layer_rowchain(layer, x, valid, wtab, shift, query)
 
 
 def _merge(m, x, maps):
-    """SwinPatchMerging: gather (even, odd) token of every pair + LayerNorm(512) + the 512 -> 256 reduction in one row-chain launch
-    (SCP_SWIN=split: gather + LayerNorm in one kernel, then the reduction as a split GEMM)."""
+    """SwinPatchMerging: gather (even, odd) token of every pair + LayerNorm(512) + the 512 -> 256 reduction in one row-chain launch."""
     ev, od = maps          # index == x.shape[0] stands for the zero row an odd-length window is padded with
-    if ROWCHAIN and MERGE_RC and x.shape[1] == 256 and m.reduction.weight.shape == (256, 512) and m.reduction.bias is None:
-        mw = derived(m, "rowchain_merge", [m.reduction.weight, m.norm.weight, m.norm.bias],
-                     lambda: native.MergeWeights(m.reduction.weight, m.norm.weight, m.norm.bias))
-        return native.swin_merge(x, ev, od, mw, m.norm.eps)
-    y = native.layernorm_rows(x, m.norm.weight, m.norm.bias, m.norm.eps, ia=ev, ib=od, split=True)
-    return linear_s(y, m.reduction.weight, None)
+    if x.shape[1] != 256 or m.reduction.weight.shape != (256, 512) or m.reduction.bias is not None:
+        raise native.ScpError("SwinPatchMerging: 2 x 256 -> 256 without bias expected")
+    mw = derived(m, "rowchain_merge", [m.reduction.weight, m.norm.weight, m.norm.bias],
+                 lambda: native.MergeWeights(m.reduction.weight, m.norm.weight, m.norm.bias))
+    return native.swin_merge(x, ev, od, mw, m.norm.eps)
 
 
 def _encoder(enc, x, valids, tabs, merges, query=None):
@@ -274,8 +232,8 @@ def _concat(hs, cmaps, extra=None):
     return out
 
 
-# SCP_CONCAT=direct builds the 1280-wide concatenation and runs one product (the literal form of ehem.py:75-86); default: per stage
-HIER = __import__('os').environ.get('SCP_CONCAT', 'hier') != 'direct'
+# False (tests only): build the 1280-wide concatenation and run one product (the literal form of ehem.py:75-86); product: per stage
+HIER = True
 
 
 def _concat_layer(lin, hs, parents, extra=None):
@@ -348,17 +306,13 @@ def ehem_phase1_packed(model, ctx, pos, plan, table=None):
     nx = g.mlp3[4].weight.shape[0]
     feat = torch.empty((P0, nx + g.edge_mlp2[4].weight.shape[0]), dtype=torch.float32, device=dev)
     leaky_mlp3_s(g.mlp3, native.split_rows(x), out=feat[:, :nx])
-    if ROWCHAIN and EDGE_RC and (pos1.shape[1], pos2.shape[1], pos3.shape[1]) == (64, 128, 256) and feat.shape[1] - nx == 128:
-        # both edge MLPs in one row-chain launch: six layers chained through the accumulators, edge_mlp1's output never leaves the registers
-        ew = derived(g, "rowchain_edge", [l.weight for l in (g.edge_mlp1[0], g.edge_mlp1[2], g.edge_mlp1[4], g.edge_mlp2[0], g.edge_mlp2[2], g.edge_mlp2[4])] +
-                     [l.bias for l in (g.edge_mlp1[0], g.edge_mlp1[2], g.edge_mlp1[4], g.edge_mlp2[0], g.edge_mlp2[2], g.edge_mlp2[4])],
-                     lambda: native.EdgeMlpWeights(g.edge_mlp1, g.edge_mlp2))
-        native.geo_edge_mlps(pos1, pos2, pos3, ew, feat[:, nx:])
-    else:
-        e_in = native.SplitAct.empty(P0, pos3.shape[1] + g.edge_mlp1[4].weight.shape[0], dev)     # cat(pos3, edge_mlp1(...))
-        native.split_rows(pos3, out=e_in.cols(0, pos3.shape[1]))
-        leaky_mlp3_s(g.edge_mlp1, split_cat((pos1, pos2, pos3)), want="split", out_split=e_in.cols(pos3.shape[1], e_in.K))
-        leaky_mlp3_s(g.edge_mlp2, e_in, out=feat[:, nx:])
+    if (pos1.shape[1], pos2.shape[1], pos3.shape[1]) != (64, 128, 256) or feat.shape[1] - nx != 128:
+        raise native.ScpError("GeoFeatGenerator: edge features of 64 / 128 / 256 channels expected (models/dgcnn.py:74-119)")
+    # both edge MLPs in one row-chain launch: six layers chained through the accumulators, edge_mlp1's output never leaves the registers
+    ew = derived(g, "rowchain_edge", [l.weight for l in (g.edge_mlp1[0], g.edge_mlp1[2], g.edge_mlp1[4], g.edge_mlp2[0], g.edge_mlp2[2], g.edge_mlp2[4])] +
+                 [l.bias for l in (g.edge_mlp1[0], g.edge_mlp1[2], g.edge_mlp1[4], g.edge_mlp2[0], g.edge_mlp2[2], g.edge_mlp2[4])],
+                 lambda: native.EdgeMlpWeights(g.edge_mlp1, g.edge_mlp2))
+    native.geo_edge_mlps(pos1, pos2, pos3, ew, feat[:, nx:])
     hs = _encoder(model.swin_self_transformer, feat, d["self_valid"], d["self_tab"], d["self_merge"])
     feat_a = _mlp_over_concat(model.ancient_mlp, hs, d["self_parent"]) if HIER else leaky_mlp3_s(model.ancient_mlp, _concat(hs, d["self_concat"]))
     Q0 = d["a1map"].shape[0]

@@ -42,7 +42,7 @@ _lib = None
 _vp = C.c_void_p
 
 
-ABI_VERSION = 200      # include/scp.h: SCP_ABI_VERSION
+ABI_VERSION = 210      # include/scp.h: SCP_ABI_VERSION
 
 
 def lib():
@@ -88,6 +88,9 @@ def lib():
         "scp_ctx_get": (C.c_int, [_vp, i32]),
         "scp_ctx_make_current": (C.c_int, [_vp]),
         "scp_rc_debug_buffer": (C.c_int, [_vp]),
+        "scp_prof_enable": (C.c_int, [i32]),
+        "scp_prof_count": (C.c_int, []),
+        "scp_prof_read": (C.c_int, [i32, _vp, _vp, _vp]),
         "scp_set_knn_mode": (C.c_int, [i32]),
         "scp_row_scale_f16": (C.c_int, [_vp, i64, i32, i32, _vp, _vp, _vp]),
         "scp_linear_f16x3_scaled": (C.c_int, [_vp, i64, _vp, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp, _vp, _vp]),
@@ -95,7 +98,6 @@ def lib():
         "scp_layernorm_add_split_f16": (C.c_int, [_vp, _vp, i64, i32, _vp, _vp, C.c_float, _vp, _vp, _vp, i64, _vp, _vp, _vp]),
         "scp_set_knn_workgroup": (C.c_int, [i32]),
         "scp_knn_debug_buffer": (C.c_int, [_vp]),
-        "scp_mlp_debug_buffer": (C.c_int, [_vp]),
         "scp_nn_sqdist_f64": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp]),
         "scp_edge_gather_max_ld": (C.c_int, [_vp, i64, _vp, i64, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_embed_gather": (C.c_int, [_vp, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp]),
@@ -111,7 +113,6 @@ def lib():
         "scp_split_weight_f16": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp, _vp, _vp]),
         "scp_linear_f16x3": (C.c_int, [_vp, i64, _vp, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp, _vp]),
         "scp_linear_split": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
-        "scp_mlp_split_fused": (C.c_int, [_vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp, i64, i32, _vp]),
         "scp_tile_weight_bf16": (C.c_int, [_vp, i32, i32, _vp, _vp]),
         "scp_swin_ln_linear": (C.c_int, [_vp, i64, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, i32, _vp]),
         "scp_swin_post_attn": (C.c_int, [_vp, _vp, i64, _vp, i64, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, _vp]),
@@ -167,6 +168,33 @@ def _dev(t, dtype=None):
 
 def _opt(t):
     return None if t is None else _dev(t)
+
+
+# ------------------------------------------------------------------------------------------------- launch brackets (scp_debug.h)
+PROF_TAGS = {1: "post_attn", 2: "ln_linear", 3: "attention", 4: "knn_feat", 5: "knn_pos", 6: "gemm_split", 7: "edge_mlp", 8: "merge",
+             9: "edge_gather", 10: "cdf", 11: "gemm_f32", 12: "gemm_rows", 13: "split_rows", 14: "layernorm", 15: "oa_attention", 16: "geom",
+             17: "other"}
+
+
+class launch_profile:
+    """`with native.launch_profile() as p: ...` - while inside, every bracketed C-ABI launch records a hipEvent pair around its kernel
+    (include/scp_debug.h: scp_prof_*; the events are recorded in C next to the launch, no Python between them).  `p.records()` waits for
+    the launches and returns [(tag name, milliseconds, algorithmic work)] in launch order.  A measurement hook, not a product path."""
+
+    def __enter__(self):
+        _check(lib().scp_prof_enable(1), "scp_prof_enable")
+        return self
+
+    def __exit__(self, *exc):
+        lib().scp_prof_enable(0)
+        return False
+
+    def records(self):
+        n = _check(lib().scp_prof_count(), "scp_prof_count")
+        tags, ms, work = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.float64)
+        if n:
+            n = _check(lib().scp_prof_read(n, tags.ctypes.data, ms.ctypes.data, work.ctypes.data), "scp_prof_read")
+        return [(PROF_TAGS.get(int(t), str(int(t))), float(m), float(w)) for t, m, w in zip(tags[:n], ms[:n], work[:n])]
 
 
 # ------------------------------------------------------------------------------------------------- stage G1
@@ -502,8 +530,8 @@ def attention_bf16x3():
 def numeric_profile(model_name, profile="current"):
     """The arithmetic variants that decide the logits' last bits - hence the integer CDFs a decoder must reproduce - as a string.  The
     encoder writes it into its side-info file and the decoder refuses a stream coded under another profile.  `profile`: a
-    NumericProfile, None (process default) or "current" (this thread's).  (The other alternates are process-wide test / benchmark
-    brackets read once at import: SCP_GEMM, SCP_CONCAT, SCP_SWIN, SCP_OCTATTN; SCP_MLP=split is bit-identical.)"""
+    NumericProfile, None (process default) or "current" (this thread's).  The remaining fields are constants since round 4 (the
+    superseded launch forms they once named are gone); they stay in the string so that round-3 streams keep decoding."""
     from . import ops
     from .models import packed
     if model_name == "OctAttention":
@@ -513,9 +541,7 @@ def numeric_profile(model_name, profile="current"):
     knn = _MODES["knn"] if profile is None else ("f16x3" if profile.knn_f16x3 else "f32")
     attn = _MODES["attn"] if profile is None else ("bf16x3" if profile.attention_bf16x3 else "f32")
     # ehem/3: patch merging and the geometry generator's edge MLPs on row-chain kernels (other last bits than ehem/2)
-    return (f"ehem/3:gemm={ops.MODE},knn={knn},attn={attn},concat={'hier' if packed.HIER else 'direct'},"
-            f"swin={'rowchain' if packed.ROWCHAIN else 'split'}" + ("" if (packed.MERGE_RC or not packed.ROWCHAIN) else ",merge=split") +
-            ("" if (packed.EDGE_RC or not packed.ROWCHAIN) else ",edge=split"))
+    return f"ehem/3:gemm={ops.MODE},knn={knn},attn={attn},concat={'hier' if packed.HIER else 'direct'},swin=rowchain"
 
 
 def edge_gather_max(u, v, idx, scale, shift, out=None):
@@ -867,20 +893,6 @@ def linear_split(a, sw, bias=None, act=ACT_NONE, residual=None, out=None, out_sp
                                 0 if o is None else o.t.stride(1), M, N, K, act, cfg, _stream())
     _check(rc, "scp_linear_split")
     return c if want == "f32" else (o if want == "split" else (c, o))
-
-
-def mlp_split_fused(a, sw1, b1, sw2, b2, residual=None):
-    """GELU(a @ W1.T + b1) @ W2.T + b2 + residual in one launch (256 -> 1024 -> 256; csrc/mlp_fused.hip): fp32 [M, 256]."""
-    if a.K != 256 or (sw1.N, sw1.K, sw2.N, sw2.K) != (1024, 256, 256, 1024):
-        raise ScpError("mlp_split_fused: 256 -> 1024 -> 256 only")
-    t = a.t
-    c = torch.empty((a.M, 256), dtype=torch.float32, device=t.device)
-    t1, t2 = sw1.tiled(), sw2.tiled()
-    rc = lib().scp_mlp_split_fused(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), t1[0].data_ptr(), t1[1].data_ptr(), t2[0].data_ptr(),
-                                   t2[1].data_ptr(), _dev(b1), _dev(b2), None if residual is None else residual.data_ptr(),
-                                   0 if residual is None else residual.stride(0), c.data_ptr(), c.stride(0), a.M, _stream())
-    _check(rc, "scp_mlp_split_fused")
-    return c
 
 
 class LnFoldedWeight:

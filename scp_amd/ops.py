@@ -3,26 +3,18 @@
 Default path: the hand-written bf16x3 MFMA GEMM (csrc/gemm.hip, fp32-class accuracy, fused bias / activation / residual
 epilogue) through the C ABI.  Layers the split does not cover (K % 4 != 0 or K < 32) and every layer that feeds a kNN search run
 on the exact fp32 MFMA kernel (scp_linear_f32): k-ordered FMA chains whose result does not depend on the batch, so the encoder's
-one packed launch and the decoder's per-window launches agree bit for bit.  `SCP_GEMM=f32` switches everything to plain fp32
-library GEMMs (rocBLAS / hipBLASLt via torch) - used by the tests to bracket the numerical effect of the split.  Everything here requires device tensors - there is no CPU path in the product.
+one packed launch and the decoder's per-window launches agree bit for bit.  There is ONE backend: every layer goes through the C ABI;
+a tensor that is not on the device raises ScpError (the fp32 library bracket the tests compare against lives in tests/).
 """
-import os
 import weakref
 
 import torch
-import torch.nn.functional as F
 
 from . import native
 
-MODE = os.environ.get("SCP_GEMM", "bf16x3")
+MODE = "bf16x3"      # the `gemm=` field of the stream's numeric-profile string (native.numeric_profile); a constant since round 4
 _ACT = {None: native.ACT_NONE, "leaky": native.ACT_LEAKY, "gelu": native.ACT_GELU, "relu": native.ACT_RELU}
 _cache = {}
-
-
-def set_mode(mode):
-    global MODE
-    assert mode in ("bf16x3", "f32")
-    MODE = mode
 
 
 def _split(w):
@@ -76,21 +68,14 @@ def linear(x, w, b=None, act=None, residual=None, exact=False, precise=False, sc
     the f16x3 kernel (22-bit operands: fp32-chain accuracy at the MFMA rate; OctAttention; `scales`: native.RowScales of x shared
     between layers that read the same rows)."""
     K = w.shape[1]
-    if MODE == "bf16x3" and x.is_cuda:
-        if precise and not exact and K % 4 == 0 and K >= 32:
-            return native.linear_f16x3(x, _split16(w), b, _ACT[act], residual, scales=scales)
-        if not exact and not precise and K % 4 == 0 and K >= 32:
-            return native.linear_bf16x3(x, _split(w), b, _ACT[act], residual)
-        # exact fp32 MFMA kernel: k-ordered FMA chains, results independent of how many rows share the launch
-        y = native.linear_f32(x, w, b, _ACT[act])
-        return y if residual is None else y + residual
-    y = F.linear(x, w, b)
-    if act == "leaky":
-        y = F.leaky_relu(y, 0.01)
-    elif act == "gelu":
-        y = F.gelu(y)
-    elif act == "relu":
-        y = torch.relu(y)
+    if not x.is_cuda:
+        raise native.ScpError("ops.linear: device tensor expected (the SCP hot path has no CPU or library-GEMM backend)")
+    if precise and not exact and K % 4 == 0 and K >= 32:
+        return native.linear_f16x3(x, _split16(w), b, _ACT[act], residual, scales=scales)
+    if not exact and not precise and K % 4 == 0 and K >= 32:
+        return native.linear_bf16x3(x, _split(w), b, _ACT[act], residual)
+    # exact fp32 MFMA kernel: k-ordered FMA chains, results independent of how many rows share the launch
+    y = native.linear_f32(x, w, b, _ACT[act])
     return y if residual is None else y + residual
 
 
@@ -128,7 +113,7 @@ def split_cat(parts, device=None):
 
 
 def layer_norm(x, ln):
-    return F.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
 
 
 def gelu_linear(x, w, b):

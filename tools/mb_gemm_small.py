@@ -10,7 +10,6 @@ def timeit(f, reps=20, warm=5):
     for _ in range(reps): f()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps * 1e3
-ops.set_mode("bf16x3")
 for M in (128, 512, 4096):
     for K in (32, 256, 1024, 2048):
         a = torch.randn((M, K), device=dev); w = torch.randn((256, K), device=dev); b = torch.randn(256, device=dev)

@@ -50,7 +50,6 @@ if 'gemm' in which:
     from scp_amd import ops
     for M, N, K in ((65536, 768, 256), (65536, 256, 256), (65536, 1024, 256), (65536, 256, 1024), (65536, 1024, 1280), (8192, 768, 256), (512, 768, 256)):
         a = torch.randn((M, K), device=dev); w = torch.randn((N, K), device=dev); b = torch.randn(N, device=dev); r = torch.randn((M, N), device=dev)
-        ops.set_mode("bf16x3")
         ms = timeit(lambda: ops.linear(a, w, b, act="gelu", residual=r))
         print(f"bf16x3 linear+gelu+res M={M} N={N} K={K}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.2f} TFLOP/s-equivalent")
     x = torch.randn((65536, 256), device=dev); ln_w = torch.ones(256, device=dev); ln_b = torch.zeros(256, device=dev)
