@@ -194,19 +194,15 @@ def measure_kernels(run, frames=3):
 def knn_pairs(enc, level_sizes):
     """Pair count of every packed kNN launch of a frame, in launch order (one per chunk of <= max_tokens tokens): the sum over 512-row
     chunks of n x 512 for the window they belong to (n = the window's even-padded length)."""
-    from scp_amd.encoder import EncodePlan
-    plan = EncodePlan(level_sizes, enc.context_size)
+    from scp_amd.encoder import EncodePlan, chunk_windows
+    ws = EncodePlan(level_sizes, enc.context_size).windows
     out = []
-    ws, i = plan.windows, 0
-    while i < len(ws):
-        j, tok, pairs = i, 0, 0
-        while j < len(ws) and (tok == 0 or tok + ws[j][1] <= enc.max_tokens):
-            n = ws[j][1] + (ws[j][1] & 1)
+    for i, j in chunk_windows(ws, enc.max_tokens):
+        pairs = 0
+        for w in ws[i:j]:
+            n = w[1] + (w[1] & 1)
             pairs += (-(-n // 512)) * 512 * n
-            tok += ws[j][1]
-            j += 1
         out.append(float(pairs))
-        i = j
     return out
 
 

@@ -319,7 +319,7 @@ def find_stream(out_root, ori):
     stem = `<sequence dir><frame>` for KITTI EHEM runs (encode.py:140-144 via the dataset's file name) or the plain file stem.  The
     reference takes the first name that merely CONTAINS the frame number (decode_ehem.py:206-214), which picks the wrong sequence's
     stream as soon as two sequences hold the same frame number; here the name must match exactly, and 0 or several candidates are
-    an error.  Returns the file name."""
+    an error.  Returns (file name, the stem that matched) - the stem names the decoder's `.ply`."""
     import re
     p = Path(ori)
     names = [f for f in os.listdir(out_root) if f.endswith(".bin")]
@@ -328,7 +328,7 @@ def find_stream(out_root, ori):
         pat = re.compile("^" + re.escape(stem) + r"((_spher|_cylin)?_\d+_-?\d+_-?\d+)?\.bin$")
         c = sorted(f for f in names if pat.match(f))
         if len(c) == 1:
-            return c[0]
+            return c[0], stem
         if len(c) > 1:
             raise native.ScpError(f"{len(c)} streams match {ori} in {out_root}: {c}")
         tried.append(stem)
@@ -369,10 +369,7 @@ def decode_main(argv=None, mullevel=False):
     elapsed, results = 0.0, []
     for i, ori in enumerate(files):
         print(f"{i}/{len(files)}")
-        name = find_stream(out_root, ori)
-        stem = name[:-4].split("_spher_")[0].split("_cylin_")[0]
-        if stem == name[:-4] and stem.count("_") >= 3:
-            stem = stem.rsplit("_", 3)[0]                      # Cartesian streams: <stem>_<levels>_<bin_num>_<z_offset>
+        name, stem = find_stream(out_root, ori)                # the stem that matched, not string surgery on the stream name
         binfile = out_root + name
         t0 = time.time()
         out = decode_file(binfile, model, args.lidar_level, args.type, mullevel, dev)

@@ -104,16 +104,33 @@ def pin_rank_threads(local, local_world, numa=True):
         return None
 
 
+def _local_nodes(local, local_world):
+    """NUMA node of the device EVERY local rank drives, agreed between the ranks: each rank looks up only the device it actually uses
+    (torch.cuda.current_device(): right under per-rank HIP_VISIBLE_DEVICES and under SCP_FORCE_DEVICE alike) and the ranks exchange the
+    answers (all_gather_object over the initialised process group).  None when there is no process group to agree through or when ANY
+    rank could not resolve its node - then every rank takes the plain split, so two schemes can never hand out overlapping cores."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return None
+    mine = (int(os.environ.get("GROUP_RANK", "0")), local, _gpu_numa_node(torch.cuda.current_device()) if torch.cuda.is_available() else None)
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    here = sorted((l, n) for g, l, n in everyone if g == mine[0])
+    if len(here) != local_world or [l for l, _ in here] != list(range(local_world)) or any(n is None for _, n in here):
+        return None
+    return [n for _, n in here]
+
+
 def _pin_rank_threads(local, local_world, numa):
     allowed = set(os.sched_getaffinity(0))
     peers, slot, pool = local_world, local, allowed
-    if numa:
-        nodes = [_gpu_numa_node(i) for i in range(local_world)]
-        mine_node = nodes[local] if local < len(nodes) else None
-        node_cpus = _node_cpus(mine_node) if mine_node is not None else None
-        if node_cpus and (node_cpus & allowed):
+    nodes = _local_nodes(local, local_world) if numa else None
+    if nodes is not None:
+        mine_node = nodes[local]
+        cpus_of = {n: _node_cpus(n) for n in set(nodes)}
+        # the NUMA split is used only if it works for EVERY node involved (every rank evaluates the same condition on the same data)
+        if all(c and (c & allowed) for c in cpus_of.values()):
             same = [i for i, n in enumerate(nodes) if n == mine_node]
-            peers, slot, pool = len(same), same.index(local), node_cpus & allowed
+            peers, slot, pool = len(same), same.index(local), cpus_of[mine_node] & allowed
     cores = _core_groups(pool)
     per = len(cores) // peers
     if per < 2:

@@ -75,6 +75,31 @@ class EncodePlan:
         return order
 
 
+# scp_swin_ln_qkv addresses its K / V planes through one 32-bit buffer resource: 4 planes x Tp rows x 512 B must stay below 2^31, i.e. a
+# packed forward holds at most 1 048 575 rows of the PADDED layout (every window owns a multiple of 512 rows)
+MAX_PACKED_ROWS = 1_048_064
+
+
+def chunk_windows(windows, max_tokens):
+    """Cut a frame's window list into the chunks of one packed forward each: [(first window, one past the last)].  A chunk holds at most
+    `max_tokens` real tokens AND at most MAX_PACKED_ROWS rows of the padded layout (a window of c nodes owns ceil((c + c % 2) / 512) * 512
+    rows at stage 0: tail windows of a few nodes still cost 512 rows each, which a token bound alone does not see)."""
+    out, i = [], 0
+    while i < len(windows):
+        j, tok, rows = i, 0, 0
+        while j < len(windows):
+            c = windows[j][1]
+            r = -(-(c + (c & 1)) // 512) * 512
+            if tok and (tok + c > max_tokens or rows + r > MAX_PACKED_ROWS):
+                break
+            tok += c
+            rows += r
+            j += 1
+        out.append((i, j))
+        i = j
+    return out
+
+
 def _quant_of(infos):
     """Per shell the quantiser's (qs[3], offset[3]) as plain floats: what de-quantisation needs and the reference's file name cannot
     carry exactly (decoder.write_sidecar)."""
@@ -250,15 +275,9 @@ class FrameEncoder:
     def packed_plans(self, plan):
         """The frame's windows cut into chunks of <= max_tokens tokens, each with its index maps: [(first row, tokens, PackedPlan)]."""
         from .models.packed import PackedPlan
-        ws, out, i = plan.windows, [], 0
-        while i < len(ws):
-            j, tok = i, 0
-            while j < len(ws) and (tok == 0 or tok + ws[j][1] <= self.max_tokens):
-                tok += ws[j][1]
-                j += 1
-            out.append((ws[i][0], tok, PackedPlan([w[1] for w in ws[i:j]], device=self.device)))
-            i = j
-        return out
+        ws = plan.windows
+        return [(ws[i][0], sum(w[1] for w in ws[i:j]), PackedPlan([w[1] for w in ws[i:j]], device=self.device))
+                for i, j in chunk_windows(ws, self.max_tokens)]
 
     def encode(self, xyz, timing=False):
         """xyz: numpy / torch float32 [P,3].  Returns dict(bytes, bits, bpp, n_nodes, n_points, bin_num, z_offset,

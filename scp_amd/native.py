@@ -488,6 +488,7 @@ class NumericProfile:
         return numeric_profile(model_name, self)
 
     def __del__(self):
+        # a profile that is current somewhere is referenced by that `use_profile` object, so this only runs for profiles nobody uses
         try:
             if self._h:
                 lib().scp_ctx_destroy(self._h)
@@ -511,13 +512,13 @@ class use_profile:
 
     def __enter__(self):
         self.prev = current_profile()
-        _TLS.profile = self.profile
         _check(lib().scp_ctx_make_current(self.profile._h if self.profile is not None else None), "scp_ctx_make_current")
+        _TLS.profile = self.profile           # only once the C side has switched: the two thread-local views never disagree
         return self.profile
 
     def __exit__(self, *exc):
-        _TLS.profile = self.prev
         lib().scp_ctx_make_current(self.prev._h if self.prev is not None else None)
+        _TLS.profile = self.prev
         return False
 
 
@@ -628,7 +629,11 @@ class SplitWeight:
         note_cache_fill()
 
     def tiled(self):
-        """(hi, lo) as the dense kernels stream them: tiled (_tile_planes) by default, row-major under SCP_WTILE=0."""
+        """(hi, lo) as the dense kernels stream them: tiled (_tile_planes) by default, row-major under SCP_WTILE=0.  A weight built with
+        the other layout than the library reads (the `tiled=` override exists for the layout tests) is refused, not multiplied."""
+        if self.tiled_layout != WTILE:
+            raise ScpError("SplitWeight: planes are %s but the library reads %s planes (SCP_WTILE)" % (
+                "tiled" if self.tiled_layout else "row-major", "tiled" if WTILE else "row-major"))
         return (self.hi, self.lo)
 
 
@@ -659,6 +664,8 @@ def linear_bf16x3(x, sw, bias=None, act=ACT_NONE, residual=None, out=None):
 
 
 def _tiled_pair(sw):
+    if sw.tiled_layout != WTILE:
+        raise ScpError("weight planes are not in the layout the library reads (SCP_WTILE)")
     return (sw.hi, sw.lo)
 
 

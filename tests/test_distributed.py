@@ -24,7 +24,15 @@ def _worker(rank, world, port, q):
     # pretend every frame i costs bpp = i, time = 2i
     sums = [sum(i for i, _ in mine), 0.0, 0.0, sum(2 * i for i, _ in mine), len(mine)]
     total = D.reduce_summary(sums)
-    q.put((r, [i for i, _ in mine], total))
+    # NUMA-aware pinning agrees between the ranks: each rank resolves only ITS device's node and the answers are exchanged; if any rank
+    # cannot resolve its node (rank 1 here), every rank falls back to the plain split - never two schemes with overlapping cores
+    D._gpu_numa_node = lambda i: 0
+    torch.cuda.is_available = lambda: True
+    torch.cuda.current_device = lambda: 0
+    both = D._local_nodes(r, w)
+    D._gpu_numa_node = (lambda i: None) if r == 1 else (lambda i: 0)
+    one_missing = D._local_nodes(r, w)
+    q.put((r, [i for i, _ in mine], total, both, one_missing))
     D.finalize()
 
 
@@ -41,8 +49,9 @@ def test_frame_sharding_and_summary_reduction_world2():
         assert p.exitcode == 0
     res.sort()
     assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5]          # round-robin, disjoint, complete
-    for _, _, total in res:
+    for _, _, total, both, one_missing in res:
         assert total == [21.0, 0.0, 0.0, 42.0, 7.0]                        # both ranks see the global sums
+        assert both == [0, 0] and one_missing is None                      # the NUMA view is agreed, or dropped by everyone
     from scp_amd import distributed as D
     m = D.summary_means(res[0][2])
     assert m["bpp"] == 3.0 and m["time"] == 6.0 and m["count"] == 7
@@ -63,7 +72,7 @@ def test_rank_thread_pinning_splits_the_host_cores(monkeypatch):
     monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: calls.append(list(cpus)), raising=False)
     monkeypatch.setattr(torch, "set_num_threads", lambda n: None)
     monkeypatch.setattr(D, "_core_groups", lambda cpus: [[c] for c in sorted(cpus)])
-    monkeypatch.setattr(D, "_gpu_numa_node", lambda i: None)
+    monkeypatch.setattr(D, "_local_nodes", lambda local, lw: None)
     monkeypatch.setattr(D, "_set_affinity_all_threads", lambda cpus: os.sched_setaffinity(0, cpus))
     assert D.pin_rank_threads(0, 8) == [0, 1] and D.pin_rank_threads(7, 8) == [14, 15] and D.pin_rank_threads(1, 2) == list(range(8, 16))
     assert calls == [[0, 1], [14, 15], list(range(8, 16))]
@@ -72,9 +81,11 @@ def test_rank_thread_pinning_splits_the_host_cores(monkeypatch):
     monkeypatch.setattr(D, "_core_groups", lambda cpus: [[c, c + 8] for c in sorted(cpus) if c < 8 and c + 8 in cpus] or [[c] for c in sorted(cpus)])
     assert D.pin_rank_threads(1, 4) == [2, 3, 10, 11]
     monkeypatch.setattr(D, "_core_groups", lambda cpus: [[c] for c in sorted(cpus)])
-    monkeypatch.setattr(D, "_gpu_numa_node", lambda i: i // 2)                  # GPUs 0,1 on node 0; 2,3 on node 1
-    monkeypatch.setattr(D, "_node_cpus", lambda n: set(range(8 * n, 8 * n + 8)))
-    assert D.pin_rank_threads(2, 4) == [8, 9, 10, 11] and D.pin_rank_threads(1, 4) == [4, 5, 6, 7]
+    monkeypatch.setattr(D, "_local_nodes", lambda local, lw: [i // 2 for i in range(lw)])      # ranks 0,1 drive GPUs on node 0; 2,3 on node 1
+    monkeypatch.setattr(D, "_node_cpus", lambda n: set(range(4 * n, 4 * n + 4)) | set(range(8 + 4 * n, 12 + 4 * n)))
+    assert D.pin_rank_threads(2, 4) == [4, 5, 6, 7] and D.pin_rank_threads(1, 4) == [8, 9, 10, 11] and D.pin_rank_threads(3, 4) == [12, 13, 14, 15]
+    monkeypatch.setattr(D, "_node_cpus", lambda n: None if n == 1 else set(range(8)))           # one node's cpulist unreadable: plain split for all
+    assert D.pin_rank_threads(2, 4) == [8, 9, 10, 11] and D.pin_rank_threads(0, 4) == [0, 1, 2, 3]
     n_calls = len(calls)
     monkeypatch.setenv("SCP_PIN", "0")
     assert D.pin_rank_threads(0, 8) is None and len(calls) == n_calls

@@ -44,4 +44,26 @@ def test_bench_single_rank_line_has_the_contract_fields():
               "config", "roofline"):
         assert k in out
     assert out["n_gpus"] == 1 and out["rccl_world"] == 1 and "ranks" not in out
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "valid", "kernel_ms_sum", "kernel_ms_bound"} <= set(out["roofline"])
+    # the self-check of the live roofline (VERDICT r3 item 1 iv): the event-timed kernels of a frame cannot take longer than the synchronised
+    # wall time of the same frame's model stage - if they do, the brackets measured host time and the line says so
+    r = out["roofline"]
+    assert r["valid"] is True and 0 < r["kernel_ms_sum"] <= 1.02 * r["kernel_ms_bound"]
+    assert 0 < r["frac"] < 1 and r["traffic"] is None              # PMC traffic is quoted for the configuration it was measured on only
+    ks = out["roofline_kernels"]
+    assert "rc_post_attn_kernel" in ks and "swin_attn_planes_kernel" in ks and "knn_f16x3_wg256_kernel" in ks
+    assert abs(sum(k["total_ms_per_frame"] for n, k in ks.items() if n != "cdf_kernel") - r["kernel_ms_sum"]) < 1e-6 * r["kernel_ms_sum"]
+    for k in ks.values():
+        assert k["launches_per_frame"] >= 1 and k["avg_launch_us"] > 0 and ("frac" not in k or 0 < k["frac"] < 1)
+    f = out["roofline_frame"]
+    assert f["flops"] > 1e12 and 0 < f["frac_mfma"] < 1 and f["attention_flops"] < f["flops"]
+    s = out["strict_identity"]
+    assert s["fps"] > 0 and out["strict_identity_fps"] == s["fps"] and abs(s["bpp_mean"] - out["bpp_mean"]) < 0.05 * out["bpp_mean"]
+    tp = out["transform_parity"]
+    assert tp["host_transform"] == [0] and tp["device_transform"][0] > 0       # L12 --spher: the strict mode has the reference's integers, the device one misses 853 points
+
+
+def test_bench_decode_mode_times_the_decoder_and_checks_the_round_trip():
+    out = _run(["--decode", "--steps", "1", "--warmup", "1", "--config", "ehem-L12-s"])
+    assert out["decoded_occupancy_equals_encoded"] is True and out["value"] > 0 and "decode" in out["metric"]
+    assert out["config"]["phase2_launch_sequences_per_frame"] >= 10

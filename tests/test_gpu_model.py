@@ -1317,3 +1317,28 @@ def test_given_the_reference_neighbour_choice_every_lattice_row_matches(dev, ehe
     parity_record(f"{name}/reference neighbour lists", rows=e.shape[0], rows_within_1e3=(e.max(1) <= LOGIT_TOL).mean(), max_dlogit=e.max())
     print(f"{name}: with the reference's neighbour lists max|dlogit| = {e.max():.3e}, rows within 1e-3: {100 * (e.max(1) <= LOGIT_TOL).mean():.2f} %")
     assert e.max() <= LOGIT_TOL
+
+
+@pytest.mark.gpu
+def test_launch_brackets_record_inside_the_library(dev):
+    """include/scp_debug.h scp_prof_*: while enabled, a bracketed entry point records a hipEvent pair around its launch - tag, algorithmic
+    work and a positive duration per launch, in launch order; nothing is recorded outside the `with` block."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((4096, 256), generator=g).to(dev)
+    w = torch.randn((512, 256), generator=g).to(dev)
+    sw = native.SplitWeight(w)
+    a = native.split_rows(x)
+    torch.cuda.synchronize()
+    with native.launch_profile() as p:
+        native.linear_split(a, sw)
+        native.split_rows(x)
+        native.linear_split(a, sw)
+    native.linear_split(a, sw)                       # outside: not recorded
+    recs = p.records()
+    assert [r[0] for r in recs] == ["gemm_split", "split_rows", "gemm_split"]
+    assert all(0 < r[1] < 50 for r in recs)
+    assert recs[0][2] == 2.0 * 4096 * 512 * 256 and recs[1][2] == 8.0 * 4096 * 256
+    with native.launch_profile() as p:
+        pass
+    assert p.records() == []

@@ -215,13 +215,54 @@ def test_decode_cli_finds_exactly_the_stream_the_encoder_wrote(tmp_path):
               "cart3_12_0_-200.bin", "thing_vox6.bin", "11000001_spher_10_820_0.bin.dat"):
         (out / n).write_bytes(b"")
     root = str(out) + "/"
-    assert find_stream(root, "/data/kitti/11/000001.bin") == "11000001_spher_10_820_0.bin"
-    assert find_stream(root, "/data/kitti/12/000001.bin") == "12000001_spher_10_821_0.bin"
-    assert find_stream(root, "/data/kitti/00/000010.bin") == "00000010_spher_10_800_0.bin"
-    assert find_stream(root, "ford/frame7.ply") == "frame7_cylin_12_3279_-1.bin"
-    assert find_stream(root, "x/cart3.bin") == "cart3_12_0_-200.bin" and find_stream(root, "thing_vox6.ply") == "thing_vox6.bin"
+    # (stream name, the stem that matched): the stem names the decoder's .ply - no string surgery on the stream name
+    assert find_stream(root, "/data/kitti/11/000001.bin") == ("11000001_spher_10_820_0.bin", "11000001")
+    assert find_stream(root, "/data/kitti/12/000001.bin") == ("12000001_spher_10_821_0.bin", "12000001")
+    assert find_stream(root, "/data/kitti/00/000010.bin") == ("00000010_spher_10_800_0.bin", "00000010")
+    assert find_stream(root, "ford/frame7.ply") == ("frame7_cylin_12_3279_-1.bin", "frame7")
+    assert find_stream(root, "x/cart3.bin") == ("cart3_12_0_-200.bin", "cart3") and find_stream(root, "thing_vox6.ply") == ("thing_vox6.bin", "thing_vox6")
+    # an un-suffixed stream whose own stem holds three underscores keeps its whole stem (it used to be cut to `a`)
+    (out / "a_b_c_d.bin").write_bytes(b"")
+    assert find_stream(root, "objs/a_b_c_d.ply") == ("a_b_c_d.bin", "a_b_c_d")
     with pytest.raises(native.ScpError):
         find_stream(root, "/data/kitti/13/000001.bin")          # `000001` is a substring of three names, a match of none
     (out / "11000001_spher_10_999_0.bin").write_bytes(b"")
     with pytest.raises(native.ScpError):
         find_stream(root, "/data/kitti/11/000001.bin")
+
+
+def test_packed_chunks_respect_the_padded_row_limit():
+    """A packed forward addresses its K / V planes through one 32-bit buffer resource: chunks are cut on real tokens AND on rows of the
+    padded layout (tail windows of a few nodes cost 512 rows each; a token bound alone overflowed the limit for batches of
+    small frames and for max_tokens above 1M)."""
+    from scp_amd.encoder import MAX_PACKED_ROWS, EncodePlan, chunk_windows
+    sizes = [1, 6, 20, 56, 208, 1372, 5605, 21322, 34427, 52308] * 16            # 16 level-12-like frames back to back
+    ws = EncodePlan(sizes, 8192).windows
+
+    def rows(i, j):
+        return sum(-(-(w[1] + (w[1] & 1)) // 512) * 512 for w in ws[i:j])
+    for max_tokens in (1_000_000, 5_000_000, 100):
+        ch = chunk_windows(ws, max_tokens)
+        assert ch[0][0] == 0 and ch[-1][1] == len(ws) and all(a[1] == b[0] for a, b in zip(ch, ch[1:]))      # a partition, in order
+        for i, j in ch:
+            assert j > i and rows(i, j) <= MAX_PACKED_ROWS
+            assert sum(w[1] for w in ws[i:j]) <= max_tokens or j == i + 1
+    assert len(chunk_windows(ws, 5_000_000)) >= 2 and 4 * MAX_PACKED_ROWS * 512 <= 0x7fffffff
+    assert chunk_windows(ws[:5], 1_000_000) == [(0, 5)]
+
+
+def test_frame_flop_formula_matches_the_survey():
+    """bench.py prices a frame with SURVEY.md 8d's formulas: 310.2 GFLOP per full EHEM window (40.0 of them attention), 27.9 per
+    OctAttention window (11.3 attention)."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("scp_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(b)
+    finally:
+        sys.argv = argv
+    assert abs(b.ehem_window_flops(8192) / 1e9 - 310.2) < 0.1 and abs(b.ehem_window_flops(8192, True) / 1e9 - 40.0) < 0.05
+    assert abs(b.octattn_window_flops(1024) / 1e9 - 27.9) < 0.1 and abs(b.octattn_window_flops(1024, True) / 1e9 - 11.3) < 0.05
+    assert b.ehem_window_flops(1) == b.ehem_window_flops(2) and b.ehem_window_flops(600) < b.ehem_window_flops(1024)
