@@ -38,6 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md: aggregate L2 bandwidth
 PMC_PROFILE = "r4_pmc_traffic.json"     # profiles/: HBM bytes per launch / per frame from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh)
 
 
@@ -163,7 +164,7 @@ KERNEL_OF = {   # launch-bracket tag -> (kernel name as rocprofv3 prints it, bou
     "gemm_f32": ("gemm_f32_kernel", "mfma_f32", "exact k-ordered fp32 layers feeding a kNN search"),
     "gemm_rows": ("gemm_bf16x3_kernel", "mfma", "dense layers reading fp32 rows (split in the tile)"),
     "oa_attention": ("oa_attn_f16x3_kernel", "mfma", "dual-stream causal attention, non-causal flop count (SURVEY.md 8d)"),
-    "edge_gather": ("edge_gather_max_kernel", "hbm", "neighbour gather + max + BN + LeakyReLU"),
+    "edge_gather": ("edge_gather_max_kernel", "l2", "neighbour gather + max + BN + LeakyReLU: 20 gathered rows per point, served by L2 (priced against its 34.5 TB/s)"),
     "cdf": ("cdf_kernel", "hbm", "softmax + serial fp32 cumsum -> (c_low, c_high)"),
     "split_rows": ("split_rows_kernel", "hbm", "fp32 rows -> hi / lo planes"),
     "layernorm": ("layernorm_*_kernel", "hbm", "LayerNorm passes left outside the row-chain kernels"),
@@ -238,6 +239,8 @@ def roofline_entry(tag, d):
                  flops_per_launch=d["work_per_launch"])
     elif bound == "hbm":
         e.update(achieved=d["rate"] / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=d["rate"] / 1e9 / HBM_PEAK_GBS, bytes_per_launch=d["work_per_launch"])
+    elif bound == "l2":
+        e.update(achieved=d["rate"] / 1e9, peak=L2_PEAK_GBS, unit="GB/s", frac=d["rate"] / 1e9 / L2_PEAK_GBS, bytes_per_launch=d["work_per_launch"])
     return e
 
 

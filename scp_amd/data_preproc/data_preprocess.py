@@ -60,19 +60,31 @@ def host_quantize(xyz, mode, qs, cart_offset=-200.0):
     divide `(points - offset) / qs_vec` and round-half-even.  This is the STRICT-IDENTITY path: the device transform
     (csrc/geom.hip: transform_kernel) evaluates atan2 / acos in float64 and rounds once, which is more accurate than numpy's float32
     routines and therefore not the same integers for a few points per frame.  Returns (int32 [P,3], HostQuantInfo)."""
+    return host_quantize_shells(xyz, mode, [qs], cart_offset)[0]
+
+
+def host_quantize_shells(xyz, mode, qs_list, cart_offset=-200.0):
+    """host_quantize for every shell of a multi-level frame: the transform depends on the points only (the reference recomputes the same
+    float32 values per shell, data_preprocess.py:107-138), so it runs ONCE and each quantisation step quantises its own copy.
+    -> [(int32 [P,3], HostQuantInfo)] in the order of qs_list."""
     pts = np.ascontiguousarray(xyz[:, :3], np.float32)
+    tr = cart2cylin(pts) if mode == native.CYLIN else (cart2spher(pts) if mode == native.SPHER else pts)
+    rho_max = tr[:, 0].max() if mode != native.CART else None
+    z_min = min(tr[:, 2]) if mode == native.CYLIN else None
+    return [_quantize_transformed(tr, mode, qs, cart_offset, rho_max, z_min) for qs in qs_list]
+
+
+def _quantize_transformed(tr, mode, qs, cart_offset, rho_max, z_min):
     if mode == native.CYLIN:
-        tr = cart2cylin(pts)
-        bin_num = np.round(tr[:, 0].max() / qs) + 1
+        bin_num = np.round(rho_max / qs) + 1
         qsv = np.array([qs, 2 * math.pi / (bin_num - 1), qs])[True]
-        off = np.array([0.0, 0.0, min(tr[:, 2])])[True]
+        off = np.array([0.0, 0.0, z_min])[True]
     elif mode == native.SPHER:
-        tr = cart2spher(pts)
-        bin_num = np.round(tr[:, 0].max() / qs) + 1
+        bin_num = np.round(rho_max / qs) + 1
         qsv = np.array([qs, 2 * math.pi / (bin_num - 1), math.pi / (bin_num - 1)])[True]
         off = 0
     else:
-        tr, bin_num, qsv, off = pts, 0.0, qs, cart_offset
+        bin_num, qsv, off = 0.0, qs, cart_offset
     q = np.round((tr - off) / qsv)
     return q.astype(np.int32), HostQuantInfo(bin_num, qsv, off)
 

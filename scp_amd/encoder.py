@@ -140,9 +140,9 @@ class FrameEncoder:
     def host_ints(self, xyz):
         """The strict-identity front end: numpy [P,>=3] float32 -> (per-shell int32 arrays, infos) exactly as the reference computes
         them (scp_amd/data_preproc/data_preprocess.py: host_quantize).  Runs on the host; the CLI calls it on its reader thread."""
-        from .data_preproc.data_preprocess import host_quantize
+        from .data_preproc.data_preprocess import host_quantize_shells
         xyz = np.ascontiguousarray(xyz.cpu().numpy() if isinstance(xyz, torch.Tensor) else xyz, np.float32)
-        out = [host_quantize(xyz, self.mode, level_qs(self.data_type, lv), 0.0 if self.mullevel else self.cart_offset) for _, lv in self.shells()]
+        out = host_quantize_shells(xyz, self.mode, [level_qs(self.data_type, lv) for _, lv in self.shells()], 0.0 if self.mullevel else self.cart_offset)
         return [q for q, _ in out], [i for _, i in out]
 
     def quantize(self, xyz_dev, ints=None):
@@ -539,9 +539,9 @@ class OctAttnFrameEncoder:
 
     def quantize(self, xyz_dev):
         if self.host_transform:
-            from .data_preproc.data_preprocess import host_quantize
+            from .data_preproc.data_preprocess import host_quantize_shells
             xyz = np.ascontiguousarray(xyz_dev.cpu().numpy(), np.float32)
-            out = [host_quantize(xyz, self.mode, level_qs(self.data_type, lv), 0.0 if self.mullevel else self.cart_offset) for _, lv in self.shells()]
+            out = host_quantize_shells(xyz, self.mode, [level_qs(self.data_type, lv) for _, lv in self.shells()], 0.0 if self.mullevel else self.cart_offset)
             return [torch.from_numpy(q).to(self.device) for q, _ in out], out[0][1].bin_num
         qs, bin_num = [], None
         for path, lv in self.shells():

@@ -784,7 +784,7 @@ def test_cli_decode_picks_the_stream_of_the_right_sequence(tmp_path, orc):
     assert r.returncode == 0, r.stderr[-2000:]
     names = sorted(p.name for p in out.iterdir() if p.name.endswith(".bin"))
     assert len(names) == 2 and names[0].startswith("11000001_") and names[1].startswith("12000001_")
-    assert find_stream(str(out) + "/", files[0]) == names[0] and find_stream(str(out) + "/", files[1]) == names[1]
+    assert find_stream(str(out) + "/", files[0]) == (names[0], "11000001") and find_stream(str(out) + "/", files[1]) == (names[1], "12000001")
     r = _run_cli("decode_ehem.py", ["--test_files"] + files + ["--random_weights", "0", "--out_dir", str(out)], tmp_path)
     assert r.returncode == 0, r.stderr[-2000:]
     a, b = ptread(str(out / "11000001.ply")), ptread(str(out / "12000001.ply"))
