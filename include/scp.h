@@ -122,6 +122,16 @@ SCP_API int scp_geom_destroy(scp_geom *g);
 SCP_API int scp_geom_build(scp_geom *g, const int32_t *q, int64_t n, const scp_segment *segs, int32_t nseg,
                    scp_segment_info *info, void *stream);
 
+/* The float front end and the build in ONE launch sequence (stage G1 + G2; two host read-backs instead of two per shell + three):
+ * frames: nframes device arrays float32 [n_points[f]][3]; every frame is cut into nshell trees - shell s with step qs[s], the rho-shell
+ * path and drop_last of shells[s] (their point_begin / point_count are ignored) - segment index = f * nshell + s.  Every point is
+ * transformed once (front_transform_kernel), one kernel then quantises it per shell, applies the shell filter and writes the Morton keys
+ * together with the sort's first digit histogram (front_key_kernel).  Same integers as scp_quantize, same trees as scp_geom_build.
+ * qinfo / info: host arrays [nframes * nshell]; q_out (optional, may be NULL): device int32 [sum over segments of n_points][3]. */
+SCP_API int scp_geom_build_xyz(scp_geom *g, const float *const *frames, const int64_t *n_points, int32_t nframes, int32_t mode,
+                               const double *qs, int32_t nshell, double cart_offset, const scp_segment *shells, int32_t *q_out,
+                               scp_quant_info *qinfo, scp_segment_info *info, void *stream);
+
 /* Node tables of the last build, all segments concatenated (segment s starts at node_base[s];
  * inside a segment nodes are in BFS order = level by level, Morton order inside a level).
  * Every pointer is a device buffer of total_nodes elements and may be NULL to skip that column.
@@ -158,6 +168,13 @@ enum { SCP_POS_MINMAX = 0,       /* (p-min)/(max-min+1e-9), scalar min/max per l
  *   pos_mm int64 [D][2]      (min,max) per level - DEVICE pointer, may be NULL                   */
 SCP_API int scp_geom_context_ehem(scp_geom *g, int32_t seg, int32_t pos_mode, int32_t lidar_level,
                           uint8_t *ctx, float *pos, uint8_t *sym, int64_t *pos_mm, void *stream);
+
+/* scp_geom_context_ehem for EVERY segment of the build in one launch: rows of all segments back to back (segment s starts at the sum of
+ * the earlier segments' n_nodes - drop_last), pos_mm int64 [sum of depths][2], and the coded symbols in CODING ORDER (encode.py:109-136:
+ * every level cut into windows of context_size rows; inside a window the even positions first, then the odd ones) - sym_coded[k] is
+ * the symbol the range coder takes k-th, no coding-order index needed.  Any of pos / sym_coded / pos_mm may be NULL. */
+SCP_API int scp_geom_context_ehem_all(scp_geom *g, int32_t pos_mode, int32_t lidar_level, int32_t context_size, uint8_t *ctx, float *pos,
+                                      uint8_t *sym_coded, int64_t *pos_mm, void *stream);
 
 /* OctAttention: ctx uint8 [rows][12] = (occ-1|255, level, octant) x 4; pos float32 [rows][4][3] =
  * xyz / 2^D for all four rows (no front padding - the window kernel pads on the fly). */

@@ -196,8 +196,13 @@ extern "C" int scp_quantize(const float *xyz, int64_t n, int32_t mode, double qs
 struct scp_geom {
     DevBuf segtab, keys_a, keys_b, red, blkcnt, leafkey, leafoct;
     DevBuf occ, level, octant, parent, pos, fchild, posmm;
+    DevBuf tr, front;             // scp_geom_build_xyz: transformed coordinates of every frame, the frame / shell tables of its two kernels
+    DevBuf rowtab;                // scp_geom_context_ehem_all: per-segment row bases
     RadixWorkspace radix;
     std::vector<SegTab> segs;     // host mirror
+    std::vector<int32_t> mm_host; // initial (min, max) words of a build: a member, so the copy that reads it never outlives it
+    std::vector<int64_t> rowtab_host; // [0, nseg): first context row of every segment, [nseg, 2 nseg): first (min, max) row (scp_geom_context_ehem_all)
+    hipEvent_t h2d_done = nullptr; // recorded behind the last host -> device table copy of a build (see geom_take_segments)
     uint64_t *sorted = nullptr;
     int64_t n_keys = 0, total_nodes = 0, total_leaves = 0;
     int nseg = 0, lmax = 0, ntiles = 0;
@@ -396,8 +401,9 @@ extern "C" int scp_geom_create(scp_geom **out) {
 extern "C" int scp_geom_destroy(scp_geom *g) {
     if (!g) return SCP_EINVAL;
     DevBuf *all[] = {&g->segtab, &g->keys_a, &g->keys_b, &g->red, &g->blkcnt, &g->leafkey, &g->leafoct, &g->occ, &g->level,
-                     &g->octant, &g->parent, &g->pos, &g->fchild, &g->posmm, &g->radix.counts};
+                     &g->octant, &g->parent, &g->pos, &g->fchild, &g->posmm, &g->radix.counts, &g->tr, &g->front, &g->rowtab};
     for (DevBuf *b : all) b->release();
+    if (g->h2d_done) (void)hipEventDestroy(g->h2d_done);
     delete g;
     return SCP_OK;
 }
@@ -407,68 +413,19 @@ static inline int grid_for(int64_t n) { int64_t b = cdiv64(n > 0 ? n : 1, WG); r
 
 void scp_launch_scan_u32(uint32_t *counts, int64_t m, hipStream_t st);  // sort_u64.hip
 
-extern "C" int scp_geom_build(scp_geom *g, const int32_t *q, int64_t n, const scp_segment *segs, int32_t nseg,
-                              scp_segment_info *info, void *stream) {
-    if (!g || !q || !segs || !info || n <= 0 || nseg <= 0 || nseg > SCP_MAX_SEGMENTS) return SCP_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    g->built = false;
-    g->nseg = nseg;
-    g->segs.assign(nseg, SegTab());
-    int64_t nk = 0, maxcount = 0;
-    for (int s = 0; s < nseg; ++s) {
-        SegTab &t = g->segs[s];
-        memset(&t, 0, sizeof(t));
-        if (segs[s].point_begin < 0 || segs[s].point_count <= 0 || segs[s].point_begin + segs[s].point_count > n ||
-            segs[s].path_len < 0 || segs[s].path_len > 8)
-            return SCP_EINVAL;
-        t.pt_begin = segs[s].point_begin; t.pt_count = segs[s].point_count; t.key_begin = nk;
-        t.path_len = segs[s].path_len; t.path_bits = segs[s].path_bits; t.drop_last = segs[s].drop_last ? 1 : 0;
-        for (int L = 0; L < NLV; ++L) t.rank0[L] = -1;  // marker: "segment owns no key"
-        nk += t.pt_count;
-        if (t.pt_count > maxcount) maxcount = t.pt_count;
-    }
-    g->n_keys = nk;
-    int rc;
-    if ((rc = g->segtab.reserve(sizeof(SegTab) * nseg))) return rc;
-    if ((rc = g->red.reserve(sizeof(int32_t) * 2 * nseg + 64))) return rc;
-    if ((rc = g->keys_a.reserve(sizeof(uint64_t) * nk))) return rc;
-    if ((rc = g->keys_b.reserve(sizeof(uint64_t) * nk))) return rc;
+// everything behind the keys: sort, head counts, node layout (the build's one size hand-back to the host), node tables.
+// g->segs[s] holds pt_count / key_begin / path / drop_last / depth, the device SegTab is current, keys_a holds the unsorted keys.
+static int geom_build_sorted(scp_geom *g, scp_segment_info *info, int dmax, hipStream_t st, bool first_hist_done) {
+    const int nseg = g->nseg;
+    const int64_t nk = g->n_keys;
     SegTab *dtab = g->segtab.as<SegTab>();
-
-    // --- depth of every segment (Octree.py:58) --------------------------------------------------------------
-    std::vector<int32_t> red(2 * nseg);
-    for (int s = 0; s < nseg; ++s) { red[2 * s] = INT32_MIN; red[2 * s + 1] = INT32_MAX; }
-    HIP_TRY(hipMemcpyAsync(g->red.p, red.data(), red.size() * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dtab, g->segs.data(), sizeof(SegTab) * nseg, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(seg_minmax_kernel, dim3(std::min(grid_for(maxcount * 3), 64), nseg), dim3(WG), 0, st, q, (const SegTab *)dtab, g->red.as<int32_t>());
-    LAUNCH_CHECK();
-    HIP_TRY(hipMemcpyAsync(red.data(), g->red.p, red.size() * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    int dmax = 0;
-    for (int s = 0; s < nseg; ++s) {
-        const int32_t mx = red[2 * s], mn = red[2 * s + 1];
-        if (mn < 0) return SCP_EINVAL;
-        int d = 0;
-        while (((int64_t)1 << d) < (int64_t)mx + 1) ++d;
-        // depth 0 (all-zero cloud) aborts inside the reference as well
-        if (d == 0 || d > SCP_MAX_DEPTH - 2 || g->segs[s].path_len > d) return SCP_EINVAL;
-        g->segs[s].depth = d;
-        if (d > dmax) dmax = d;
-        memset(&info[s], 0, sizeof(info[s]));
-        info[s].depth = d;
-        info[s].max_coord = mx;
-    }
     g->lmax = dmax + 1;
     const int lmax = g->lmax;
-
-    // --- keys + sort ----------------------------------------------------------------------------------------
-    HIP_TRY(hipMemcpyAsync(dtab, g->segs.data(), sizeof(SegTab) * nseg, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(morton_key_kernel, dim3(grid_for(maxcount), nseg), dim3(WG), 0, st, q, (const SegTab *)dtab, g->keys_a.as<uint64_t>());
-    LAUNCH_CHECK();
+    int rc;
     int plo[16], pnb[16], np = 0;
     for (int b = 0; b < 3 * dmax; b += 8) { plo[np] = b; pnb[np] = (3 * dmax - b) < 8 ? (3 * dmax - b) : 8; ++np; }
     plo[np] = SEG_SHIFT; pnb[np] = 6; ++np;  // segment id (and the all-ones sentinel of filtered points) last
-    rc = scp_radix_sort_u64(g->keys_a.as<uint64_t>(), g->keys_b.as<uint64_t>(), nk, plo, pnb, np, &g->radix, st, &g->sorted);
+    rc = scp_radix_sort_u64(g->keys_a.as<uint64_t>(), g->keys_b.as<uint64_t>(), nk, plo, pnb, np, &g->radix, st, &g->sorted, first_hist_done);
     if (rc) return rc;
 
     // --- head counts per level, scanned ---------------------------------------------------------------------
@@ -517,10 +474,24 @@ extern "C" int scp_geom_build(scp_geom *g, const int32_t *q, int64_t n, const sc
         (rc = g->pos.reserve(N * 12)) || (rc = g->fchild.reserve(N * 4 + 4)) || (rc = g->leafkey.reserve(U * 8)) ||
         (rc = g->leafoct.reserve(U)) || (rc = g->posmm.reserve(sizeof(int32_t) * 2 * NLV * nseg)))
         return rc;
-    std::vector<int32_t> mm((size_t)2 * NLV * nseg);
+    std::vector<int32_t> &mm = g->mm_host;
+    mm.resize((size_t)2 * NLV * nseg);
     for (size_t k = 0; k < mm.size(); k += 2) { mm[k] = INT32_MAX; mm[k + 1] = INT32_MIN; }
     HIP_TRY(hipMemcpyAsync(g->posmm.p, mm.data(), mm.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dtab, g->segs.data(), sizeof(SegTab) * nseg, hipMemcpyHostToDevice, st));
+    {
+        std::vector<int64_t> &rt = g->rowtab_host;
+        rt.resize(2 * (size_t)nseg);
+        int64_t rows = 0, mmrows = 0;
+        for (int s = 0; s < nseg; ++s) {
+            rt[s] = rows; rt[nseg + s] = mmrows;
+            rows += g->segs[s].n_nodes - g->segs[s].drop_last; mmrows += g->segs[s].depth;
+        }
+        if ((rc = g->rowtab.reserve(sizeof(int64_t) * 2 * nseg))) return rc;
+        HIP_TRY(hipMemcpyAsync(g->rowtab.p, rt.data(), rt.size() * 8, hipMemcpyHostToDevice, st));
+    }
+    if (!g->h2d_done) HIP_TRY(hipEventCreateWithFlags(&g->h2d_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(g->h2d_done, st));
     hipLaunchKernelGGL(tree_write_kernel, dim3(nblk), dim3(WG), 0, st, (const uint64_t *)g->sorted, nk, (const SegTab *)dtab, lmax,
                        (const uint32_t *)blk, nblk, g->level.as<uint8_t>(), g->octant.as<uint8_t>(), g->parent.as<int32_t>(),
                        g->pos.as<int32_t>(), g->fchild.as<int32_t>(), g->leafkey.as<uint64_t>(), g->leafoct.as<uint8_t>());
@@ -531,10 +502,303 @@ extern "C" int scp_geom_build(scp_geom *g, const int32_t *q, int64_t n, const sc
                        g->octant.as<uint8_t>(), g->fchild.as<int32_t>(), g->leafoct.as<uint8_t>(), g->pos.as<int32_t>(), g->occ.as<uint8_t>(),
                        g->posmm.as<int32_t>());
     LAUNCH_CHECK();
-    // the host vectors above are pageable: make sure the async copies that read them have completed before returning
-    HIP_TRY(hipStreamSynchronize(st));
+    // no trailing synchronisation: the two host tables copied above are members of the handle and stay untouched until the next build,
+    // which first waits for h2d_done (long signalled by then); the node tables are ordered behind this stream like any kernel output
     g->built = true;
     return SCP_OK;
+}
+
+static int geom_take_segments(scp_geom *g, const scp_segment *segs, int32_t nseg, int64_t n, int64_t *maxcount) {
+    if (g->h2d_done) HIP_TRY(hipEventSynchronize(g->h2d_done));   // the previous build's table copies have read g->segs / g->mm_host
+    g->built = false;
+    g->nseg = nseg;
+    g->segs.assign(nseg, SegTab());
+    int64_t nk = 0;
+    *maxcount = 0;
+    for (int s = 0; s < nseg; ++s) {
+        SegTab &t = g->segs[s];
+        memset(&t, 0, sizeof(t));
+        if (segs[s].point_begin < 0 || segs[s].point_count <= 0 || segs[s].point_begin + segs[s].point_count > n ||
+            segs[s].path_len < 0 || segs[s].path_len > 8)
+            return SCP_EINVAL;
+        t.pt_begin = segs[s].point_begin; t.pt_count = segs[s].point_count; t.key_begin = nk;
+        t.path_len = segs[s].path_len; t.path_bits = segs[s].path_bits; t.drop_last = segs[s].drop_last ? 1 : 0;
+        for (int L = 0; L < NLV; ++L) t.rank0[L] = -1;  // marker: "segment owns no key"
+        nk += t.pt_count;
+        if (t.pt_count > *maxcount) *maxcount = t.pt_count;
+    }
+    g->n_keys = nk;
+    int rc;
+    if ((rc = g->segtab.reserve(sizeof(SegTab) * nseg))) return rc;
+    if ((rc = g->red.reserve(sizeof(int32_t) * 8 * (nseg + 1) + 64))) return rc;
+    if ((rc = g->keys_a.reserve(sizeof(uint64_t) * nk))) return rc;
+    if ((rc = g->keys_b.reserve(sizeof(uint64_t) * nk))) return rc;
+    return SCP_OK;
+}
+
+static inline int depth_of(int32_t mx) {
+    int d = 0;
+    while (((int64_t)1 << d) < (int64_t)mx + 1) ++d;
+    return d;
+}
+
+extern "C" int scp_geom_build(scp_geom *g, const int32_t *q, int64_t n, const scp_segment *segs, int32_t nseg,
+                              scp_segment_info *info, void *stream) {
+    if (!g || !q || !segs || !info || n <= 0 || nseg <= 0 || nseg > SCP_MAX_SEGMENTS) return SCP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t maxcount = 0;
+    int rc = geom_take_segments(g, segs, nseg, n, &maxcount);
+    if (rc) return rc;
+    SegTab *dtab = g->segtab.as<SegTab>();
+
+    // --- depth of every segment (Octree.py:58) --------------------------------------------------------------
+    std::vector<int32_t> red(2 * nseg);
+    for (int s = 0; s < nseg; ++s) { red[2 * s] = INT32_MIN; red[2 * s + 1] = INT32_MAX; }
+    HIP_TRY(hipMemcpyAsync(g->red.p, red.data(), red.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dtab, g->segs.data(), sizeof(SegTab) * nseg, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(seg_minmax_kernel, dim3(std::min(grid_for(maxcount * 3), 64), nseg), dim3(WG), 0, st, q, (const SegTab *)dtab, g->red.as<int32_t>());
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(red.data(), g->red.p, red.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int dmax = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const int32_t mx = red[2 * s], mn = red[2 * s + 1];
+        if (mn < 0) return SCP_EINVAL;
+        const int d = depth_of(mx);
+        // depth 0 (all-zero cloud) aborts inside the reference as well
+        if (d == 0 || d > SCP_MAX_DEPTH - 2 || g->segs[s].path_len > d) return SCP_EINVAL;
+        g->segs[s].depth = d;
+        if (d > dmax) dmax = d;
+        memset(&info[s], 0, sizeof(info[s]));
+        info[s].depth = d;
+        info[s].max_coord = mx;
+    }
+
+    // --- keys -----------------------------------------------------------------------------------------------
+    HIP_TRY(hipMemcpyAsync(dtab, g->segs.data(), sizeof(SegTab) * nseg, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(morton_key_kernel, dim3(grid_for(maxcount), nseg), dim3(WG), 0, st, q, (const SegTab *)dtab, g->keys_a.as<uint64_t>());
+    LAUNCH_CHECK();
+    return geom_build_sorted(g, info, dmax, st, false);
+}
+
+// ------------------------------------------------------------------------------------------------ G1 + G2 in one launch sequence
+// scp_geom_build_xyz: float frames in, node tables out.  Two kernels in front of the sort instead of (transform, quantise) per shell +
+// concatenation + min / max + key kernel, every point transformed ONCE (float64 atan2 / acos are the expensive part of stage G):
+//   front_transform_kernel  xyz -> (rho, phi, theta | z) float32 for every frame, per-frame max / min of every axis (6 ordered words);
+//                           ONE read-back: the maxima fix bin_num, the steps, and - the quantiser being monotone - the largest integer of
+//                           every shell, hence every tree's depth, without another pass over the points;
+//   front_key_kernel        one workgroup per 4096-key tile of the (frame, shell)-major key array: quantise the point for ITS shell, apply
+//                           the rho-shell filter, write the 64-bit key - and the sort's first digit histogram of the tile, which
+//                           radix_hist_kernel would otherwise re-read the keys for.
+struct FrontFrame { const float *xyz; int64_t n; int64_t tr_begin; };
+struct FrontSeg { int64_t key_begin, pt_count, tr_begin; QuantParams qp; int32_t depth, path_len, path_bits, pad; };
+
+__global__ __launch_bounds__(WG) void front_transform_kernel(const FrontFrame *__restrict__ frames, int mode, float *__restrict__ tr,
+                                                            uint32_t *__restrict__ red /* [frame][8]: max a, b, c, min a, b, c (ordered) */) {
+    const FrontFrame f = frames[blockIdx.y];
+    uint32_t omax[3] = {0u, 0u, 0u}, omin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < f.n; i += (int64_t)gridDim.x * WG) {
+        const float x = f.xyz[3 * i], y = f.xyz[3 * i + 1], z = f.xyz[3 * i + 2];
+        float a, b, c;
+        if (mode == SCP_CART) {
+            a = x; b = y; c = z;
+        } else {       // the arithmetic of transform_kernel, line for line
+            const float xx = __fmul_rn(x, x), yy = __fmul_rn(y, y);
+            float s = __fadd_rn(xx, yy);
+            if (mode == SCP_SPHER) s = __fadd_rn(s, __fmul_rn(z, z));
+            a = sqrt_cr(s);
+            const float xe = __fadd_rn(x, 1e-9f);
+            float phi = (float)atan2((double)y, (double)xe);
+            if (phi < 0.f) phi = __fadd_rn(phi, 6.2831855f);
+            b = phi;
+            c = (mode == SCP_SPHER) ? (float)acos((double)(float)((double)z / (double)a)) : z;
+        }
+        float *o = tr + 3 * (f.tr_begin + i);
+        o[0] = a; o[1] = b; o[2] = c;
+        const uint32_t oa = f2ord(a), ob = f2ord(b), oc = f2ord(c);
+        omax[0] = max(omax[0], oa); omax[1] = max(omax[1], ob); omax[2] = max(omax[2], oc);
+        omin[0] = min(omin[0], oa); omin[1] = min(omin[1], ob); omin[2] = min(omin[2], oc);
+    }
+    __shared__ uint32_t sm[4][6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int off = 32; off > 0; off >>= 1) {
+            omax[k] = max(omax[k], (uint32_t)__shfl_xor(omax[k], off));
+            omin[k] = min(omin[k], (uint32_t)__shfl_xor(omin[k], off));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; ++k) { sm[threadIdx.x >> 6][k] = omax[k]; sm[threadIdx.x >> 6][3 + k] = omin[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        uint32_t v = sm[0][k];
+        for (int w = 1; w < 4; ++w) v = k < 3 ? max(v, sm[w][k]) : min(v, sm[w][k]);
+        if (k < 3) atomicMax(&red[8 * blockIdx.y + k], v); else atomicMin(&red[8 * blockIdx.y + k], v);
+    }
+}
+
+// the quantiser of quantize_kernel for one coordinate (same expressions: identical integers)
+__device__ __forceinline__ int32_t quant1(float t, const QuantParams &p, int k) {
+    double r;
+    if (p.cart_f32) r = (double)rintf((float)((double)__fsub_rn(t, p.offf) / (double)p.qsf));
+    else r = rint(((double)t - p.off[k]) / p.qs[k]);
+    return (int32_t)r;
+}
+static inline int32_t quant1_host(float t, const QuantParams &p, int k) {      // the same arithmetic on the host (IEEE, no contraction: one operation per statement)
+    if (p.cart_f32) {
+        const float d = t - p.offf;
+        const float qf = (float)((double)d / (double)p.qsf);
+        return (int32_t)(double)rintf(qf);
+    }
+    const double d = (double)t - p.off[k];
+    const double qd = d / p.qs[k];
+    return (int32_t)rint(qd);
+}
+
+__global__ __launch_bounds__(WG) void front_key_kernel(const float *__restrict__ tr, const FrontSeg *__restrict__ segs, int nseg, int64_t nk,
+                                                      uint64_t *__restrict__ keys, int32_t *__restrict__ q_out /* optional [nk][3] */,
+                                                      uint32_t mask0, uint32_t *__restrict__ counts, int ntiles) {
+    __shared__ uint32_t hist[256];
+    __shared__ FrontSeg ss[2];           // a 4096-key tile touches at most two segments unless segments are tiny: others are fetched from memory
+    hist[threadIdx.x] = 0;
+    const int64_t base = (int64_t)blockIdx.x * SCP_RADIX_TILE;
+    // first segment of the tile (segments are in key order): the last one whose key_begin <= base
+    int s0 = 0;
+    for (int s = 1; s < nseg; ++s) if (segs[s].key_begin <= base) s0 = s;
+    if (threadIdx.x < 2 && s0 + (int)threadIdx.x < nseg) ss[threadIdx.x] = segs[s0 + threadIdx.x];
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < SCP_RADIX_TILE / WG; ++r) {
+        const int64_t k = base + r * WG + threadIdx.x;
+        if (k >= nk) break;
+        int si = 0;
+        const FrontSeg *sp = &ss[0];
+        if (s0 + 1 < nseg && k >= ss[1].key_begin) {
+            si = 1; sp = &ss[1];
+            if (k >= ss[1].key_begin + ss[1].pt_count) {        // tiny segments: walk on in memory
+                int s = s0 + 2;
+                while (s + 1 < nseg && k >= segs[s + 1].key_begin) ++s;
+                si = s - s0; sp = &segs[s];
+            }
+        }
+        const FrontSeg &sg = *sp;
+        const int64_t i = k - sg.key_begin;
+        const float *t = tr + 3 * (sg.tr_begin + i);
+        const int32_t qx = quant1(t[0], sg.qp, 0), qy = quant1(t[1], sg.qp, 1), qz = quant1(t[2], sg.qp, 2);
+        if (q_out) { q_out[3 * k] = qx; q_out[3 * k + 1] = qy; q_out[3 * k + 2] = qz; }
+        uint64_t key = ((uint64_t)(s0 + si) << SEG_SHIFT) | (spread3((uint32_t)qx) << 2) | (spread3((uint32_t)qy) << 1) | spread3((uint32_t)qz);
+        if (sg.path_len > 0 && (int)((uint32_t)qx >> (sg.depth - sg.path_len)) != sg.path_bits) key = ~0ull;
+        keys[k] = key;
+        atomicAdd(&hist[(uint32_t)key & mask0], 1u);
+    }
+    __syncthreads();
+    counts[(int64_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+// frames: nframes device arrays float32 [n_points[f]][3]; every frame is cut into nshell trees (shell s: step qs[s], rho-shell path of
+// shells[s], drop_last of shells[s]; point_begin / point_count of shells[] are ignored), segment index = f * nshell + s.
+// qinfo / info: host arrays [nframes * nshell].  q_out (optional): device int32 [nframes * nshell * n][3] = the integers of every segment.
+extern "C" int scp_geom_build_xyz(scp_geom *g, const float *const *frames, const int64_t *n_points, int32_t nframes, int32_t mode,
+                                  const double *qs, int32_t nshell, double cart_offset, const scp_segment *shells, int32_t *q_out,
+                                  scp_quant_info *qinfo, scp_segment_info *info, void *stream) {
+    if (!g || !frames || !n_points || !qs || !shells || !qinfo || !info || nframes <= 0 || nshell <= 0 || mode < 0 || mode > 2 ||
+        (int64_t)nframes * nshell > SCP_MAX_SEGMENTS)
+        return SCP_EINVAL;
+    const int nseg = nframes * nshell;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t npts = 0, maxn = 0;
+    std::vector<scp_segment> segv(nseg);
+    std::vector<FrontFrame> ff(nframes);
+    for (int f = 0; f < nframes; ++f) {
+        if (!frames[f] || n_points[f] <= 0 || ((uintptr_t)frames[f] & 3)) return SCP_EINVAL;
+        ff[f].xyz = frames[f]; ff[f].n = n_points[f]; ff[f].tr_begin = npts;
+        for (int s = 0; s < nshell; ++s) {
+            if (!(qs[s] > 0)) return SCP_EINVAL;
+            scp_segment &sg = segv[f * nshell + s];
+            sg = shells[s];
+            sg.point_begin = 0; sg.point_count = n_points[f];
+        }
+        npts += n_points[f];
+        if (n_points[f] > maxn) maxn = n_points[f];
+    }
+    int64_t maxcount = 0;
+    int rc = geom_take_segments(g, segv.data(), nseg, maxn, &maxcount);
+    if (rc) return rc;
+    if ((rc = g->tr.reserve((size_t)npts * 12 + 64))) return rc;
+    if ((rc = g->front.reserve(sizeof(FrontFrame) * nframes + sizeof(FrontSeg) * nseg + 256))) return rc;
+    FrontFrame *dff = g->front.as<FrontFrame>();
+    FrontSeg *dfs = (FrontSeg *)((char *)g->front.p + ((sizeof(FrontFrame) * nframes + 63) & ~(size_t)63));
+    uint32_t *dred = g->red.as<uint32_t>();
+    std::vector<uint32_t> red((size_t)8 * nframes);
+    for (int f = 0; f < nframes; ++f)
+        for (int k = 0; k < 8; ++k) red[8 * f + k] = (k < 3) ? 0u : 0xffffffffu;
+    HIP_TRY(hipMemcpyAsync(dred, red.data(), red.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dff, ff.data(), sizeof(FrontFrame) * nframes, hipMemcpyHostToDevice, st));
+    {
+        SCP_PROF(SCP_PROF_GEOM, st, 24.0 * npts);
+        hipLaunchKernelGGL(front_transform_kernel, dim3(std::min(grid_for(maxn), 512), nframes), dim3(WG), 0, st, (const FrontFrame *)dff, mode,
+                           g->tr.as<float>(), dred);
+    }
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(red.data(), dred, red.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));                 // read-back 1 of 2: the extrema fix the steps and the depths
+
+    std::vector<FrontSeg> fs(nseg);
+    int dmax = 0;
+    for (int f = 0; f < nframes; ++f) {
+        float tmax[3], tmin[3];
+        for (int k = 0; k < 3; ++k) { tmax[k] = ord2f_host(red[8 * f + k]); tmin[k] = ord2f_host(red[8 * f + 3 + k]); }
+        for (int s = 0; s < nshell; ++s) {
+            const int sidx = f * nshell + s;
+            QuantParams p;
+            memset(&p, 0, sizeof(p));
+            scp_quant_info &qi = qinfo[sidx];
+            memset(&qi, 0, sizeof(qi));
+            if (mode == SCP_CART) {
+                p.cart_f32 = 1; p.qsf = (float)qs[s]; p.offf = (float)cart_offset;
+                for (int k = 0; k < 3; ++k) { qi.qs[k] = qs[s]; qi.offset[k] = cart_offset; }
+            } else {               // scp_quantize's float32 expressions
+                const float binf = rintf(tmax[0] / (float)qs[s]) + 1.0f;
+                const float q_phi = 6.2831855f / (binf - 1.0f);
+                const float q_th = 3.1415927f / (binf - 1.0f);
+                qi.bin_num = (double)binf;
+                p.qs[0] = qs[s]; p.qs[1] = (double)q_phi; p.qs[2] = (mode == SCP_SPHER) ? (double)q_th : qs[s];
+                p.off[2] = (mode == SCP_CYLIN) ? (double)tmin[2] : 0.0;
+                for (int k = 0; k < 3; ++k) { qi.qs[k] = p.qs[k]; qi.offset[k] = p.off[k]; }
+            }
+            // the quantiser is monotone in every coordinate: the extreme integers are the integers of the extreme coordinates
+            int32_t mx = INT32_MIN, mn = INT32_MAX;
+            for (int k = 0; k < 3; ++k) {
+                const int32_t hi = quant1_host(tmax[k], p, k), lo = quant1_host(tmin[k], p, k);
+                mx = std::max(mx, hi); mn = std::min(mn, lo);
+            }
+            qi.max_coord = mx; qi.min_coord = mn;
+            if (mn < 0) return SCP_EINVAL;
+            const int d = depth_of(mx);
+            if (d == 0 || d > SCP_MAX_DEPTH - 2 || g->segs[sidx].path_len > d) return SCP_EINVAL;
+            g->segs[sidx].depth = d;
+            if (d > dmax) dmax = d;
+            memset(&info[sidx], 0, sizeof(info[sidx]));
+            info[sidx].depth = d;
+            info[sidx].max_coord = mx;
+            FrontSeg &o = fs[sidx];
+            o.key_begin = g->segs[sidx].key_begin; o.pt_count = n_points[f]; o.tr_begin = ff[f].tr_begin; o.qp = p;
+            o.depth = d; o.path_len = g->segs[sidx].path_len; o.path_bits = g->segs[sidx].path_bits; o.pad = 0;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(dfs, fs.data(), sizeof(FrontSeg) * nseg, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(g->segtab.p, g->segs.data(), sizeof(SegTab) * nseg, hipMemcpyHostToDevice, st));
+    int ntiles = 0;
+    uint32_t *counts = scp_radix_counts(&g->radix, g->n_keys, &ntiles);
+    if (!counts) return SCP_ENOMEM;
+    const int nb0 = 3 * dmax < 8 ? 3 * dmax : 8;
+    {
+        SCP_PROF(SCP_PROF_GEOM, st, 12.0 * g->n_keys + 8.0 * g->n_keys);
+        hipLaunchKernelGGL(front_key_kernel, dim3(ntiles), dim3(WG), 0, st, g->tr.as<float>(), (const FrontSeg *)dfs, nseg, g->n_keys,
+                           g->keys_a.as<uint64_t>(), q_out, (1u << nb0) - 1u, counts, ntiles);
+    }
+    LAUNCH_CHECK();
+    return geom_build_sorted(g, info, dmax, st, g->n_keys > 1);
 }
 
 #define REQUIRE_BUILT(g) do { if (!(g)) return SCP_EINVAL; if (!(g)->built) return SCP_ESTATE; } while (0)
@@ -679,6 +943,91 @@ extern "C" int scp_geom_context_ehem(scp_geom *g, int32_t seg, int32_t pos_mode,
         hipLaunchKernelGGL(posmm_i64_kernel, dim3(1), dim3(64), 0, st, mm, t.depth, pos_mm);
         LAUNCH_CHECK();
     }
+    return SCP_OK;
+}
+
+// The same for EVERY segment of the build in one launch, rows of all segments back to back (segment s starts at row_base[s] = the sum of
+// the earlier segments' n_nodes - drop_last), and with the coded symbols written straight in CODING ORDER (encode.py:109-136: the rows
+// of a level are cut into windows of context_size, inside a window all even positions come first, then the odd ones): the encoder needs
+// no per-segment launches, no concatenation and no gather through a coding-order index.
+__global__ __launch_bounds__(WG) void ctx_ehem_all_kernel(const SegTab *__restrict__ tab, const int64_t *__restrict__ row_base, const uint8_t *__restrict__ occ,
+                                                         const uint8_t *__restrict__ level, const uint8_t *__restrict__ octant,
+                                                         const int32_t *__restrict__ parent, const int32_t *__restrict__ pos,
+                                                         const int32_t *__restrict__ posmm, int pos_mode, int lidar_level, int cs,
+                                                         uint8_t *__restrict__ ctx, float *__restrict__ posn, uint8_t *__restrict__ sym_coded,
+                                                         int64_t *__restrict__ pos_mm_out, const int64_t *__restrict__ mm_base) {
+    const SegTab &s = tab[blockIdx.y];
+    const int64_t rows = s.n_nodes - s.drop_last, rb = row_base[blockIdx.y];
+    const int depth = s.depth;
+    const int32_t *mm = posmm + (size_t)blockIdx.y * NLV * 2;
+    if (pos_mm_out && blockIdx.x == 0 && (int)threadIdx.x < depth) {
+        const int L = threadIdx.x + 1;
+        pos_mm_out[2 * (mm_base[blockIdx.y] + L - 1)] = mm[2 * L];
+        pos_mm_out[2 * (mm_base[blockIdx.y] + L - 1) + 1] = mm[2 * L + 1];
+    }
+    for (int64_t r = (int64_t)blockIdx.x * WG + threadIdx.x; r < rows; r += (int64_t)gridDim.x * WG) {
+        const int64_t nd = s.node_base + r;
+        int64_t a[4];
+        ancestors(parent, nd, a);
+        const int L = level[nd];
+        const bool last = (L == depth);
+        uint8_t c[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t an = a[k];
+            if (an < 0) { c[3 * k] = 0; c[3 * k + 1] = 0; c[3 * k + 2] = 255; }
+            else {
+                int lv = level[an];
+                if (last && lv > lidar_level) lv = lidar_level;
+                c[3 * k] = (uint8_t)lv; c[3 * k + 1] = octant[an]; c[3 * k + 2] = (uint8_t)(occ[an] - 1);
+            }
+        }
+        uint32_t *cw = (uint32_t *)(ctx + (rb + r) * 12);
+        cw[0] = c[0] | (c[1] << 8) | (c[2] << 16) | ((uint32_t)c[3] << 24);
+        cw[1] = c[4] | (c[5] << 8) | (c[6] << 16) | ((uint32_t)c[7] << 24);
+        cw[2] = c[8] | (c[9] << 8) | (c[10] << 16) | ((uint32_t)c[11] << 24);
+        if (sym_coded) {
+            const int64_t l0 = s.level_off[L];
+            const int64_t nl = s.level_off[L + 1] - l0 - ((last && s.drop_last) ? 1 : 0);      // coded rows of this level
+            const int64_t i = r - l0, w0 = (i / cs) * cs, p = i - w0;
+            const int64_t cw_len = (nl - w0) < cs ? (nl - w0) : cs, ne = (cw_len + 1) >> 1;
+            sym_coded[rb + l0 + w0 + ((p & 1) ? ne + (p >> 1) : (p >> 1))] = (uint8_t)(occ[nd] - 1);
+        }
+        if (posn) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double pv = (double)pos[3 * nd + k];
+                double v;
+                if (pos_mode == SCP_POS_POW2) v = pv / (double)(1ll << depth);
+                else {
+                    const double mn = (double)mm[2 * L], mx = (double)mm[2 * L + 1];
+                    const double eps = (pos_mode == SCP_POS_MINMAX_MUL && last) ? 0.0 : 1e-9;
+                    v = (pv - mn) / (mx - mn + eps);
+                }
+                posn[3 * (rb + r) + k] = (float)v;
+            }
+        }
+    }
+}
+
+extern "C" int scp_geom_context_ehem_all(scp_geom *g, int32_t pos_mode, int32_t lidar_level, int32_t context_size, uint8_t *ctx, float *pos,
+                                         uint8_t *sym_coded, int64_t *pos_mm, void *stream) {
+    REQUIRE_BUILT(g);
+    if (!ctx || pos_mode < 0 || pos_mode > 2 || context_size <= 0 || ((uintptr_t)ctx & 3)) return SCP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nseg = g->nseg;
+    int64_t rows = 0, maxrows = 1;
+    for (int s = 0; s < nseg; ++s) {
+        const int64_t r = g->segs[s].n_nodes - g->segs[s].drop_last;
+        rows += r;
+        if (r > maxrows) maxrows = r;
+    }
+    SCP_PROF(SCP_PROF_GEOM, st, 25.0 * rows);
+    hipLaunchKernelGGL(ctx_ehem_all_kernel, dim3(grid_for(maxrows), nseg), dim3(WG), 0, st, (const SegTab *)g->segtab.p,
+                       (const int64_t *)g->rowtab.p, g->occ.as<uint8_t>(), g->level.as<uint8_t>(), g->octant.as<uint8_t>(), g->parent.as<int32_t>(),
+                       g->pos.as<int32_t>(), g->posmm.as<int32_t>(), pos_mode, lidar_level, context_size, ctx, pos, sym_coded, pos_mm,
+                       (const int64_t *)g->rowtab.p + nseg);
+    LAUNCH_CHECK();
     return SCP_OK;
 }
 

@@ -124,8 +124,17 @@ void scp_launch_scan_u32(uint32_t *counts, int64_t m, hipStream_t st) {
     else hipLaunchKernelGGL(radix_scan_kernel<true>, dim3(1), dim3(1024), 0, st, counts, m);
 }
 
+// first_hist_done: the producer of keys_a has already written pass 0's [digit][tile] table into ws->counts (scp_radix_counts; the fused
+// key kernel of geom.hip does, one workgroup per 4096-key tile like radix_hist_kernel): pass 0 starts at its scan.
+uint32_t *scp_radix_counts(RadixWorkspace *ws, int64_t n, int *ntiles_out) {
+    const int ntiles = (int)cdiv64(n, TILE);
+    if (ws->counts.reserve((size_t)256 * ntiles * sizeof(uint32_t))) return nullptr;
+    if (ntiles_out) *ntiles_out = ntiles;
+    return ws->counts.as<uint32_t>();
+}
+
 int scp_radix_sort_u64(uint64_t *keys_a, uint64_t *keys_b, int64_t n, const int *pass_lo, const int *pass_bits,
-                       int npass, RadixWorkspace *ws, hipStream_t st, uint64_t **result) {
+                       int npass, RadixWorkspace *ws, hipStream_t st, uint64_t **result, bool first_hist_done) {
     *result = keys_a;
     if (n <= 1 || npass == 0) return SCP_OK;
     const int ntiles = (int)cdiv64(n, TILE);
@@ -136,7 +145,8 @@ int scp_radix_sort_u64(uint64_t *keys_a, uint64_t *keys_b, int64_t n, const int 
     for (int p = 0; p < npass; ++p) {
         const int lo = pass_lo[p], nb = pass_bits[p];
         if (nb < 1 || nb > 8) return SCP_EINVAL;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(WG), 0, st, src, n, lo, (1u << nb) - 1u, counts, ntiles);
+        if (!(p == 0 && first_hist_done))
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(WG), 0, st, src, n, lo, (1u << nb) - 1u, counts, ntiles);
         LAUNCH_CHECK();
         scp_launch_scan_u32(counts, (int64_t)256 * ntiles, st);
         LAUNCH_CHECK();

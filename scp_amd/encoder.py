@@ -173,11 +173,30 @@ class FrameEncoder:
         return metrics.chamfer_psnr(xyz_dev, torch.cat(pts), metrics.PEAK.get(self.data_type, 1.0))
 
     def preprocess(self, xyz_dev, ints=None):
-        qs, bin_num, z_off = self.quantize(xyz_dev, ints)
-        pre = self.preprocess_ints(qs, bin_num, z_off, xyz_dev.shape[0])
+        if ints is None and not self.host_transform:
+            # device transform: stage G1 + G2 as ONE launch sequence (scp_geom_build_xyz: every point transformed once, keys for all
+            # shells and the sort's first histogram out of one kernel, two host read-backs per frame)
+            self._infos = self.geom.build_xyz([xyz_dev], self.mode, [level_qs(self.data_type, lv) for _, lv in self.shells()],
+                                              0.0 if self.mullevel else self.cart_offset, [(path, self.mullevel) for path, _ in self.shells()])
+            pre = self._tables(self._infos[0].bin_num, self._infos[0].offset[2] if self.cylin else 0.0, xyz_dev.shape[0])
+        else:
+            qs, bin_num, z_off = self.quantize(xyz_dev, ints)
+            pre = self.preprocess_ints(qs, bin_num, z_off, xyz_dev.shape[0])
         pre["bin_nums"] = [float(i.bin_num) for i in self._infos]      # every shell's own (the file name carries the first)
         pre["quant"] = _quant_of(self._infos)                          # the steps and offsets the integers were made with (sidecar)
         return pre
+
+    def _tables(self, bin_num, z_offset, n_points):
+        """ctx / pos / coded symbols of every segment of the geometry just built, one launch (scp_geom_context_ehem_all)."""
+        pos_mode = native.POS_MINMAX_MUL if self.mullevel else (native.POS_POW2 if self.mode == native.CART else native.POS_MINMAX)
+        ctx, pos, sym_coded, mm = self.geom.context_ehem_all(pos_mode, self.lidar_level, self.context_size)
+        sizes = []
+        for s in range(len(self.geom.info)):
+            counts = self.geom.level_counts(s)
+            if self.mullevel:
+                counts[-1] -= 1          # Octree.py:259-262: the records drop the last BFS node
+            sizes += counts
+        return dict(ctx=ctx, pos=pos, sym_coded=sym_coded, pos_mm=mm, level_sizes=sizes, bin_num=bin_num, z_offset=z_offset, n_points=n_points)
 
     def preprocess_ints(self, qs, bin_num, z_offset, n_points):
         """qs: per-shell quantised integer clouds (device int32 [P_s,3]) - the entry point for already-quantised input
@@ -189,17 +208,7 @@ class FrameEncoder:
             segs.append((off, qq.shape[0], path, self.mullevel))
             off += qq.shape[0]
         self.geom.build(q.contiguous(), segs)
-        pos_mode = native.POS_MINMAX_MUL if self.mullevel else (native.POS_POW2 if self.mode == native.CART else native.POS_MINMAX)
-        ctxs, poss, syms, mms, sizes = [], [], [], [], []
-        for s in range(len(segs)):
-            ctx, pos, sym, mm = self.geom.context_ehem(s, pos_mode, L)
-            ctxs.append(ctx); poss.append(pos); syms.append(sym); mms.append(mm)
-            counts = self.geom.level_counts(s)
-            if self.mullevel:
-                counts[-1] -= 1          # Octree.py:259-262: the records drop the last BFS node
-            sizes += counts
-        return dict(ctx=torch.cat(ctxs), pos=torch.cat(poss), sym=torch.cat(syms), pos_mm=torch.cat(mms),
-                    level_sizes=sizes, bin_num=bin_num, z_offset=z_offset, n_points=n_points)
+        return self._tables(bin_num, z_offset, n_points)
 
     def preprocess_records(self, records, bin_num, z_offset, n_points):
         """--preproc_path flow (encode_dataset_ehem.py:149-157 + :52-105): the reference's int64 [N,4,6] record files (one per
@@ -338,8 +347,7 @@ class FrameEncoder:
             plan = EncodePlan(pre["level_sizes"], self.context_size)
             if self.packed:
                 pre["packed_plans"] = self.packed_plans(plan)
-            order = plan.coding_order_device(self.device)
-            sym_coded = pre["sym"][order].contiguous()
+            sym_coded = self._sym_coded(pre, plan)
             ready = torch.cuda.Event()
             ready.record()
         main.wait_event(ready)
@@ -363,7 +371,7 @@ class FrameEncoder:
             return native.ac_encode_lohi(host.numpy())
 
         fut = self._pool.submit(work)
-        return dict(future=fut, pre=pre, plan=plan, t0=t0, keep=(order, sym_coded, table, lohi))
+        return dict(future=fut, pre=pre, plan=plan, t0=t0, keep=(sym_coded, table, lohi))
 
     # ------------------------------------------------------------------------------------------ batches of small frames
     def preprocess_batch(self, frames):
@@ -371,37 +379,37 @@ class FrameEncoder:
         the frames' context tables back to back.  Frames share nothing (encode.py:274-291 rebuilds everything per frame): the batch is
         ONE sequence of levels - the frames' level lists one after the other - for the window plan, the packed forward and the CDF
         kernel, and is cut into frames again in front of the range coder.  Returns (combined `pre`, per-frame meta)."""
-        L = self.lidar_level
-        qs_all, metas = [], []
-        for xyz_dev in frames:
-            qs, bin_num, z_off = self.quantize(xyz_dev)
-            qs_all.append(qs)
-            metas.append(dict(bin_num=bin_num, z_offset=z_off, n_points=int(xyz_dev.shape[0]), bin_nums=[float(i.bin_num) for i in self._infos],
-                              quant=_quant_of(self._infos)))
-        flat = [q for qs in qs_all for q in qs]
-        if len(flat) > 62:
-            raise native.ScpError("a batch holds at most 62 (frame, shell) trees (SCP_MAX_SEGMENTS)")
-        segs, off = [], 0
-        for qs in qs_all:
-            for (path, _), qq in zip(self.shells(), qs):
-                segs.append((off, qq.shape[0], path, self.mullevel))
-                off += qq.shape[0]
-        self.geom.build(torch.cat(flat).contiguous(), segs)
-        pos_mode = native.POS_MINMAX_MUL if self.mullevel else (native.POS_POW2 if self.mode == native.CART else native.POS_MINMAX)
-        ctxs, poss, syms, sizes = [], [], [], []
         ns = len(self.shells())
-        for f, meta in enumerate(metas):
-            mms, fsizes = [], []
-            for s in range(f * ns, (f + 1) * ns):
-                ctx, pos, sym, mm = self.geom.context_ehem(s, pos_mode, L)
-                ctxs.append(ctx); poss.append(pos); syms.append(sym); mms.append(mm)
-                counts = self.geom.level_counts(s)
-                if self.mullevel:
-                    counts[-1] -= 1
-                fsizes += counts
-            meta.update(pos_mm=torch.cat(mms), level_sizes=fsizes, n_nodes=int(sum(fsizes)))
-            sizes += fsizes
-        return dict(ctx=torch.cat(ctxs), pos=torch.cat(poss), sym=torch.cat(syms), level_sizes=sizes), metas
+        if len(frames) * ns > 62:
+            raise native.ScpError("a batch holds at most 62 (frame, shell) trees (SCP_MAX_SEGMENTS)")
+        if self.host_transform:
+            qs_all, infos = [], []
+            for xyz_dev in frames:
+                hq, inf = self.host_ints(xyz_dev)
+                qs_all += [torch.from_numpy(q).to(self.device, non_blocking=True) for q in hq]
+                infos += inf
+            segs, off = [], 0
+            for f in range(len(frames)):
+                for (path, _), qq in zip(self.shells(), qs_all[f * ns:(f + 1) * ns]):
+                    segs.append((off, qq.shape[0], path, self.mullevel))
+                    off += qq.shape[0]
+            self.geom.build(torch.cat(qs_all).contiguous(), segs)
+        else:
+            infos = self.geom.build_xyz(list(frames), self.mode, [level_qs(self.data_type, lv) for _, lv in self.shells()],
+                                        0.0 if self.mullevel else self.cart_offset, [(path, self.mullevel) for path, _ in self.shells()])
+        self._infos = infos[-ns:]
+        pre = self._tables(infos[0].bin_num, 0.0, 0)
+        metas, sizes, mm0 = [], pre["level_sizes"], 0
+        depths = [i.depth for i in self.geom.info]
+        for f, xyz_dev in enumerate(frames):
+            fi = infos[f * ns:(f + 1) * ns]
+            nl = sum(depths[f * ns:(f + 1) * ns])
+            fsizes = sizes[mm0:mm0 + nl]
+            metas.append(dict(bin_num=fi[0].bin_num, z_offset=(fi[0].offset[2] if self.cylin else 0.0), n_points=int(xyz_dev.shape[0]),
+                              bin_nums=[float(i.bin_num) for i in fi], quant=_quant_of(fi), pos_mm=pre["pos_mm"][mm0:mm0 + nl],
+                              level_sizes=fsizes, n_nodes=int(sum(fsizes))))
+            mm0 += nl
+        return dict(ctx=pre["ctx"], pos=pre["pos"], sym_coded=pre["sym_coded"], level_sizes=sizes), metas
 
     def encode_batch_async(self, frames):
         """k frames through ONE stage G, ONE packed forward and ONE CDF launch (the small-frame configurations: a level-12 frame has
@@ -426,8 +434,7 @@ class FrameEncoder:
             plan = EncodePlan(pre["level_sizes"], self.context_size)
             if self.packed:
                 pre["packed_plans"] = self.packed_plans(plan)
-            order = plan.coding_order_device(self.device)
-            sym_coded = pre["sym"][order].contiguous()
+            sym_coded = self._sym_coded(pre, plan)
             ready = torch.cuda.Event()
             ready.record()
         main.wait_event(ready)
@@ -451,7 +458,14 @@ class FrameEncoder:
             copied.synchronize()
             h = host.numpy()
             return [native.ac_encode_lohi(h[cuts[f]:cuts[f + 1]]) for f in range(len(metas))]
-        return dict(future=self._pool.submit(work), metas=metas, t0=t0, keep=(pre, plan, order, sym_coded, table, lohi, dev_frames))
+        return dict(future=self._pool.submit(work), metas=metas, t0=t0, keep=(pre, plan, sym_coded, table, lohi, dev_frames))
+
+    def _sym_coded(self, pre, plan):
+        """The coded symbols in coding order: written by the context kernel itself (scp_geom_context_ehem_all), or - for tables that
+        did not come out of it (the --preproc_path record files) - gathered through the plan's coding-order index."""
+        if pre.get("sym_coded") is not None:
+            return pre["sym_coded"]
+        return pre["sym"][plan.coding_order_device(self.device)].contiguous()
 
     def finish_batch(self, h):
         out = []
@@ -477,8 +491,7 @@ class FrameEncoder:
         t1 = time.perf_counter()
         plan = EncodePlan(pre["level_sizes"], self.context_size)
         table = self.logits_in_coding_order(pre, plan)
-        order = plan.coding_order_device(self.device)
-        sym_coded = pre["sym"][order].contiguous()
+        sym_coded = self._sym_coded(pre, plan)
         if timing:
             torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -491,7 +504,7 @@ class FrameEncoder:
                     bin_num=pre["bin_num"], z_offset=pre["z_offset"], n_levels=len(pre["level_sizes"]),
                     pos_mm=pre["pos_mm"].cpu().numpy(), level_sizes=pre["level_sizes"], bin_nums=pre.get("bin_nums", [float(pre["bin_num"])]),
                     quant=pre.get("quant"), times=dict(geom=t1 - t0, model=t2 - t1, cdf=t3 - t2, coder=t4 - t3, total=t4 - t0),
-                    _debug=dict(table=table, sym_coded=sym_coded, order=order, pre=pre))
+                    _debug=dict(table=table, sym_coded=sym_coded, pre=pre))
 
     def outfile(self, base, res):
         """encode.py:140-144 file name."""
@@ -555,6 +568,9 @@ class OctAttnFrameEncoder:
         if isinstance(xyz, np.ndarray):
             xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
         xyz_dev = xyz.to(self.device)
+        if not self.host_transform:
+            bin_num = self.build_from_xyz(xyz_dev)
+            return self.encode_ints(None, bin_num, xyz_dev.shape[0], t0, sequential=sequential, front=self._front(None))
         qs, bin_num = self.quantize(xyz_dev)
         return self.encode_ints(qs, bin_num, xyz_dev.shape[0], t0, sequential=sequential)
 
@@ -574,18 +590,27 @@ class OctAttnFrameEncoder:
         if cs > 1:
             table[N - 1] = self.model(seq_ctx[-1:].reshape(1, 1, 4, 3), seq_pos[-1:].reshape(1, 1, 4, 3))[0, -1]
 
+    def build_from_xyz(self, xyz_dev):
+        """Device transform: stage G1 + G2 in one launch sequence (scp_geom_build_xyz) -> bin_num of the first shell."""
+        infos = self.geom.build_xyz([xyz_dev], self.mode, [level_qs(self.data_type, lv) for _, lv in self.shells()],
+                                    0.0 if self.mullevel else self.cart_offset, [(path, self.mullevel) for path, _ in self.shells()])
+        return infos[0].bin_num
+
     def _front(self, qs):
         """stage G + the front-padded context sequences (encode_dataset.py:32-55 / encode_dataset_mullevel.py:44-73) on the
-        current stream.  qs: one integer cloud, or the list of per-shell clouds.  -> (chunks [(seq_ctx, seq_pos, n)], sym, N)."""
-        if not isinstance(qs, (list, tuple)):
-            qs = [qs]
-        if len(qs) != len(self.shells()):
-            raise native.ScpError(f"expected {len(self.shells())} integer cloud(s), got {len(qs)}")
-        segs, off = [], 0
-        for (path, _), qq in zip(self.shells(), qs):
-            segs.append((off, qq.shape[0], path, self.mullevel))
-            off += qq.shape[0]
-        self.geom.build((torch.cat(qs) if len(qs) > 1 else qs[0]).contiguous(), segs)
+        current stream.  qs: one integer cloud, or the list of per-shell clouds; None: the geometry has been built already
+        (build_from_xyz).  -> (chunks [(seq_ctx, seq_pos, n)], sym, N)."""
+        if qs is not None:
+            if not isinstance(qs, (list, tuple)):
+                qs = [qs]
+            if len(qs) != len(self.shells()):
+                raise native.ScpError(f"expected {len(self.shells())} integer cloud(s), got {len(qs)}")
+            segs, off = [], 0
+            for (path, _), qq in zip(self.shells(), qs):
+                segs.append((off, qq.shape[0], path, self.mullevel))
+                off += qq.shape[0]
+            self.geom.build((torch.cat(qs) if len(qs) > 1 else qs[0]).contiguous(), segs)
+        segs = self.geom.segments
         cs = self.context_size
         pad_ctx = torch.zeros((cs - 1, 12), dtype=torch.uint8, device=self.device)
         pad_ctx[:, 0::3] = 255
@@ -701,7 +726,10 @@ class OctAttnFrameEncoder:
         with torch.cuda.stream(self._front_stream):
             self._front_stream.wait_stream(caller)
             xyz_dev = xyz.to(self.device, non_blocking=True)
-            q, bin_num = self.quantize(xyz_dev)
+            if not self.host_transform:
+                q, bin_num = None, self.build_from_xyz(xyz_dev)
+            else:
+                q, bin_num = self.quantize(xyz_dev)
             front = self._front(q)
             ready = torch.cuda.Event()
             ready.record()

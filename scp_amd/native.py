@@ -71,6 +71,9 @@ def lib():
         "scp_geom_create": (C.c_int, [C.POINTER(_vp)]),
         "scp_geom_destroy": (C.c_int, [_vp]),
         "scp_geom_build": (C.c_int, [_vp, _vp, i64, C.POINTER(Segment), i32, C.POINTER(SegmentInfo), _vp]),
+        "scp_geom_build_xyz": (C.c_int, [_vp, _vp, _vp, i32, i32, _vp, i32, C.c_double, C.POINTER(Segment), _vp, C.POINTER(QuantInfo),
+                                         C.POINTER(SegmentInfo), _vp]),
+        "scp_geom_context_ehem_all": (C.c_int, [_vp, i32, i32, i32, _vp, _vp, _vp, _vp, _vp]),
         "scp_geom_emit_nodes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
         "scp_geom_emit_leaves": (C.c_int, [_vp, i32, _vp, _vp]),
         "scp_geom_krecords_i64": (C.c_int, [_vp, i32, _vp, _vp]),
@@ -249,6 +252,47 @@ class Geom:
         self.device = q.device
         self.total_nodes = sum(i.n_nodes for i in self.info)
         return self.info
+
+    def build_xyz(self, frames, mode, qs_list, cart_offset, shells, want_q=False):
+        """Stage G1 + G2 in one launch sequence (scp_geom_build_xyz): frames = list of cuda float32 [n,3] tensors, shells = list of
+        (path bits or None, drop_last) - one tree per (frame, shell), segment index = frame * len(shells) + shell.  Every point is
+        transformed once; -> list of QuantInfo per segment (and the int32 [sum n, 3] integers of all segments when want_q)."""
+        nf, ns = len(frames), len(shells)
+        if len(qs_list) != ns or nf == 0:
+            raise ScpError("build_xyz: one step per shell expected")
+        ptrs = (C.c_void_p * nf)(*[_dev(f, torch.float32) for f in frames])
+        cnt = (C.c_int64 * nf)(*[int(f.shape[0]) for f in frames])
+        qs = (C.c_double * ns)(*[float(q) for q in qs_list])
+        segs = (Segment * ns)()
+        for i, (path, drop) in enumerate(shells):
+            path = list(path or [])
+            bits = 0
+            for p in path:
+                bits = (bits << 1) | int(p)
+            segs[i] = Segment(0, 0, len(path), bits, int(bool(drop)), 0)
+        nseg = nf * ns
+        qinfo, infos = (QuantInfo * nseg)(), (SegmentInfo * nseg)()
+        q = torch.empty((sum(int(f.shape[0]) for f in frames) * ns, 3), dtype=torch.int32, device=frames[0].device) if want_q else None
+        rc = lib().scp_geom_build_xyz(self._h, ptrs, cnt, nf, mode, qs, ns, float(cart_offset), segs, _opt(q), qinfo, infos, _stream())
+        _check(rc, "scp_geom_build_xyz")
+        self.info = list(infos)
+        self.segments = [(0, int(f.shape[0]), path, drop) for f in frames for (path, drop) in shells]
+        self.device = frames[0].device
+        self.total_nodes = sum(i.n_nodes for i in self.info)
+        return (list(qinfo), q) if want_q else list(qinfo)
+
+    def context_ehem_all(self, pos_mode, lidar_level, context_size):
+        """Context tables of EVERY segment of the last build in one launch, rows back to back: -> (ctx u8 [R,12], pos f32 [R,3], the coded
+        symbols IN CODING ORDER u8 [R], (min, max) per level int64 [sum of depths, 2])."""
+        R = sum(self.rows(s) for s in range(len(self.info)))
+        dev = self.device
+        ctx = torch.empty((R, 12), dtype=torch.uint8, device=dev)
+        pos = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        sym = torch.empty(R, dtype=torch.uint8, device=dev)
+        mm = torch.empty((sum(i.depth for i in self.info), 2), dtype=torch.int64, device=dev)
+        _check(lib().scp_geom_context_ehem_all(self._h, pos_mode, lidar_level, context_size, _dev(ctx), _dev(pos), _dev(sym), _dev(mm), _stream()),
+               "scp_geom_context_ehem_all")
+        return ctx, pos, sym, mm
 
     def level_counts(self, seg):
         i = self.info[seg]

@@ -398,3 +398,91 @@ def test_quantizer_any_point_count(dev, orc, n):
         g = native.Geom()
         g.build(q, [(0, n, None, False)])
         assert g.info[0].n_leaves == len(np.unique(got, axis=0))
+
+
+@pytest.mark.parametrize("mode,level,mul,ford", [("spher", 16, True, False), ("spher", 12, False, False), ("cylin", 14, False, False),
+                                                 ("cart", 12, False, False), ("spher", 17, True, True)])
+@pytest.mark.parametrize("n", [120000, 4097, 1, 7])
+def test_fused_front_equals_the_separate_launches(dev, mode, level, mul, ford, n):
+    """scp_geom_build_xyz (transform once, one kernel for quantiser + shell filter + Morton keys + the sort's first histogram) against
+    scp_quantize per shell + scp_geom_build: the same integers, quantiser reports, level counts and node tables, for every coordinate
+    system, multi-level shells, Ford-like millimetre frames, and point counts that leave tiles ragged or nearly empty."""
+    import torch
+    from scp_amd import native
+    from scp_amd.encoder import level_qs
+    from scp_amd.synth import ford_like, synth_frame
+    xyz = synth_frame(3)[:: max(1, 120000 // n)][:n].copy()
+    if ford:
+        xyz = ford_like(xyz)
+    x = torch.from_numpy(xyz).to(dev)
+    m = {"cart": native.CART, "spher": native.SPHER, "cylin": native.CYLIN}[mode]
+    dt = "ford" if ford else "kitti"
+    shells = [([0, 0], level), ([0, 1], level + 1), ([1], level + 2)] if mul else [(None, level)]
+    off = 0.0 if mul else (-200.0 if not ford else -float(2 ** 17))
+    qs_list = [level_qs(dt, lv) for _, lv in shells]
+    ref_q, ref_info = [], []
+    for q_ in qs_list:
+        q, qi, _ = native.quantize(x, m, q_, off)
+        ref_q.append(q); ref_info.append(qi)
+    g0 = native.Geom()
+    segs, o = [], 0
+    for (path, _), q in zip(shells, ref_q):
+        segs.append((o, q.shape[0], path, mul)); o += q.shape[0]
+    try:
+        g0.build(torch.cat(ref_q).contiguous(), segs)
+    except native.ScpError:                       # e.g. a shell that keeps no point of a 1-point frame: both entry points refuse
+        g1 = native.Geom()
+        with pytest.raises(native.ScpError):
+            g1.build_xyz([x], m, qs_list, off, [(p, mul) for p, _ in shells])
+        return
+    g1 = native.Geom()
+    infos, q1 = g1.build_xyz([x], m, qs_list, off, [(p, mul) for p, _ in shells], want_q=True)
+    assert torch.equal(q1, torch.cat(ref_q))
+    for a, b in zip(infos, ref_info):
+        assert a.bin_num == b.bin_num and list(a.qs) == list(b.qs) and list(a.offset) == list(b.offset)
+        assert a.max_coord == b.max_coord and a.min_coord == b.min_coord
+    for s in range(len(shells)):
+        assert g0.level_counts(s) == g1.level_counts(s) and g0.info[s].depth == g1.info[s].depth and g0.info[s].n_leaves == g1.info[s].n_leaves
+        assert torch.equal(g0.leaves(s), g1.leaves(s))
+    n0, n1 = g0.nodes(), g1.nodes()
+    for k in n0:
+        assert torch.equal(n0[k], n1[k]), k
+    # context tables of all segments in one launch + coded symbols in coding order == per-segment launches + a gather through the plan
+    from scp_amd.encoder import EncodePlan
+    pm = native.POS_MINMAX_MUL if mul else (native.POS_POW2 if m == native.CART else native.POS_MINMAX)
+    cs = 8192
+    ctx, pos, sym_coded, mm = g1.context_ehem_all(pm, level, cs)
+    parts = [g0.context_ehem(s, pm, level) for s in range(len(shells))]
+    assert torch.equal(ctx, torch.cat([p[0] for p in parts])) and torch.equal(pos, torch.cat([p[1] for p in parts]))
+    assert torch.equal(mm, torch.cat([p[3] for p in parts]))
+    sizes = []
+    for s in range(len(shells)):
+        c = g0.level_counts(s)
+        if mul:
+            c[-1] -= 1
+        sizes += c
+    order = torch.from_numpy(EncodePlan(sizes, cs).coding_order()).to(dev)
+    assert torch.equal(sym_coded, torch.cat([p[2] for p in parts])[order])
+
+
+def test_fused_front_batches_frames(dev):
+    """Four frames in one scp_geom_build_xyz (FrameEncoder.preprocess_batch): every frame's trees and tables equal its own build."""
+    import torch
+    from scp_amd import native
+    from scp_amd.encoder import level_qs
+    from scp_amd.synth import synth_frame
+    frames = [torch.from_numpy(synth_frame(s)[: 120000 - 1000 * s].copy()).to(dev) for s in range(4)]
+    qs = [level_qs("kitti", 12)]
+    g = native.Geom()
+    infos = g.build_xyz(frames, native.SPHER, qs, -200.0, [(None, False)])
+    ctx, pos, sym, mm = g.context_ehem_all(native.POS_MINMAX, 12, 8192)
+    r0 = m0 = 0
+    for f, x in enumerate(frames):
+        g1 = native.Geom()
+        i1 = g1.build_xyz([x], native.SPHER, qs, -200.0, [(None, False)])
+        assert infos[f].bin_num == i1[0].bin_num and g.level_counts(f) == g1.level_counts(0)
+        c1, p1, s1, m1 = g1.context_ehem_all(native.POS_MINMAX, 12, 8192)
+        n, d = c1.shape[0], m1.shape[0]
+        assert torch.equal(ctx[r0:r0 + n], c1) and torch.equal(pos[r0:r0 + n], p1) and torch.equal(sym[r0:r0 + n], s1) and torch.equal(mm[m0:m0 + d], m1)
+        r0 += n; m0 += d
+    assert r0 == ctx.shape[0]
