@@ -166,6 +166,7 @@ KERNEL_OF = {   # launch-bracket tag -> (kernel name as rocprofv3 prints it, bou
     "oa_attention": ("oa_attn_f16x3_kernel", "mfma", "dual-stream causal attention, non-causal flop count (SURVEY.md 8d)"),
     "edge_gather": ("edge_gather_max_kernel", "l2", "neighbour gather + max + BN + LeakyReLU: 20 gathered rows per point, served by L2 (priced against its 34.5 TB/s)"),
     "cdf": ("cdf_kernel", "hbm", "softmax + serial fp32 cumsum -> (c_low, c_high)"),
+    "geom": ("stage_G_front_and_context_kernels", "hbm", "front_transform_kernel, front_key_kernel, ctx_ehem_all_kernel (the sort and tree kernels between them are not bracketed)"),
     "split_rows": ("split_rows_kernel", "hbm", "fp32 rows -> hi / lo planes"),
     "layernorm": ("layernorm_*_kernel", "hbm", "LayerNorm passes left outside the row-chain kernels"),
     "other": ("(operand preparation)", "hbm", "oa_prep / oa_absmax"),

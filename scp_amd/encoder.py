@@ -24,6 +24,15 @@ from . import native
 KITTI, FORD = "kitti", "ford"
 
 
+def _wait_event(ev, poll_s=0.0005):
+    """Wait for a CUDA / HIP event on a worker thread WITHOUT burning a core: hipEventSynchronize spins (measured on the GPU box with
+    tools/host_cpu_threads.py: each of the two coder threads sat at 100 % of a core for the whole run - 130 of a rank's 200 CPU-ms per
+    frame - blocking-sync flag or not), so the coder thread polls the event and sleeps in between.  The coder is off the critical path
+    (frames in flight hide it); half a millisecond of extra latency per frame costs nothing."""
+    while not ev.query():
+        time.sleep(poll_s)
+
+
 def level_qs(data_type, level):
     """encode_dataset_ehem.py:164 / encode_dataset_ehem_mullevel.py:162-185."""
     return 400 / (2 ** level - 1) if data_type == KITTI else 2 ** (18 - level)
@@ -363,11 +372,11 @@ class FrameEncoder:
             self._copy_stream.wait_event(done)
             host.copy_(lohi, non_blocking=True)
             lohi.record_stream(self._copy_stream)
-            copied = torch.cuda.Event()
+            copied = torch.cuda.Event(blocking=True)      # the coder thread SLEEPS until the pairs have landed (a default event spins a core)
             copied.record()
 
         def work():
-            copied.synchronize()
+            _wait_event(copied)
             return native.ac_encode_lohi(host.numpy())
 
         fut = self._pool.submit(work)
@@ -450,12 +459,12 @@ class FrameEncoder:
             self._copy_stream.wait_event(done)
             host.copy_(lohi, non_blocking=True)
             lohi.record_stream(self._copy_stream)
-            copied = torch.cuda.Event()
+            copied = torch.cuda.Event(blocking=True)      # the coder thread SLEEPS until the pairs have landed (a default event spins a core)
             copied.record()
         cuts = np.concatenate(([0], np.cumsum([m["n_nodes"] for m in metas])))
 
         def work():
-            copied.synchronize()
+            _wait_event(copied)
             h = host.numpy()
             return [native.ac_encode_lohi(h[cuts[f]:cuts[f + 1]]) for f in range(len(metas))]
         return dict(future=self._pool.submit(work), metas=metas, t0=t0, keep=(pre, plan, sym_coded, table, lohi, dev_frames))
@@ -745,11 +754,11 @@ class OctAttnFrameEncoder:
             self._copy_stream.wait_event(done)
             host.copy_(lohi, non_blocking=True)
             lohi.record_stream(self._copy_stream)
-            copied = torch.cuda.Event()
+            copied = torch.cuda.Event(blocking=True)      # the coder thread SLEEPS until the pairs have landed (a default event spins a core)
             copied.record()
 
         def work():
-            copied.synchronize()
+            _wait_event(copied)
             return native.ac_encode_lohi(host.numpy())
 
         return dict(future=self._pool.submit(work), meta=meta, t0=t0, keep=(keep, lohi, q, xyz_dev))

@@ -52,7 +52,7 @@ def test_bench_single_rank_line_has_the_contract_fields():
     assert 0 < r["frac"] < 1 and r["traffic"] is None              # PMC traffic is quoted for the configuration it was measured on only
     ks = out["roofline_kernels"]
     assert "rc_post_attn_kernel" in ks and "swin_attn_planes_kernel" in ks and "knn_f16x3_wg256_kernel" in ks
-    assert abs(sum(k["total_ms_per_frame"] for n, k in ks.items() if n != "cdf_kernel") - r["kernel_ms_sum"]) < 1e-6 * r["kernel_ms_sum"]
+    assert abs(sum(k["total_ms_per_frame"] for n, k in ks.items() if n not in ("cdf_kernel", "stage_G_front_and_context_kernels")) - r["kernel_ms_sum"]) < 1e-6 * r["kernel_ms_sum"]
     for k in ks.values():
         assert k["launches_per_frame"] >= 1 and k["avg_launch_us"] > 0 and ("frac" not in k or 0 < k["frac"] < 1)
     f = out["roofline_frame"]
@@ -67,3 +67,18 @@ def test_bench_decode_mode_times_the_decoder_and_checks_the_round_trip():
     out = _run(["--decode", "--steps", "1", "--warmup", "1", "--config", "ehem-L12-s"])
     assert out["decoded_occupancy_equals_encoded"] is True and out["value"] > 0 and "decode" in out["metric"]
     assert out["config"]["phase2_launch_sequences_per_frame"] >= 10
+
+
+def test_four_ranks_on_one_gpu_keep_the_aggregate_rate():
+    """The only proxy for host-side contention a one-GPU box offers: four ranks - four launch threads, four coder
+    pools, four HIP runtimes - share ONE GPU (SCP_FORCE_DEVICE=0, gloo).  The GPU is the bottleneck either way, so the aggregate rate must
+    stay at the one-rank rate; it falls when the ranks' host sides get in each other's way (cores, allocator locks, the GIL of one
+    process is not shared here).  Each rank also reports its host CPU per frame: about 80 ms (1.2 cores) since round 4."""
+    common = ["--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-strict-leg", "--config", "ehem-L16-m"]
+    one = _run(common)
+    four = _run(["--gpus", "4"] + common, {"SCP_FORCE_DEVICE": "0", "SCP_DIST_BACKEND": "gloo"})
+    assert four["n_gpus"] == 4 and four["ranks"]["shared_frame_streams_identical"]
+    print(f"1 rank {one['value']:.2f} frames/s ({one['host_cpu_ms_per_frame']:.0f} ms host CPU per frame); 4 ranks on the same GPU {four['value']:.2f} frames/s "
+          f"aggregate, per rank {four['ranks']['fps_min']:.2f} .. {four['ranks']['fps_max']:.2f}, host CPU per frame {four['ranks']['host_cpu_ms_per_frame_max']:.0f} ms")
+    assert four["value"] >= 0.9 * one["value"], (four["value"], one["value"])
+    assert one["host_cpu_ms_per_frame"] < 120.0
