@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--host-transform", action="store_true", help="strict-identity mode as the HEADLINE: numpy float32 transform + quantiser on a "
                     "prefetch thread one frame ahead (the default line reports it beside the device transform as `strict_identity`)")
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the second timed loop in strict-identity mode")
+    ap.add_argument("--oa-batch", type=int, default=None, help="OctAttention: windows per forward (OctAttnFrameEncoder.max_batch)")
     ap.add_argument("--decode", action="store_true", help="time the decoder (FrameDecoder) on the configuration's frame instead of the encoder")
     ap.add_argument("--all-configs", action="store_true", help="run every configuration of CONFIGS in turn (child processes), one JSON line each")
     ap.add_argument("--out-dir", default=None, help="with --all-configs: also write <out-dir>/<tag>_bench_<config>.json")
@@ -421,7 +422,7 @@ def main():
     else:
         model = fill_weights(OctAttention(octattn_cfg()), 0).to(dev)
         enc = OctAttnFrameEncoder(model, "kitti", cfg["level"], spher=cfg["mode"] == "spher", cylin=cfg["mode"] == "cylin", device=dev,
-                                  host_transform=True if args.host_transform else None)
+                                  host_transform=True if args.host_transform else None, **({"max_batch": args.oa_batch} if args.oa_batch else {}))
 
     total = args.warmup + args.steps
     frames_host = [synth_frame(rank * 1000 + i) for i in range(total)]

@@ -260,7 +260,7 @@ SCP_API int scp_layernorm_add_split_f16(const float *a, const float *b, int64_t 
                                         float *out, void *hi, void *lo, int64_t ldp, float *scale, float *inv_scale, void *stream);
 SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, int64_t lda, const float *a_inv_scale, const void *Whi, const void *Wlo,
                                  const float *w_inv_scale, int32_t Npad, int32_t Kpad, const float *bias, const float *residual, int64_t ldr,
-                                 float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, void *stream);
+                                 float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream);
 /* The same dense layer with the ACTIVATION pre-split too: A arrives as bf16 planes hi/lo [M][lda] (lda % 8 == 0, lda >= Kpad,
  * columns K..Kpad zero) written by the producing kernel (scp_split_rows, scp_layernorm_rows_split, the attention kernels, or this
  * function's own split output), so operand tiles go global -> LDS by LDS-DMA with no conversion.  Outputs: C fp32 [M][ldc]
@@ -329,6 +329,15 @@ SCP_API int64_t scp_octattn_f16x3_ws_bytes(int32_t B, int32_t c, int32_t H);
 SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
                                         int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *workspace,
                                         int64_t ws_bytes, void *stream);
+/* OctAttention's input stage in one launch (oct_attention.py:48-66): embeddings of the four ancestors + Linear(3 -> d_pos) of their
+ * positions, concatenated to D = 4 (d_occ + d_lvl + d_oct + d_pos) <= 768 channels, scaled by sqrt(D), plus the position table pe [c][D];
+ * both streams (1 = "unknown": occ_enc[255] for the node's own occupancy).  ctx uint8 [n][12] = (occ, level, octant) x 4, pos fp32
+ * [n][4][3], row r is position r % c of its window; levels are shifted / clipped as the reference does (level_cap 12, or 10 for obj).
+ * Out: E fp32 [2][n][D] and E's f16x3 operand (planes [2 n][ldp] + row scales: what scp_split_rows_f16 makes of E). */
+SCP_API int scp_octattn_embed(const uint8_t *ctx, const float *pos, int64_t n, int32_t c, const float *occ_enc, int32_t d_occ,
+                              const float *level_enc, int32_t d_lvl, int32_t max_level, const float *octant_enc, int32_t d_oct,
+                              const float *pos_w, const float *pos_b, int32_t d_pos, const float *pe, int32_t level_cap, float *E,
+                              void *hi, void *lo, int64_t ldp, float *scale, float *inv_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stage C - softmax -> integer CDF, on device

@@ -27,6 +27,10 @@ SCP_API int scp_knn_debug_buffer(unsigned long long *dev_buf);
 /* the same for the row-chain kernels (scp_swin_ln_linear / scp_swin_post_attn): (workgroups * 4 * 8) u64, per wave the cycle sums of
  * the kernel's phases and its tile count (tools/mb_rowchain_probe.py, tools/mb_postattn.py) */
 SCP_API int scp_rc_debug_buffer(unsigned long long *dev_buf);
+/* A/B bracket of swin_attn_planes_kernel (bit-identical forms; tools/mb_attn_planes.py): 0 = the round-3 instruction order, 1 (default) =
+ * K fragment reads requested in two pinned groups + v_permlane32_swap exchanges (1 096 against 1 103 us per 1 152 windows: the kernel is
+ * bound by its VALU count per tile, not by these latencies - DESIGN.md 4.7) */
+SCP_API int scp_set_attention_variant(int32_t v);
 /* persistent workgroups of the row-chain launches (0 = one per CU of the device): for launches on a stream created with a CU mask
  * (tools/mb_cumask.py), whose CU set is smaller than the device's */
 SCP_API int scp_rc_set_grid(int32_t workgroups);

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libscp_hip.so")
 SOURCES = ["api.cpp", "geom.hip", "sort_u64.hip", "cdf.hip", "rangecoder.cpp", "legacy_octree.cpp",
-           "knn.hip", "edge.hip", "attn.hip", "octattn.hip", "octattn_f16.hip", "gemm.hip", "gemm_split.hip", "rowchain.hip", "fused.hip", "metrics.hip", "plan.hip"]
+           "knn.hip", "edge.hip", "attn.hip", "octattn.hip", "octattn_f16.hip", "octattn_embed.hip", "gemm.hip", "gemm_split.hip", "rowchain.hip", "fused.hip", "metrics.hip", "plan.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fvisibility=hidden", "-x", "hip"]
@@ -16,7 +16,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # bit-exact kernels: numpy / torch evaluate a*a + b*b as two roundings, so FMA contraction must be off there
 # (HIP's __fmul_rn / __fadd_rn are plain operators and do NOT stop the contraction).
 EXTRA = {"geom.hip": ["-ffp-contract=off"], "knn.hip": ["-ffp-contract=off"], "cdf.hip": ["-ffp-contract=off"],
-         "edge.hip": ["-ffp-contract=off"], "metrics.hip": ["-ffp-contract=off"]}
+         "edge.hip": ["-ffp-contract=off"], "metrics.hip": ["-ffp-contract=off"], "octattn_embed.hip": ["-ffp-contract=off"]}
 if os.environ.get("SCP_ATTN_DEFS"):    # experiment builds of csrc/attn.hip (e.g. SCP_ATTN_DEFS="-DPNS=3")
     EXTRA["attn.hip"] = os.environ["SCP_ATTN_DEFS"].split()
 if os.environ.get("SCP_RC_DEFS"):      # experiment builds of csrc/rowchain.hip (e.g. SCP_RC_DEFS="-DRC_WAIT0")

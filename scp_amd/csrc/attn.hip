@@ -396,6 +396,13 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bf16x3_kernel(const float *_
 //             8 (j >> 2) (bits 2 and 3 of the key index swapped: the 8 keys of a lane's P fragment are contiguous).
 // Both are linear images of the LDS tiles, so a DMA instruction copies 1 KiB as it lies.  Same products in the same order as
 // swin_attn_bf16x3_kernel: identical bits.  (scp_swin_kv_planes writes the planes from fp32 k / v.)
+// value of lane ^ 32 (the other half-lane of a query) by v_permlane32_swap - the half exchange of gfx950 - instead of ds_bpermute
+__device__ __forceinline__ float attn_xchg32(float x, int h) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(h ? r[0] : r[1]);
+}
+
 typedef __attribute__((address_space(3))) void *attn_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *attn_glb_ptr_t;
 #define PKT 32          // keys per tile
@@ -404,6 +411,7 @@ typedef const __attribute__((address_space(1))) void *attn_glb_ptr_t;
 #define PNS 2            // stages (tiles requested PNS - 1 iterations ahead).  3 (52 KiB of LDS: three workgroups per CU instead of four): 1 282 against 1 227 us per 1 152 windows
 #endif
 
+template <int VAR>      // A/B bracket (scp_debug.h: scp_set_attention_variant): 0 = round-3 instruction order, 1 = K reads in two pinned groups + permlane exchanges
 __global__ __launch_bounds__(256, 3) void swin_attn_planes_kernel(const float *__restrict__ q, const __bf16 *__restrict__ khi, const __bf16 *__restrict__ klo,
                                                                  const __bf16 *__restrict__ vthi, const __bf16 *__restrict__ vtlo,
                                                                  const float *__restrict__ table, int shift, int ldq, float *__restrict__ out,
@@ -479,13 +487,38 @@ __global__ __launch_bounds__(256, 3) void swin_attn_planes_kernel(const float *_
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        // all eight K fragments of the tile are requested before the first product (round 4: the compiler used to read one fragment,
+        // wait for it, multiply - eight exposed LDS round trips per tile; same products in the same order)
+        constexpr int KPIN = 2;    // K fragments (pairs of planes) requested together: 2 keeps 128 registers = four waves per SIMD (all four at once: 132 registers, three waves: 1 157 against 1 096 us per 1 152 windows)
+        if (VAR == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int ko = col * 128 + (((2 * c + h) ^ (col & 7)) << 4);
-            const bf16x8 ah = *(const bf16x8 *)(S + ko), al = *(const bf16x8 *)(S + 4096 + ko);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[c], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[c], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[c], s, 0, 0, 0);
+            for (int c = 0; c < 4; ++c) {
+                const int ko = col * 128 + (((2 * c + h) ^ (col & 7)) << 4);
+                const bf16x8 ah = *(const bf16x8 *)(S + ko), al = *(const bf16x8 *)(S + 4096 + ko);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[c], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[c], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[c], s, 0, 0, 0);
+            }
+        } else {
+            bf16x8 kah[4], kal[4];
+#pragma unroll
+            for (int c0 = 0; c0 < 4; c0 += KPIN) {
+#pragma unroll
+                for (int c = c0; c < c0 + KPIN; ++c) {
+                    const int ko = col * 128 + (((2 * c + h) ^ (col & 7)) << 4);
+                    kah[c] = *(const bf16x8 *)(S + ko);
+                    kal[c] = *(const bf16x8 *)(S + 4096 + ko);
+                }
+                // pin: hipcc otherwise sinks every read down to its first use again (ds_read -> s_waitcnt lgkmcnt(0) -> one product, eight times)
+#pragma unroll
+                for (int c = c0; c < c0 + KPIN; ++c) asm volatile("" : "+v"(kah[c]), "+v"(kal[c]));
+#pragma unroll
+                for (int c = c0; c < c0 + KPIN; ++c) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kal[c], qh[c], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kah[c], ql[c], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kah[c], qh[c], s, 0, 0, 0);
+                }
+            }
         }
         const int j0 = t * PKT + 4 * h;
         float mx = -INFINITY;
@@ -495,14 +528,14 @@ __global__ __launch_bounds__(256, 3) void swin_attn_planes_kernel(const float *_
             s[r] = s[r] + tab[qi - j + (WIN - 1)];
             mx = fmaxf(mx, s[r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32)) + madd;
+        mx = fmaxf(mx, VAR == 0 ? __shfl_xor(mx, 32) : attn_xchg32(mx, h)) + madd;          // the query's other half-lane: one v_permlane32_swap, no LDS round trip
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         const float msub = m_new - madd;
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - msub); ps += s[r]; }
-        ps += __shfl_xor(ps, 32);
+        ps += VAR == 0 ? __shfl_xor(ps, 32) : attn_xchg32(ps, h);
         l_run = l_run * alpha + ps;
         m_run = m_new;
         if (__any(alpha != 1.f)) {
@@ -593,6 +626,9 @@ extern "C" SCP_API int scp_swin_kv_planes(const float *k, const float *v, int64_
     return SCP_OK;
 }
 
+static int g_attn_variant = 1;
+extern "C" SCP_API int scp_set_attention_variant(int32_t v) { g_attn_variant = v; return SCP_OK; }
+
 // packed window attention on those planes (q fp32 [rows][ldq]); out fp32 [rows][256] or (ohi, olo) planes [rows][ldo]
 extern "C" SCP_API int scp_swin_attention_packed_planes(const float *q, const void *khi, const void *klo, const void *vthi, const void *vtlo,
                                                         const float *bias_table, const int32_t *wtab, int32_t total_windows, int32_t shift, int32_t ldq,
@@ -602,8 +638,10 @@ extern "C" SCP_API int scp_swin_attention_packed_planes(const float *q, const vo
         (ohi && (!olo || ldo < NH * HD || (ldo & 3) || (((uintptr_t)ohi | (uintptr_t)olo) & 7))))
         return SCP_EINVAL;
     SCP_PROF(SCP_PROF_ATTENTION, stream, (double)total_windows * WIN * 2.0 * 2.0 * WIN * NH * HD);
-    hipLaunchKernelGGL(swin_attn_planes_kernel, dim3(total_windows * NH * (WIN / QT)), dim3(256), 0, (hipStream_t)stream, q, (const __bf16 *)khi,
-                       (const __bf16 *)klo, (const __bf16 *)vthi, (const __bf16 *)vtlo, bias_table, shift, ldq, out, wtab, (__bf16 *)ohi, (__bf16 *)olo, ldo);
+#define ATTN_GO(V) hipLaunchKernelGGL(swin_attn_planes_kernel<V>, dim3(total_windows * NH * (WIN / QT)), dim3(256), 0, (hipStream_t)stream, q, (const __bf16 *)khi, \
+                                      (const __bf16 *)klo, (const __bf16 *)vthi, (const __bf16 *)vtlo, bias_table, shift, ldq, out, wtab, (__bf16 *)ohi, (__bf16 *)olo, ldo)
+    if (g_attn_variant == 0) ATTN_GO(0); else ATTN_GO(1);
+#undef ATTN_GO
     LAUNCH_CHECK();
     return SCP_OK;
 }

@@ -430,7 +430,7 @@ extern "C" SCP_API int scp_split_rows(const float *src, int64_t ld_src, int64_t 
 
 static int g_num_cu = 0;
 
-template <int WM, int WN, int TM, bool EXT>
+template <int WM, int WN, int TM, bool EXT, bool F16 = false>
 static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st, double work) {
     constexpr int BM = WM * TM * 32, BN = WN * 64;
     constexpr int STAGE = (BM + BN) * 128;
@@ -438,18 +438,21 @@ static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st, double w
     constexpr int LDS = STAGE + (STAGE > BOUNCE ? STAGE : BOUNCE) + (EXT ? 2 * BM * 8 : 0);   // stage 0 + max(stage 1, the epilogue's 8 KiB bounce slice per wave) [+ row maps]
     static bool configured = false;
     if (!configured) {
-        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_NONE, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_LEAKY, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_GELU, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_RELU, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_NONE, EXT, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_RELU, EXT, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        if (!F16) {
+            HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_LEAKY, EXT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<WM, WN, TM, ACT_GELU, EXT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        }
         configured = true;
     }
     const int64_t ntiles = cdiv64(ga.M, BM) * cdiv64(ga.N, BN);
     const int64_t slots = (int64_t)g_num_cu * (WM * WN == 4 ? 2 : 1);
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
     SCP_PROF(SCP_PROF_GEMM_SPLIT, st, work);
-#define GOS(ACT) hipLaunchKernelGGL((gemm_split_kernel<WM, WN, TM, ACT, EXT>), dim3(grid), dim3(WM * WN * 64), LDS, st, ga)
-    switch (act) { case ACT_LEAKY: GOS(ACT_LEAKY); break; case ACT_GELU: GOS(ACT_GELU); break; case ACT_RELU: GOS(ACT_RELU); break; default: GOS(ACT_NONE); }
+#define GOS(ACT, F) hipLaunchKernelGGL((gemm_split_kernel<WM, WN, TM, ACT, EXT, F>), dim3(grid), dim3(WM * WN * 64), LDS, st, ga)
+    if (F16) { if (act == ACT_RELU) GOS(ACT_RELU, F16); else GOS(ACT_NONE, F16); }
+    else switch (act) { case ACT_LEAKY: GOS(ACT_LEAKY, false); break; case ACT_GELU: GOS(ACT_GELU, false); break; case ACT_RELU: GOS(ACT_RELU, false); break; default: GOS(ACT_NONE, false); }
 #undef GOS
     LAUNCH_CHECK();
     return SCP_OK;
@@ -515,8 +518,8 @@ extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_
 // Bit-identical to scp_linear_f16x3_scaled on the fp32 rows the planes were made from.
 extern "C" SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, int64_t lda, const float *a_inv_scale, const void *Whi, const void *Wlo,
                                             const float *w_inv_scale, int32_t Npad, int32_t Kpad, const float *bias, const float *residual, int64_t ldr,
-                                            float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, void *stream) {
-    if (!Ahi || !Alo || !a_inv_scale || !Whi || !Wlo || !w_inv_scale || !C || M <= 0 || N <= 0 || K <= 0 || (lda & 7) || Kpad < K || (Kpad & 31) ||
+                                            float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream) {
+    if (!Ahi || !Alo || !a_inv_scale || !Whi || !Wlo || !w_inv_scale || !C || M <= 0 || N <= 0 || K <= 0 || (lda & 7) || Kpad < K || (Kpad & 31) || cfg < 0 || cfg > 3 ||
         lda < Kpad || (Npad & 255) || Npad < N || (act != ACT_NONE && act != ACT_RELU) || ldc < N || (residual && ldr < N) ||
         (((uintptr_t)Ahi | (uintptr_t)Alo | (uintptr_t)Whi | (uintptr_t)Wlo) & 15) || (((uintptr_t)C | (uintptr_t)residual) & 3))
         return SCP_EINVAL;
@@ -534,23 +537,16 @@ extern "C" SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, in
     ga.a_isc = a_inv_scale; ga.w_isc = w_inv_scale;
     { static int wt = -1; if (wt < 0) { const char *e = getenv("SCP_WTILE"); wt = (e && e[0] == '0') ? 0 : 1; } ga.wtiled = wt; }
     ga.vec_ok = !((ldc & 3) || ((uintptr_t)C & 15) || (residual && ((ldr & 3) || ((uintptr_t)residual & 15))));
-    // 128 x 128 tiles, 4 waves, two workgroups per CU: N = 600 / 300 waste 6 % / 22 % of a 128-wide column tiling where 256-wide tiles
-    // waste 22 % / 41 % (tools/mb_oa_gemm.py: 660 against 711 us at M = 245 760, N = K = 600 with the bf16 planes)
-    constexpr int STAGE = (128 + 128) * 128, BOUNCE = 4 * 8192, LDS = STAGE + (STAGE > BOUNCE ? STAGE : BOUNCE);
-    static bool configured = false;
-    if (!configured) {
-        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<2, 2, 2, ACT_NONE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        HIP_TRY(hipFuncSetAttribute((const void *)gemm_split_kernel<2, 2, 2, ACT_RELU, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        configured = true;
-    }
-    const int64_t ntiles = cdiv64(M, 128) * cdiv64(N, 128);
-    const int64_t slots = 2 * (int64_t)g_num_cu;
-    const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
-    SCP_PROF(SCP_PROF_GEMM_SPLIT, stream, 2.0 * M * (double)N * K);
-    if (act == ACT_RELU) hipLaunchKernelGGL((gemm_split_kernel<2, 2, 2, ACT_RELU, false, true>), dim3(grid), dim3(256), LDS, (hipStream_t)stream, ga);
-    else hipLaunchKernelGGL((gemm_split_kernel<2, 2, 2, ACT_NONE, false, true>), dim3(grid), dim3(256), LDS, (hipStream_t)stream, ga);
-    LAUNCH_CHECK();
-    return SCP_OK;
+    // cfg 0 = automatic.  3: 128 x 128 tiles, 4 waves, two workgroups per CU: N = 600 / 300 waste 6 % / 22 % of a 128-wide column tiling
+    // where 256-wide tiles waste 22 % / 41 % (tools/mb_oa_gemm.py: 660 against 711 us at M = 245 760, N = K = 600 with the bf16 planes);
+    // 2: 256 rows x 128 columns, 8 waves (the same column waste, 1.33 x fewer LDS-DMA bytes per flop); 1: 256 x 256 (N a multiple of 256,
+    // or wide concatenated projections such as key | value, N = 1200: 6.7 % waste, half the fill of the 128 x 128 tile).
+    const double work = 2.0 * M * (double)N * K;
+    hipStream_t st = (hipStream_t)stream;
+    if (cfg == 0) cfg = (N > 768 || (N & 255) == 0) ? 1 : 3;
+    if (cfg == 1) return launch_cfg<2, 4, 4, false, true>(ga, act, st, work);
+    if (cfg == 2) return launch_cfg<4, 2, 2, false, true>(ga, act, st, work);
+    return launch_cfg<2, 2, 2, false, true>(ga, act, st, work);
 }
 
 // the same with a GATHERED residual added BEFORE the activation: out[m] = act(A[m] . W^T + bias + residual[res_map[m]]).

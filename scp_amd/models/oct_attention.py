@@ -89,14 +89,12 @@ class OctAttention(nn.Module):
         m.load_state_dict(sd["state_dict"] if "state_dict" in sd else sd, strict=True)
         return m
 
-    @torch.no_grad()
-    def forward(self, data, pos=None):
-        if not data.is_cuda:
-            raise native.ScpError("OctAttention runs on the MI355X only (no CPU fallback)")
+    def _embed_torch(self, data, pos, cap):
+        """The input stage as a sequence of torch index operations - the executable specification of csrc/octattn_embed.hip (tests
+        compare the two bit for bit) and the path of the rows form (PLANES = False)."""
         B, c = data.shape[:2]
         data = data.long()
         occ, level, octant = data[..., 0], data[..., 1], data[..., 2]
-        cap = 10 if self.cfg.train.type == "obj" else 12
         level = level - torch.clip(level[:, :, -1:] - cap, 0, None)           # oct_attention.py:57-61, out of place
         level = torch.clip(level, 0, self.cfg.model.max_octree_level)
         oe = F.embedding(occ, self.occ_enc.weight)
@@ -112,19 +110,37 @@ class OctAttention(nn.Module):
         D = self.embed_dimension
         # both streams travel as one [2, B, c, D] tensor (0: known, 1: unknown): every layer they share runs as one launch
         E = torch.stack((torch.cat(parts, 3).reshape(B, c, D), torch.cat(parts_u, 3).reshape(B, c, D))) * math.sqrt(D)
-        E = E + self.transformer_encoder.position_enc.pe[:c]
-        # Every dense layer that reads an embedding tensor reads PRE-SPLIT f16 planes (native.SplitActF16: one pass per tensor writes the
-        # row scales and both planes; key / value / query / linear1 / decoder0 then stream them by LDS-DMA - csrc/gemm_split.hip, F16
-        # instantiation - instead of converting fp32 rows in every tile).  Bit-identical to the fp32-row kernel (SCP_OA_DENSE=rows).
+        return E + self.transformer_encoder.position_enc.pe[:c]
+
+    @torch.no_grad()
+    def forward(self, data, pos=None):
+        if not data.is_cuda:
+            raise native.ScpError("OctAttention runs on the MI355X only (no CPU fallback)")
+        B, c = data.shape[:2]
+        cap = 10 if self.cfg.train.type == "obj" else 12
+        D = self.embed_dimension
         planes = PLANES
         n = B * c
+        pa = None                                      # planes of E, when the kernel that produced E wrote them
+        pe_tab = self.transformer_encoder.position_enc.pe
+        if planes and D <= 768 and D % 4 == 0 and pos is not None and c <= pe_tab.shape[0]:
+            # the whole input stage in ONE kernel (csrc/octattn_embed.hip): three embedding lookups x four ancestors, the position
+            # Linear, concatenation, sqrt(D) scale, position table - both streams - and the f16x3 operand of the first dense layers
+            ctx8 = data.reshape(n, 12)
+            ctx8 = ctx8 if ctx8.dtype == torch.uint8 else ctx8.to(torch.uint8)
+            ap = self.abs_pos_enc if self.abs_pos_embed_dim else None
+            E, pa = native.octattn_embed(ctx8.contiguous(), pos.reshape(n, 4, 3).float().contiguous(), c, self.occ_enc.weight, self.level_enc.weight,
+                                         self.octant_enc.weight, None if ap is None else ap.weight, None if ap is None else ap.bias, pe_tab, cap,
+                                         self.cfg.model.max_octree_level)
+            E = E.reshape(2, B, c, D)
+        else:
+            E = self._embed_torch(data, pos, cap)
 
         def lin(a, x, w, b, act=None, residual=None, rows=None, scales=None):
             if planes:
                 return native.linear_split_f16(a if rows is None else a.rows(*rows), _ops._split16(w), b, _ops._ACT[act], residual)
             return linear(x, w, b, act=act, residual=residual, scales=scales)
 
-        pa = None                                      # planes of E, when the LayerNorm that produced E wrote them
         for lyr in self.transformer_encoder.layers:
             a = lyr.attn
             E2 = E.reshape(-1, D)

@@ -63,7 +63,7 @@ def lib():
         "scp_swin_kv_planes": (C.c_int, [_vp, _vp, i64, i64, _vp, _vp, _vp, _vp, _vp]),
         "scp_swin_attention_packed_planes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, i32, i32, i32, _vp, _vp, _vp, i64, _vp]),
         "scp_split_rows_f16": (C.c_int, [_vp, i64, i32, i32, _vp, _vp, i64, _vp, _vp, _vp]),
-        "scp_linear_split_f16": (C.c_int, [_vp, _vp, i64, _vp, _vp, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp]),
+        "scp_linear_split_f16": (C.c_int, [_vp, _vp, i64, _vp, _vp, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_last_hip_error": (C.c_int, []),
         "scp_device_count": (C.c_int, []),
         "scp_device_name": (C.c_int, [C.c_char_p, C.c_int]),
@@ -110,6 +110,7 @@ def lib():
         "scp_swin_attention": (C.c_int, [_vp, _vp, _vp, _vp, i32, i32, i32, i32, i32, _vp, _vp]),
         "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
         "scp_octattn_f16x3_ws_bytes": (C.c_int64, [i32, i32, i32]),
+        "scp_octattn_embed": (C.c_int, [_vp, _vp, i64, i32, _vp, i32, _vp, i32, i32, _vp, i32, _vp, _vp, i32, _vp, i32, _vp, _vp, _vp, i64, _vp, _vp, _vp]),
         "scp_octattn_attention_f16x3": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp, i64, _vp]),
         "scp_split_weight_bf16": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp, _vp]),
         "scp_linear_bf16x3": (C.c_int, [_vp, i64, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp]),
@@ -795,7 +796,7 @@ class SplitActF16:
         return SplitActF16(parts=(self.hi[a:b], self.lo[a:b], self.sc[a:b], self.isc[a:b], self.K))
 
 
-def linear_split_f16(a, sw, bias=None, act=ACT_NONE, residual=None):
+def linear_split_f16(a, sw, bias=None, act=ACT_NONE, residual=None, cfg=0, out=None):
     """act(A W^T + bias) + residual on pre-split f16 planes (SplitActF16 x SplitWeightF16) -> fp32 [M, N]; bit-identical to linear_f16x3
     on the fp32 rows the planes were made from (csrc/gemm_split.hip, F16 instantiation: operands by LDS-DMA, no conversion in the tile)."""
     if not sw.tiled_layout and WTILE:
@@ -803,7 +804,8 @@ def linear_split_f16(a, sw, bias=None, act=ACT_NONE, residual=None):
     M, N = a.M, sw.N
     if a.K != sw.K:
         raise ScpError("linear_split_f16: K mismatch")
-    out = torch.empty((M, N), dtype=torch.float32, device=a.hi.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.hi.device)
     r2 = None
     if residual is not None:
         r2 = residual.reshape(-1, N)
@@ -811,7 +813,7 @@ def linear_split_f16(a, sw, bias=None, act=ACT_NONE, residual=None):
             r2 = r2.contiguous()
     rc = lib().scp_linear_split_f16(a.hi.data_ptr(), a.lo.data_ptr(), a.hi.stride(0), a.isc.data_ptr(), sw.hi.data_ptr(), sw.lo.data_ptr(),
                                     sw.inv_scale.data_ptr(), sw.Npad, sw.Kpad, _opt(bias), None if r2 is None else r2.data_ptr(),
-                                    0 if r2 is None else r2.stride(0), out.data_ptr(), out.stride(0), M, N, sw.K, act, _stream())
+                                    0 if r2 is None else r2.stride(0), out.data_ptr(), out.stride(0), M, N, sw.K, act, cfg, _stream())
     _check(rc, "scp_linear_split_f16")
     return out
 
@@ -1200,6 +1202,25 @@ def octattn_attention(q_u, k, k_u, v, v_u, heads, out=None, out_u=None):
                                      _dev(out), _dev(out_u), _stream())
     _check(rc, "scp_octattn_attention")
     return out, out_u
+
+
+def octattn_embed(ctx, pos, c, occ_enc, level_enc, octant_enc, pos_w, pos_b, pe, level_cap, max_level):
+    """OctAttention's input stage in one launch (csrc/octattn_embed.hip): ctx uint8 [n,12], pos f32 [n,4,3] (n = B * c rows) ->
+    (E f32 [2, n, D] both streams, SplitActF16 of E's 2 n rows)."""
+    n = ctx.shape[0]
+    d_occ, d_lvl, d_oct = occ_enc.shape[1], level_enc.shape[1], octant_enc.shape[1]
+    d_pos = 0 if pos_w is None else pos_w.shape[0]
+    D = 4 * (d_occ + d_lvl + d_oct + d_pos)
+    ld = -(-D // 32) * 32
+    dev = ctx.device
+    E = torch.empty((2, n, D), dtype=torch.float32, device=dev)
+    pl = torch.empty((2, 2 * n, ld), dtype=torch.float16, device=dev)
+    ws = torch.empty((2, 2 * n), dtype=torch.float32, device=dev)
+    rc = lib().scp_octattn_embed(_dev(ctx, torch.uint8), _dev(pos, torch.float32), n, c, _dev(occ_enc, torch.float32), d_occ, _dev(level_enc, torch.float32),
+                                 d_lvl, max_level, _dev(octant_enc, torch.float32), d_oct, _opt(pos_w), _opt(pos_b), d_pos, _dev(pe, torch.float32),
+                                 level_cap, E.data_ptr(), pl[0].data_ptr(), pl[1].data_ptr(), ld, ws[0].data_ptr(), ws[1].data_ptr(), _stream())
+    _check(rc, "scp_octattn_embed")
+    return E, SplitActF16(parts=(pl[0], pl[1], ws[0], ws[1], D))
 
 
 # ------------------------------------------------------------------------------------------------- stage C

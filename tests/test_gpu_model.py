@@ -1342,3 +1342,29 @@ def test_launch_brackets_record_inside_the_library(dev):
     with native.launch_profile() as p:
         pass
     assert p.records() == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,c,obj", [(1, 1, False), (2, 300, False), (3, 1024, False), (2, 257, True)])
+def test_octattn_embed_kernel_equals_the_torch_input_stage(dev, B, c, obj):
+    """scp_octattn_embed (embeddings x 4 ancestors, position Linear, concatenation, sqrt(D), position table, both streams, f16x3 planes -
+    one launch) against the sequence of torch operations it replaces + the standalone split pass: identical bits, including levels
+    above the cap (shifted and clipped as oct_attention.py:57-61 does)."""
+    from scp_amd import native
+    from scp_amd.models import OctAttention
+    from scp_amd.weights import fill_weights
+    cfg = octattn_cfg()
+    if obj:
+        cfg["train"]["type"] = "obj"
+    m = fill_weights(OctAttention(cfg), 3).to(dev)
+    g = torch.Generator().manual_seed(B * 1000 + c)
+    data = torch.stack((torch.randint(0, 256, (B, c, 4), generator=g), torch.randint(0, 17, (B, c, 4), generator=g),
+                        torch.randint(0, 9, (B, c, 4), generator=g)), 3).to(dev)
+    pos = torch.rand((B, c, 4, 3), generator=g).to(dev)
+    want = m._embed_torch(data, pos, 10 if obj else 12)
+    ap = m.abs_pos_enc
+    E, pa = native.octattn_embed(data.reshape(B * c, 12).to(torch.uint8), pos.reshape(B * c, 4, 3).contiguous(), c, m.occ_enc.weight, m.level_enc.weight,
+                                 m.octant_enc.weight, ap.weight, ap.bias, m.transformer_encoder.position_enc.pe, 10 if obj else 12, cfg.model.max_octree_level)
+    assert torch.equal(E.reshape(want.shape), want)
+    ref = native.SplitActF16(want.reshape(-1, want.shape[-1]).contiguous())
+    assert torch.equal(pa.hi, ref.hi) and torch.equal(pa.lo, ref.lo) and torch.equal(pa.sc, ref.sc) and torch.equal(pa.isc, ref.isc)

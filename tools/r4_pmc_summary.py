@@ -1,0 +1,52 @@
+"""Summarise the counter passes of tools/r4_profiles.sh: python tools/r4_pmc_summary.py <out dir> <tag> <name>
+-> <out>/<tag>_<name>_pmc_traffic.json (HBM bytes per launch per kernel and per frame; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+for gfx950 - it reports half of the bytes of wide coalesced reads; both counters are in KB) and <out>/<tag>_<name>_sq_wave_states.txt."""
+import collections, csv, glob, json, os, sys
+O, tag, name = sys.argv[1:4]
+frames = 3 if "ehem" in name else 17       # run_frame.py 16 1 3 | run_octattn.py: 3 single + 2 warm-up + 12 pipelined frames
+tot = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    fs = glob.glob(f"{O}/pmc_{name}_{c}/*/*counter_collection.csv")
+    if not fs:
+        print("no counter file for", c); sys.exit(0)
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
+        if r["Counter_Name"] != c:
+            continue
+        k = r["Kernel_Name"].split("(")[0]
+        acc[k][0] += 1
+        acc[k][1] += float(r["Counter_Value"])
+    tot[c] = acc
+per = {}
+for k in tot["FETCH_SIZE"]:
+    n = tot["FETCH_SIZE"][k][0]
+    fb = 2.0 * 1024 * tot["FETCH_SIZE"][k][1]
+    wb = 1024.0 * tot["WRITE_SIZE"].get(k, [0, 0.0])[1]
+    per[k] = {"launches": n, "hbm_bytes_per_launch": (fb + wb) / n, "fetch_bytes_corrected": fb, "write_bytes": wb}
+frame_bytes = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in per.values()) / frames
+big = dict(sorted(per.items(), key=lambda kv: -(kv[1]["fetch_bytes_corrected"] + kv[1]["write_bytes"]))[:16])
+dom = "rc_post_attn_kernel" if "ehem" in name else "void gemm_split_kernel<2, 2, 2, 0, false, true>"
+g = [v for k, v in per.items() if k.startswith(dom) or dom in k]
+out = {"config": "ehem-L16-m" if "ehem" in name else "octattn-L14-cylin", "frames_profiled": frames,
+       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs (no tracing options beside --pmc) of " +
+               ("tools/run_frame.py 16 1 3" if "ehem" in name else "tools/run_octattn.py 14 1") +
+               "; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); units KB -> bytes; one-time weight preparation of the first frame included",
+       "dominant_kernel": dom, "dominant_hbm_bytes_per_launch": (sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in g) / max(1, sum(v["launches"] for v in g))) if g else None,
+       "frame_hbm_bytes": frame_bytes, "per_kernel": big}
+json.dump(out, open(f"{O}/{tag}_{name}_pmc_traffic.json", "w"), indent=1)
+print(f"{name}: frame HBM traffic {frame_bytes / 1e9:.1f} GB; dominant {dom}: {out['dominant_hbm_bytes_per_launch']}")
+fs = glob.glob(f"{O}/pmc_{name}_sq/*/*counter_collection.csv")
+if fs:
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
+        k = r["Kernel_Name"].split("(")[0][:52]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    rows = sorted(acc.items(), key=lambda kv: -kv[1]["SQ_WAVE_CYCLES"])[:14]
+    with open(f"{O}/{tag}_{name}_sq_wave_states.txt", "w") as f:
+        f.write(f"# SQ wave-state counters, one rocprofv3 --pmc pass of {name} (quad-cycle counts; fractions of SQ_WAVE_CYCLES; mfma = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES)\n")
+        f.write(f"{'kernel':52s} {'wave_cyc':>10s} {'wait_any':>8s} {'wait_inst':>9s} {'active':>7s} {'valu':>6s} {'mfma_busy/busy':>14s}\n")
+        for k, v in rows:
+            wc = max(v["SQ_WAVE_CYCLES"], 1.0)
+            f.write(f"{k:52s} {wc:10.3e} {v['SQ_WAIT_ANY']/wc:8.2f} {v['SQ_WAIT_INST_ANY']/wc:9.2f} {v['SQ_ACTIVE_INST_ANY']/wc:7.2f} "
+                    f"{v['SQ_ACTIVE_INST_VALU']/wc:6.2f} {v['SQ_VALU_MFMA_BUSY_CYCLES']/max(v['SQ_BUSY_CYCLES'],1.0):14.3f}\n")
+    print(open(f"{O}/{tag}_{name}_sq_wave_states.txt").read())

@@ -10,8 +10,11 @@ K = P * S * FB          # keys per build
 N = N * FB              # nodes per build
 nf = nf / FB            # builds
 B = {   # kernel name fragment -> (bytes per call, what moves)
-    "transform_kernel": (24 * P, "xyz f32 in, (rho, phi, theta) f32 out, one shell of one frame"),
-    "quantize_kernel": (24 * P, "f32 in, int32 out, one shell of one frame"),
+    "front_transform_kernel": (24 * P * FB, "xyz f32 in, (rho, phi, theta | z) f32 out, every frame of the build, each point once"),
+    "front_key_kernel": (12 * K + 8 * K, "transformed point in (L2: a point is read once per shell), 64-bit key out + the sort's first digit histogram"),
+    "ctx_ehem_all_kernel": (37 * N, "ancestor gathers in, 12 B context + 12 B position + 1 B coded symbol out, every segment"),
+    "transform_kernel": (24 * P, "xyz f32 in, (rho, phi, theta) f32 out, one shell of one frame (scp_quantize path)"),
+    "quantize_kernel": (24 * P, "f32 in, int32 out, one shell of one frame (scp_quantize path)"),
     "seg_minmax_kernel": (12 * K, "int32 coordinates in"),
     "morton_key_kernel": (20 * K, "int32 x3 in, 64-bit key out, all shells"),
     "radix_hist_kernel": (8 * K, "keys in (digit histogram)"),
@@ -20,7 +23,7 @@ B = {   # kernel name fragment -> (bytes per call, what moves)
     "tree_segrank_kernel": (8 * K, "sorted keys in"),
     "tree_write_kernel": (8 * K + 22 * N, "sorted keys in, node tables out"),
     "tree_occ_kernel": (10 * N, "octant / parent in, occupancy out"),
-    "ctx_ehem_kernel": (int(37 * N / (S * FB)), "ancestor gathers in, 12 B context + 12 B position + 1 B symbol out, one segment"),
+    "ctx_ehem_kernel(": (int(37 * N / (S * FB)), "ancestor gathers in, 12 B context + 12 B position + 1 B symbol out, one segment"),
 }
 rows = list(csv.DictReader(open(f)))
 print("| kernel | calls / frame | avg µs | algorithmic MB / call | achieved GB/s | moves |")
@@ -28,7 +31,7 @@ print("|---|---|---|---|---|---|")
 tot_t = tot_b = 0.0
 for r in rows:
     for k, (b, what) in B.items():
-        if k in r["Name"]:
+        if r["Name"].startswith(k):
             us = float(r["AverageNs"]) / 1e3
             calls = int(r["Calls"]) / nf
             print(f"| `{k}` | {calls:.0f} | {us:.1f} | {b / 1e6:.2f} | {b / us / 1e3:.0f} | {what} |")
@@ -44,4 +47,4 @@ print()
 unit = "build of %d frames" % FB if FB > 1 else "frame"
 print(f"Sum over the listed kernels: {tot_t / 1e3:.2f} ms of kernel time per {unit}, {tot_b / 1e6:.0f} MB moved = {tot_b / tot_t / 1e3:.0f} GB/s "
       f"({100 * tot_b / tot_t / 1e3 / 8000:.1f} % of 8 TB/s).  SURVEY.md 8d's algorithmic figure for the whole stage is 12 P + 25 N = "
-      f"{(12 * P * S * FB + 25 * N) / 1e6:.1f} MB per {unit}.")
+      f"{(12 * P * FB + 25 * N) / 1e6:.1f} MB per {unit}: bytes moved / algorithmic = {tot_b / (12 * P * FB + 25 * N):.1f}.")
