@@ -429,11 +429,14 @@ SCP_API int scp_packed_plan(const int64_t *lengths, int32_t W, int64_t *tables_d
  *                        16 columns, columns 4-7 and 8-11 change places (the order in which an MFMA accumulator holds a row's
  *                        channels); b1 = fc1 bias + W1 beta.
  * Results are per row: independent of M, of the row's position and of what else is in the launch.
- * ---------------------------------------------------------------------------------------------- */
+ * ----------------------------------------------------------------------------------------------  * tile_list (device int32 [n_tiles], ascending; may be NULL = every tile): the 128-row tiles to process.  The packed forward passes the
+ * tiles that hold at least one real row: tiles of nothing but window padding (4.7 % of a level-16 multi-level frame) keep their old
+ * contents - run it in place (out == x) so that these stay finite. */
 SCP_API int scp_swin_ln_linear(const float *x, int64_t ldx, const float *valid, const void *Whi, const void *Wlo, const float *bias,
                                const float *wbeta, float eps, float *out, int64_t ldo, int32_t M, int32_t N, void *stream);
 SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int64_t ldo_in, const float *x, int64_t ldx, const void *W, const float *bp,
-                               const float *b1, const float *b2, float eps, float *out, int64_t ldc, int32_t M, void *stream);
+                               const float *b1, const float *b2, float eps, float *out, int64_t ldc, int32_t M, const int32_t *tile_list,
+                               int32_t n_tiles, void *stream);
 SCP_API int64_t scp_swin_post_attn_weight_bytes(void);
 
 /* SwinPatchMerging (swin_transformer.py:350-384) in one launch: out[m] = LayerNorm(cat(x[ia[m]], x[ib[m]])) . W^T for M merged rows (the
@@ -466,13 +469,14 @@ SCP_API int scp_geo_edge_mlps(const float *pos1, int64_t ld1, const float *pos2,
  *   scp_swin_ln_qkv                 : scp_swin_ln_linear for N = 768 (query | key | value; q fp32 [M][ldq]) or N = 512 (key | value, q NULL)
  *                                     writing the key / value heads as planes straight from the accumulators (M % 128 == 0, Tp >= M)
  *   scp_swin_attention_packed_planes: scp_swin_attention_packed(_split) on (q fp32, planes); out fp32 [rows][256] or ohi / olo planes
- * All three give the bits of the fp32 hand-over (scp_swin_ln_linear + scp_swin_attention_packed). */
+ * All three give the bits of the fp32 hand-over (scp_swin_ln_linear + scp_swin_attention_packed).  * valid (device fp32 [rows], may be NULL): 1 for real rows, 0 for window padding - a query tile (128 aligned rows) whose first row is
+ * padding is skipped and its output rows are not written. */
 SCP_API int scp_swin_kv_planes(const float *k, const float *v, int64_t ldkv, int64_t rows, void *khi, void *klo, void *vthi, void *vtlo, void *stream);
 SCP_API int scp_swin_ln_qkv(const float *x, int64_t ldx, const float *valid, const void *Whi, const void *Wlo, const float *bias, const float *wbeta,
                             float eps, float *q, int64_t ldq, void *planes, int64_t Tp, int32_t M, int32_t N, void *stream);
 SCP_API int scp_swin_attention_packed_planes(const float *q, const void *khi, const void *klo, const void *vthi, const void *vtlo,
                                              const float *bias_table, const int32_t *wtab, int32_t total_windows, int32_t shift, int32_t ldq,
-                                             float *out, void *ohi, void *olo, int64_t ldo, void *stream);
+                                             float *out, void *ohi, void *olo, int64_t ldo, const float *valid, void *stream);
 
 #ifdef __cplusplus
 }

@@ -574,6 +574,7 @@ struct RcPostArgs {
     float eps;
     unsigned long long *dbg;
     int dbg_mode;                               // SCP_RC_DUMP: 1 = write the normalised rows instead of the result, 2 = mean / rstd in columns 0, 1
+    const int32_t *tile_list; int n_list;       // optional: the 128-row tiles to process, ascending (others - tiles of nothing but window padding - are left alone)
 };
 
 #define RC_W_PROJ 0
@@ -751,8 +752,12 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
     for (int i = threadIdx.x; i < 256; i += 256) { sbp[i] = a.bp[i]; sb2[i] = a.b2[i]; }
     for (int i = threadIdx.x; i < 1024; i += 256) sb1[i] = a.b1[i];
     __syncthreads();
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    // tile sequence of this workgroup: every gridDim.x-th entry of the tile list (all tiles without a list)
+    const int nlist = a.tile_list ? a.n_list : ntiles;
+    auto tile_of = [&](int i) { return a.tile_list ? a.tile_list[i] : i; };
+    int ti = blockIdx.x;
+    if (ti >= nlist) return;
+    int tile = tile_of(ti);
     char *bounce = smem + RC_OFF_BOUNCE + L.w * RC_BOUNCE;
     const int ldc_bytes = (int)(a.ldc * 4);
     const int voff = (32 * L.w + (L.lane >> 3)) * ldc_bytes + (L.lane & 7) * 16;
@@ -821,9 +826,11 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
         RC_DS_READ4_WAIT(A[0][1], f.r0, 16384, A[0][3], f.r0, RC_SLOT + 16384, A[0][0], f.r0, 0, A[0][2], f.r0, RC_SLOT);
     }
     int gstep = 0;
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; ti < nlist; ti += gridDim.x) {
+        tile = tile_of(ti);
         const int m0 = tile * RC_ROWS;
-        const bool more = tile + (int)gridDim.x < ntiles;
+        const bool more = ti + (int)gridDim.x < nlist;
+        const int tile_next = more ? tile_of(ti + (int)gridDim.x) : tile;
         rf32x16 Y[8];
         // ---- phase 0: x1 = x + bp + proj(attention rows): four steps of two 32-channel blocks (ONE copy of the step's code; the unrolled
         // form that accumulates straight into Y[2 j], Y[2 j + 1] is 680 instructions longer and no faster).  The residual
@@ -971,7 +978,7 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
         // MFMA gap of slices 8 - 15 with the barrier leaving them in flight, they cost 7.5 k more: 159.4 k.)
         load_bias(31);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        load_o(more ? tile + (int)gridDim.x : tile);
+        load_o(tile_next);
         rc_body_step<false, true, 0>(L, smem, gstep & 1, Y, a1[0], a1[1], bg, Hh[0], Hl[0], Hnh, Hnl, Bh, Bl, A, wr, src_2(31), src_2(31));
         ++gstep;
         // body 31: P2 only; the step after it is phase 0 of the next tile
@@ -1347,8 +1354,9 @@ extern "C" SCP_API int scp_swin_ln_qkv(const float *x, int64_t ldx, const float 
 // W2[:, rc_perm16] [256][1024]; rc_perm16: inside every group of 16 columns, columns 4 - 7 and 8 - 11 change places.  b1 = the fc1 bias
 // + W1 beta (the LayerNorm affine folded in).
 extern "C" SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int64_t ldo_in, const float *x, int64_t ldx, const void *W, const float *bp,
-                                          const float *b1, const float *b2, float eps, float *out, int64_t ldc, int32_t M, void *stream) {
-    if (!Ohi || !Olo || !x || !W || !bp || !b1 || !b2 || !out || M <= 0 || ldo_in < 256 || (ldo_in & 7) || ldx < 256 || (ldx & 3) || ldc < 256 ||
+                                          const float *b1, const float *b2, float eps, float *out, int64_t ldc, int32_t M, const int32_t *tile_list,
+                                          int32_t n_tiles, void *stream) {
+    if (!Ohi || !Olo || !x || !W || !bp || !b1 || !b2 || !out || M <= 0 || (tile_list && (n_tiles <= 0 || n_tiles > (M + RC_ROWS - 1) / RC_ROWS)) || ldo_in < 256 || (ldo_in & 7) || ldx < 256 || (ldx & 3) || ldc < 256 ||
         (ldc & 3) || (((uintptr_t)Ohi | (uintptr_t)Olo | (uintptr_t)x | (uintptr_t)out | (uintptr_t)W) & 15) ||
         (int64_t)RC_ROWS * ldc * 4 > 0x7fffffffLL)
         return SCP_EINVAL;
@@ -1362,9 +1370,11 @@ extern "C" SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int6
     a.bp = bp; a.b1 = b1; a.b2 = b2; a.out = out; a.ldc = ldc; a.M = M; a.eps = eps;
     a.dbg = g_rc_dbg;
     { const char *e = getenv("SCP_RC_DUMP"); a.dbg_mode = e ? atoi(e) : 0; }
-    const int ntiles = (M + RC_ROWS - 1) / RC_ROWS;
+    a.tile_list = tile_list; a.n_list = tile_list ? n_tiles : 0;
+    const int ntiles = tile_list ? n_tiles : (M + RC_ROWS - 1) / RC_ROWS;
     const int ncu = rc_num_cu();
-    SCP_PROF(SCP_PROF_POST_ATTN, stream, 2.0 * M * (256.0 * 256.0 + 2.0 * 256.0 * 1024.0));
+    // algorithmic work: the rows of the tiles processed (a tile list leaves out tiles of nothing but window padding)
+    SCP_PROF(SCP_PROF_POST_ATTN, stream, 2.0 * (tile_list ? (double)n_tiles * RC_ROWS : (double)M) * (256.0 * 256.0 + 2.0 * 256.0 * 1024.0));
     hipLaunchKernelGGL(rc_post_attn_kernel, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;

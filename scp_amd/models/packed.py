@@ -157,8 +157,10 @@ def _rowchain_weights(layer, cross):
     return derived(layer, "rowchain+" if cross else "rowchain", srcs, build)
 
 
-def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None):
-    """The same block on two row-chain launches around the attention kernel."""
+def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None, tiles=None):
+    """The same block on two row-chain launches around the attention kernel.  With `tiles` (the 128-row tiles that hold a real row) the
+    block's second half runs IN PLACE on those tiles only and the attention skips the query tiles of pure window padding: their rows
+    keep finite old values, which is all the next block needs (it multiplies their normalised rows by valid = 0)."""
     att = layer.attention.self
     cross = query is not None
     w = _rowchain_weights(layer, cross)
@@ -171,7 +173,9 @@ def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None):
         else:
             q = native.swin_ln_linear(query, w["q"], att.query.bias, lnb.eps, v1)
             _, kvp = native.swin_ln_qkv(x, w["kv"], w["b"], lnb.eps, v1)
-        o = native.swin_attention_packed_planes(q, kvp, att.relative_position_bias_table, wtab, shift, split=True)
+        o = native.swin_attention_packed_planes(q, kvp, att.relative_position_bias_table, wtab, shift, split=True, valid=v1 if tiles is not None else None)
+        if tiles is not None and tiles.shape[0] > 0:
+            return native.swin_post_attn(o, x, w["post"], layer.layernorm_after.eps, out=x, tiles=tiles)
         return native.swin_post_attn(o, x, w["post"], layer.layernorm_after.eps)
     # numeric profile "attention = fp32 MFMA" (scp_ctx): the fp32-fed attention kernel takes q, k, v as rows
     if not cross:
@@ -185,13 +189,13 @@ def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None):
     return native.swin_post_attn(o, x, w["post"], layer.layernorm_after.eps)
 
 
-def _swin_layer(layer, x, valid, wtab, shift, query=None):
+def _swin_layer(layer, x, valid, wtab, shift, query=None, tiles=None):
     """swin_transformer.py:654-706 on a packed layout (rows beyond a window's length are don't-care, except that the
     LayerNorm output is zeroed there - the reference zero-pads AFTER LayerNorm): two row-chain launches around the attention kernel."""
     fc1, fc2 = layer.intermediate.dense, layer.output.dense
     if x.shape[1] != 256 or fc1.weight.shape != (1024, 256) or fc2.weight.shape != (256, 1024):
         raise native.ScpError("EHEM's Swin blocks are 256 wide with a 1024-wide MLP (configs/model/ehem.yaml); other widths are not built")
-    return _swin_layer_rowchain(layer, x, valid, wtab, shift, query)
+    return _swin_layer_rowchain(layer, x, valid, wtab, shift, query, tiles)
 
 
 def _merge(m, x, maps):
@@ -204,11 +208,11 @@ def _merge(m, x, maps):
     return native.swin_merge(x, ev, od, mw, m.norm.eps)
 
 
-def _encoder(enc, x, valids, tabs, merges, query=None):
+def _encoder(enc, x, valids, tabs, merges, query=None, tiles=None):
     hs = [x]
     for s, stage in enumerate(enc.layers):
         for b, blk in enumerate(stage.blocks):
-            x = _swin_layer(blk, x, valids[s], tabs[s], SHIFT if b % 2 else 0, query)
+            x = _swin_layer(blk, x, valids[s], tabs[s], SHIFT if b % 2 else 0, query, None if tiles is None else tiles[s])
         hs.append(x)
         if s < len(enc.layers) - 1:
             x = _merge(stage.downsample, x, merges[s])
@@ -313,7 +317,7 @@ def ehem_phase1_packed(model, ctx, pos, plan, table=None):
                  [l.bias for l in (g.edge_mlp1[0], g.edge_mlp1[2], g.edge_mlp1[4], g.edge_mlp2[0], g.edge_mlp2[2], g.edge_mlp2[4])],
                  lambda: native.EdgeMlpWeights(g.edge_mlp1, g.edge_mlp2))
     native.geo_edge_mlps(pos1, pos2, pos3, ew, feat[:, nx:])
-    hs = _encoder(model.swin_self_transformer, feat, d["self_valid"], d["self_tab"], d["self_merge"])
+    hs = _encoder(model.swin_self_transformer, feat, d["self_valid"], d["self_tab"], d["self_merge"], tiles=d.get("self_tiles"))
     feat_a = _mlp_over_concat(model.ancient_mlp, hs, d["self_parent"]) if HIER else leaky_mlp3_s(model.ancient_mlp, _concat(hs, d["self_concat"]))
     Q0 = d["a1map"].shape[0]
     a1 = native.split_rows(feat_a, idx=d["a1map"])
@@ -339,7 +343,7 @@ def ehem_phase2_packed(model, st, plan, pre_occ=None, table=None):
     pre = torch.empty((a2.shape[0], no + model.pre_attn_mlp[4].weight.shape[0]), dtype=torch.float32, device=a2.device)
     pre[:, :no] = occ_feat
     leaky_mlp3_s(model.pre_attn_mlp, a1, out=pre[:, no:])
-    hc = _encoder(model.swin_cross_transformer, pre, d["cross_valid"], d["cross_tab"], d["cross_merge"], query=a2)
+    hc = _encoder(model.swin_cross_transformer, pre, d["cross_valid"], d["cross_tab"], d["cross_merge"], query=a2, tiles=d.get("cross_tiles"))
     if table is not None:
         a = _concat_layer(model.prob_pred_mlp2[0], hc, d["cross_parent"], a2) if HIER else linear_s(_concat(hc, d["cross_concat"], extra=(a2, None)), model.prob_pred_mlp2[0].weight, model.prob_pred_mlp2[0].bias, act="leaky", want="split")
         from ..ops import _split

@@ -61,7 +61,7 @@ def lib():
         "scp_swin_merge": (C.c_int, [_vp, i64, i64, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, _vp]),
         "scp_swin_ln_qkv": (C.c_int, [_vp, i64, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, _vp, i64, i32, i32, _vp]),
         "scp_swin_kv_planes": (C.c_int, [_vp, _vp, i64, i64, _vp, _vp, _vp, _vp, _vp]),
-        "scp_swin_attention_packed_planes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, i32, i32, i32, _vp, _vp, _vp, i64, _vp]),
+        "scp_swin_attention_packed_planes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, i32, i32, i32, _vp, _vp, _vp, i64, _vp, _vp]),
         "scp_split_rows_f16": (C.c_int, [_vp, i64, i32, i32, _vp, _vp, i64, _vp, _vp, _vp]),
         "scp_linear_split_f16": (C.c_int, [_vp, _vp, i64, _vp, _vp, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_last_hip_error": (C.c_int, []),
@@ -119,7 +119,7 @@ def lib():
         "scp_linear_split": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_tile_weight_bf16": (C.c_int, [_vp, i32, i32, _vp, _vp]),
         "scp_swin_ln_linear": (C.c_int, [_vp, i64, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, i32, _vp]),
-        "scp_swin_post_attn": (C.c_int, [_vp, _vp, i64, _vp, i64, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, _vp]),
+        "scp_swin_post_attn": (C.c_int, [_vp, _vp, i64, _vp, i64, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, _vp, i32, _vp]),
         "scp_swin_post_attn_weight_bytes": (C.c_int64, []),
         "scp_split_rows": (C.c_int, [_vp, i64, i64, _vp, i32, _vp, _vp, i64, i64, _vp]),
         "scp_linear_split_scatter": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
@@ -407,21 +407,23 @@ class KvPlanes:
         self.t = t
 
 
-def swin_attention_packed_planes(q, kv, bias_table, wtab, shift, split=False):
-    """swin_attention_packed with K / V as KvPlanes: operands staged by LDS-DMA, no conversion in the kernel; identical bits."""
+def swin_attention_packed_planes(q, kv, bias_table, wtab, shift, split=False, valid=None):
+    """swin_attention_packed with K / V as KvPlanes: operands staged by LDS-DMA, no conversion in the kernel; identical bits.
+    valid (fp32 [T] / [T, 1], optional): query tiles of nothing but window padding are skipped, their output rows stay unwritten."""
     T = q.shape[0]
     p = kv.t
+    vp = None if valid is None else _dev(valid, torch.float32)
     if split:
         o = SplitAct.empty(T, 256, q.device)
         rc = lib().scp_swin_attention_packed_planes(q.data_ptr(), p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr(), p[3].data_ptr(),
                                                     _dev(bias_table, torch.float32), _dev(wtab, torch.int32), T // 512, shift, q.stride(0), None,
-                                                    o.t[0].data_ptr(), o.t[1].data_ptr(), o.t.stride(1), _stream())
+                                                    o.t[0].data_ptr(), o.t[1].data_ptr(), o.t.stride(1), vp, _stream())
         _check(rc, "scp_swin_attention_packed_planes")
         return o
     out = torch.empty((T, 256), dtype=torch.float32, device=q.device)
     rc = lib().scp_swin_attention_packed_planes(q.data_ptr(), p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr(), p[3].data_ptr(),
                                                 _dev(bias_table, torch.float32), _dev(wtab, torch.int32), T // 512, shift, q.stride(0), _dev(out), None,
-                                                None, 0, _stream())
+                                                None, 0, vp, _stream())
     _check(rc, "scp_swin_attention_packed_planes")
     return out
 
@@ -487,7 +489,34 @@ def packed_plan(lengths, device):
              self_valid=[t[f"valid{l}"] for l in range(5)], cross_valid=[t[f"valid{l}"] for l in range(5, 9)],
              self_parent=[t[f"sp{s_}"] for s_ in range(4)], cross_parent=[t[f"cp{s_}"] for s_ in range(3)],
              even_out=t["even_out"], odd_out=t["odd_out"])
+    d["self_tiles"], d["cross_tiles"] = real_tiles(c, device)
     return r, d
+
+
+def real_tiles(lengths, device, n_self=5, n_cross=4):
+    """Per Swin stage of the packed layout the 128-row tiles that hold at least one real row (int32 device tensors, ascending): host
+    arithmetic on the list of window lengths (a window's real rows are a prefix of its 512-aligned run), ONE host -> device copy.  The
+    row-chain block kernel walks this list instead of every tile; tiles of nothing but window padding are 4.7 % of an L16-m frame."""
+    import numpy as np
+    c = np.asarray(lengths, np.int64)
+    e = c + (c & 1)
+
+    def lists(L, n):
+        out = []
+        for _ in range(n):
+            Lp = -(-L // 512) * 512
+            base = np.cumsum(Lp) - Lp
+            nt = -(-L // 128)
+            first = np.repeat(base // 128, nt)
+            within = np.arange(int(nt.sum())) - np.repeat(np.cumsum(nt) - nt, nt)
+            out.append((first + within).astype(np.int32))
+            L = (L + 1) // 2
+        return out
+    parts = lists(e, n_self) + lists(e // 2, n_cross)
+    flat = torch.from_numpy(np.concatenate(parts)).to(device, non_blocking=True)
+    cuts = np.cumsum([0] + [len(p) for p in parts])
+    views = [flat[cuts[i]:cuts[i + 1]] for i in range(len(parts))]
+    return views[:n_self], views[n_self:]
 
 
 def edge_gather_max_rows(u, v, idx, scale, shift):
@@ -1096,9 +1125,10 @@ class PostAttnWeights:
         note_cache_fill()
 
 
-def swin_post_attn(o, x, pw, eps=1e-5, out=None):
+def swin_post_attn(o, x, pw, eps=1e-5, out=None, tiles=None):
     """x + proj(o) -> LayerNorm -> fc1 -> GELU -> fc2 -> + residual, one launch (csrc/rowchain.hip).  o: SplitAct [M, 256] (the attention
-    output planes), x: fp32 [M, 256] residual stream, pw: PostAttnWeights.  -> fp32 [M, 256] (`out` may be x itself)."""
+    output planes), x: fp32 [M, 256] residual stream, pw: PostAttnWeights.  -> fp32 [M, 256] (`out` may be x itself).
+    tiles (int32 device tensor, optional): the 128-row tiles to process (ascending); the others keep what `out` held (use out=x)."""
     M = x.shape[0]
     if o.K != 256 or o.M != M or x.shape[1] != 256 or x.stride(1) != 1:
         raise ScpError("swin_post_attn: [M, 256] operands expected")
@@ -1106,7 +1136,8 @@ def swin_post_attn(o, x, pw, eps=1e-5, out=None):
         out = torch.empty((M, 256), dtype=torch.float32, device=x.device)
     t = o.t
     rc = lib().scp_swin_post_attn(t[0].data_ptr(), t[1].data_ptr(), t.stride(1), x.data_ptr(), x.stride(0), pw.packed.data_ptr(), _dev(pw.bp),
-                                  _dev(pw.b1), _dev(pw.b2), float(eps), out.data_ptr(), out.stride(0), M, _stream())
+                                  _dev(pw.b1), _dev(pw.b2), float(eps), out.data_ptr(), out.stride(0), M,
+                                  None if tiles is None else _dev(tiles, torch.int32), 0 if tiles is None else int(tiles.shape[0]), _stream())
     _check(rc, "scp_swin_post_attn")
     return out
 

@@ -1368,3 +1368,48 @@ def test_octattn_embed_kernel_equals_the_torch_input_stage(dev, B, c, obj):
     assert torch.equal(E.reshape(want.shape), want)
     ref = native.SplitActF16(want.reshape(-1, want.shape[-1]).contiguous())
     assert torch.equal(pa.hi, ref.hi) and torch.equal(pa.lo, ref.lo) and torch.equal(pa.sc, ref.sc) and torch.equal(pa.isc, ref.isc)
+
+
+@pytest.mark.gpu
+def test_pad_tiles_are_skipped_and_real_rows_keep_their_bits(dev):
+    """Round 4: the block's second half (scp_swin_post_attn) walks a list of the 128-row tiles that hold a real row and the plane-fed
+    attention leaves query tiles of pure window padding: the listed tiles get exactly the bits of a full run, the others are not touched."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *sh, s=1.0: (torch.randn(sh, generator=g) * s).to(dev)
+    lengths = [700, 3, 1030, 512, 129]
+    st, _ = native.real_tiles(lengths, dev)
+    tiles = st[0]
+    Lp = [-(-(c + (c & 1)) // 512) * 512 for c in lengths]
+    M = sum(Lp)
+    valid = torch.zeros(M, device=dev)
+    base = 0
+    for c, lp in zip(lengths, Lp):
+        valid[base:base + c + (c & 1)] = 1.0
+        base += lp
+    assert tiles.shape[0] < M // 128
+    x, o = rn(M, 256), rn(M, 256)
+    pw = native.PostAttnWeights(rn(256, 256, s=0.05), rn(256, s=0.1), 1 + rn(256, s=0.1), rn(256, s=0.1), rn(1024, 256, s=0.05), rn(1024, s=0.1),
+                                rn(256, 1024, s=0.03), rn(256, s=0.1))
+    osp = native.split_rows(o)
+    full = native.swin_post_attn(osp, x, pw)
+    xc = x.clone()
+    got = native.swin_post_attn(osp, xc, pw, out=xc, tiles=tiles)
+    listed = torch.zeros(M // 128, dtype=torch.bool, device=dev)
+    listed[tiles.long()] = True
+    rows = listed.repeat_interleave(128)
+    assert torch.equal(got[rows], full[rows]) and torch.equal(got[~rows], x[~rows])
+    assert bool((valid[~rows] == 0).all())                                    # nothing real was left out
+    # attention: the same tiles, shifted and unshifted windows
+    qkv = rn(M, 768, s=2.0)
+    table = rn(1023, 4, s=0.5)
+    wtab, b = [], 0
+    for lp in Lp:
+        wtab += [[b, lp]] * (lp // 512)
+        b += lp
+    wtab = torch.tensor(wtab, dtype=torch.int32, device=dev)
+    kv = native.KvPlanes(qkv[:, 256:512], qkv[:, 512:])
+    for shift in (0, 256):
+        a = native.swin_attention_packed_planes(qkv[:, :256], kv, table, wtab, shift)
+        bb = native.swin_attention_packed_planes(qkv[:, :256], kv, table, wtab, shift, valid=valid)
+        assert torch.equal(a[rows], bb[rows])

@@ -266,3 +266,21 @@ def test_frame_flop_formula_matches_the_survey():
     assert abs(b.ehem_window_flops(8192) / 1e9 - 310.2) < 0.1 and abs(b.ehem_window_flops(8192, True) / 1e9 - 40.0) < 0.05
     assert abs(b.octattn_window_flops(1024) / 1e9 - 27.9) < 0.1 and abs(b.octattn_window_flops(1024, True) / 1e9 - 11.3) < 0.05
     assert b.ehem_window_flops(1) == b.ehem_window_flops(2) and b.ehem_window_flops(600) < b.ehem_window_flops(1024)
+
+
+@pytest.mark.parametrize("lengths", [[1], [1, 6, 20, 56, 208, 1372, 5605, 8192, 4938, 7, 2, 513], [8192, 8192], [3, 3, 3], [129, 257, 1025]])
+def test_real_tile_lists_match_the_valid_masks(lengths):
+    """native.real_tiles (host arithmetic on the window lengths) lists exactly the 128-row tiles of every Swin stage whose first row is a
+    real row of the packed layout - what the valid masks of the plan say; every other tile is pure window padding."""
+    from scp_amd import native
+    from scp_amd.models.packed import PackedPlan
+    p = PackedPlan(lengths, device=torch.device("cpu"))
+    st, ct = native.real_tiles(lengths, torch.device("cpu"))
+    assert len(st) == 5 and len(ct) == 4
+    for tiles, valid in list(zip(st, p.d["self_valid"])) + list(zip(ct, p.d["cross_valid"])):
+        v = valid.reshape(-1)
+        want = torch.nonzero(v[::128]).reshape(-1).to(torch.int32)
+        assert torch.equal(tiles, want)
+        # a tile is either listed or holds no real row at all
+        allpad = v.reshape(-1, 128).sum(1) == 0
+        assert torch.equal(torch.nonzero(~allpad).reshape(-1).to(torch.int32), tiles)
