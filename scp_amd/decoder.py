@@ -128,6 +128,34 @@ class FrameDecoder:
         self.polar = polar            # spherical / cylindrical: positions normalised with the .dat (min, max) pairs
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.context_size = model.cfg.model.context_size
+        self.stats = None             # set to {} to collect wall seconds per stage (adds a device synchronisation per stamp: bench.py --decode)
+        self._plans = {}              # one-window plans by window length (index maps depend on the length only): built once, reused
+
+    def _stamp(self, key, t0):
+        if self.stats is None:
+            return t0
+        import time
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        self.stats[key] = self.stats.get(key, 0.0) + (t - t0)
+        return t
+
+    def _t0(self):
+        if self.stats is None:
+            return 0.0
+        import time
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    def _plan1(self, c):
+        """The packed plan of ONE window of c nodes (cached: a frame has 55 windows of 8192 nodes and the plan is a function of c alone)."""
+        from .models.packed import PackedPlan
+        p = self._plans.get(c)
+        if p is None:
+            if len(self._plans) > 64:
+                self._plans.clear()
+            p = self._plans[c] = PackedPlan([c], device=self.device)
+        return p
 
     def _decode_window(self, dec, ctx, pos):
         """ctx uint8 [c,12] (own occupancy = 255 placeholder), pos f32 [c,3] -> int64 symbols [c] (device).
@@ -135,19 +163,27 @@ class FrameDecoder:
         integer CDFs, and every kernel on the path is deterministic per row / per window, independent of the batch."""
         from .models.packed import PackedPlan, ehem_phase1_packed, ehem_phase2_packed
         c = ctx.shape[0]
-        plan = PackedPlan([c], device=self.device)
+        t = self._t0()
+        plan = self._plan1(c)
         prob1, st = ehem_phase1_packed(self.model, ctx, pos, plan)
+        t = self._stamp("phase1_model", t)
         cdf = native.softmax_cdf(prob1.contiguous(), want_lohi=False, want_cdf=True)["cdf"].cpu().numpy()
+        t = self._stamp("cdf_d2h", t)
         even = torch.from_numpy(dec.run(cdf).astype(np.int64)).to(self.device)
+        t = self._stamp("range_decoder", t)
         sym = torch.empty(c, dtype=torch.int64, device=self.device)
         sym[0::2] = even
         if c > 1:
             Q0 = plan.d["a1map"].shape[0]
             po = torch.zeros(Q0, dtype=torch.int64, device=self.device)
             po[:even.shape[0]] = even                       # one window: its real rows are the first rows of the cross layout
+            t = self._stamp("index_ops", t)
             prob2 = ehem_phase2_packed(self.model, st, plan, po)
+            t = self._stamp("phase2_model", t)
             cdf = native.softmax_cdf(prob2.contiguous(), want_lohi=False, want_cdf=True)["cdf"].cpu().numpy()
+            t = self._stamp("cdf_d2h", t)
             sym[1::2] = torch.from_numpy(dec.run(cdf).astype(np.int64)).to(self.device)
+            t = self._stamp("range_decoder", t)
         return sym
 
     def _decode_level(self, dec, ctx, pos):
@@ -162,25 +198,33 @@ class FrameDecoder:
         lengths = [min(cs, n - i) for i in range(0, n, cs)]
         if len(lengths) == 1:
             return self._decode_window(dec, ctx, pos)
+        t = self._t0()
         plan = PackedPlan(lengths, device=self.device)
         prob1, st = ehem_phase1_packed(self.model, ctx, pos, plan)
+        t = self._stamp("phase1_model", t)
         cdf1 = native.softmax_cdf(prob1.contiguous(), want_lohi=False, want_cdf=True)["cdf"].cpu().numpy()
+        t = self._stamp("cdf_d2h", t)
         sym = torch.empty(n, dtype=torch.int64, device=self.device)
         row0 = e0 = q0 = 0
         for c in lengths:
             ne = (c + 1) // 2
             qp = -(-((c + (c & 1)) // 2) // 512) * 512                     # cross-layout rows of this window (padded to 512)
             even = torch.from_numpy(dec.run(cdf1[e0:e0 + ne]).astype(np.int64)).to(self.device)
+            t = self._stamp("range_decoder", t)
             sym[row0:row0 + c:2] = even
             if c > 1:
-                pw = PackedPlan([c], device=self.device)
+                pw = self._plan1(c)
                 stw = dict(a1=native.SplitAct(st["a1"].t[:, q0:q0 + qp], st["a1"].K), a2=st["a2"][q0:q0 + qp],
                            pre_occ=st["pre_occ"][q0:q0 + qp])
                 po = torch.zeros(qp, dtype=torch.int64, device=self.device)
                 po[:ne] = even
+                t = self._stamp("index_ops", t)
                 prob2 = ehem_phase2_packed(self.model, stw, pw, po)
+                t = self._stamp("phase2_model", t)
                 cdf = native.softmax_cdf(prob2.contiguous(), want_lohi=False, want_cdf=True)["cdf"].cpu().numpy()
+                t = self._stamp("cdf_d2h", t)
                 sym[row0 + 1:row0 + c:2] = torch.from_numpy(dec.run(cdf).astype(np.int64)).to(self.device)
+                t = self._stamp("range_decoder", t)
             row0 += c
             e0 += ne
             q0 += qp
@@ -212,8 +256,10 @@ class FrameDecoder:
                 posn = (pos.double() / float(2 ** depth)).float()
             rows = n - (1 if (self.mullevel and last) else 0)                  # the dropped last node is never coded
             sym = torch.full((n,), -1, dtype=torch.int64, device=dev)
+            t = self._stamp("tree_expansion", t) if L > 1 else self._t0()
             if rows > 0:
                 sym[:rows] = self._decode_level(dec, ctx[:rows].contiguous(), posn[:rows].contiguous())
+            t = self._t0()
             occ = sym + 1                                                       # 1..255; 0 = unknown (dropped node)
             codes.append(occ.to(torch.uint8))
             # children in (parent, digit) order
