@@ -327,8 +327,9 @@ SCP_API int scp_octattn_attention(const float *q_u, const float *k, const float 
  * (device memory, 1 KiB aligned, scp_octattn_f16x3_ws_bytes(B, c, H) bytes).  q_u, k, v must be 16-byte aligned. */
 SCP_API int64_t scp_octattn_f16x3_ws_bytes(int32_t B, int32_t c, int32_t H);
 SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
-                                        int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *workspace,
-                                        int64_t ws_bytes, void *stream);
+                                        int64_t ldkv, int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *workspace,
+                                        int64_t ws_bytes, void *stream);   /* ldkv: row stride (floats) of k, k_u, v, v_u - H * hd for dense
+                                        rows, 1280 when they are column slices of one key | value projection (round 4); q_u, out, out_u dense */
 /* OctAttention's input stage in one launch (oct_attention.py:48-66): embeddings of the four ancestors + Linear(3 -> d_pos) of their
  * positions, concatenated to D = 4 (d_occ + d_lvl + d_oct + d_pos) <= 768 channels, scaled by sqrt(D), plus the position table pe [c][D];
  * both streams (1 = "unknown": occ_enc[255] for the node's own occupancy).  ctx uint8 [n][12] = (occ, level, octant) x 4, pos fp32

@@ -378,9 +378,21 @@ __global__ __launch_bounds__(WG) void tree_occ_kernel(const SegTab *__restrict__
         uint32_t o = 0;
         for (int64_t c = c0; c < c1; ++c) o |= 1u << (src[c] - 1);
         occ[nd] = (uint8_t)o;
-        if (!(s.drop_last && r == s.n_nodes - 1)) {
+        // per-level (min, max) of the node origins.  Nodes are in BFS order, so the 64 nodes of a wavefront nearly always share one level:
+        // then the wave reduces by shuffles and ONE lane touches the LDS slot (256 same-address LDS atomics per workgroup pass used to
+        // serialise: 44 us for the 577 k nodes of an L16-m frame, the slowest kernel of the stage)
+        const bool counts = !(s.drop_last && r == s.n_nodes - 1);
+        int32_t mn = INT32_MAX, mx = INT32_MIN;
+        if (counts) {
             const int32_t a = pos[3 * nd], b = pos[3 * nd + 1], cc = pos[3 * nd + 2];
-            const int32_t mn = min(a, min(b, cc)), mx = max(a, max(b, cc));
+            mn = min(a, min(b, cc)); mx = max(a, max(b, cc));
+        }
+        const int L0 = __builtin_amdgcn_readfirstlane(L);
+        if (__ballot(L != L0) == 0ull && __ballot(1) == ~0ull) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o)); mx = max(mx, __shfl_xor(mx, o)); }
+            if ((threadIdx.x & 63) == 0 && mn != INT32_MAX) { atomicMin(&smn[L0], mn); atomicMax(&smx[L0], mx); }
+        } else if (counts) {
             atomicMin(&smn[L], mn);
             atomicMax(&smx[L], mx);
         }

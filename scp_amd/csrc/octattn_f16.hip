@@ -49,10 +49,12 @@ __device__ __forceinline__ void oa_pow2_scale(float mx, float &sc, float &isc) {
 }
 
 // max |v| over the launch (non-negative floats order like their bit patterns)
-__global__ __launch_bounds__(256) void oa_absmax_kernel(const float *__restrict__ v, int64_t n4, unsigned *__restrict__ out) {
+__global__ __launch_bounds__(256) void oa_absmax_kernel(const float *__restrict__ v, int64_t n4, int d4 /* float4 per row */, int64_t ld,
+                                                       unsigned *__restrict__ out) {
     float mx = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const float4 x = ((const float4 *)v)[i];
+        const int64_t r = i / d4;
+        const float4 x = *(const float4 *)(v + r * ld + 4 * (i - r * d4));
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
     }
 #pragma unroll
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void oa_absmax_kernel(const float *__restrict_
 
 // workgroup = one 32-token tile of one (batch, head): thread (t = tid >> 3, s = tid & 7) walks float2 pieces s, s + 8, ... of row t
 __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ q_u, const float *__restrict__ k, const float *__restrict__ k_u,
-                                                     const float *__restrict__ v, int c, int H, int nt, const unsigned *__restrict__ vmax_bits,
+                                                     const float *__restrict__ v, int64_t ldkv, int c, int H, int nt, const unsigned *__restrict__ vmax_bits,
                                                      _Float16 *__restrict__ qp, float *__restrict__ isq, float2 *__restrict__ diag,
                                                      char *__restrict__ kimg, char *__restrict__ vimg) {
     __shared__ float vt[32][FHD + 1];
@@ -71,7 +73,8 @@ __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ 
     const int D = H * FHD, cpad = nt * 32;
     const int tok = tile * 32 + t;
     const bool real = tok < c;
-    const size_t row = ((size_t)b * c + (real ? tok : c - 1)) * D + (size_t)head * FHD;
+    const size_t row = ((size_t)b * c + (real ? tok : c - 1)) * D + (size_t)head * FHD;            // q_u: dense rows
+    const size_t rowk = ((size_t)b * c + (real ? tok : c - 1)) * (size_t)ldkv + (size_t)head * FHD;   // k, k_u, v: rows ldkv floats apart
     float vs, ivs;
     oa_pow2_scale(__uint_as_float(*vmax_bits), vs, ivs);
 
@@ -82,8 +85,8 @@ __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ 
         const int p = s + 8 * i;
         const bool ok = real && p < 75;
         const int pc = p < 75 ? p : 74;
-        const float2 a = *(const float2 *)(q_u + row + 2 * pc), bb = *(const float2 *)(k + row + 2 * pc), cc = *(const float2 *)(v + row + 2 * pc),
-                     uu = *(const float2 *)(k_u + row + 2 * pc);
+        const float2 a = *(const float2 *)(q_u + row + 2 * pc), bb = *(const float2 *)(k + rowk + 2 * pc), cc = *(const float2 *)(v + rowk + 2 * pc),
+                     uu = *(const float2 *)(k_u + rowk + 2 * pc);
         qv[i] = ok ? a : make_float2(0.f, 0.f);
         kv[i] = ok ? bb : make_float2(0.f, 0.f);
         qm = fmaxf(qm, fmaxf(fabsf(qv[i].x), fabsf(qv[i].y)));
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ 
 }
 
 __global__ __launch_bounds__(256, 2) void oa_attn_f16x3_kernel(const float *__restrict__ v,
-                                                              const float *__restrict__ v_u, int c, int H, int nt,
+                                                              const float *__restrict__ v_u, int64_t ldkv, int c, int H, int nt,
                                                               const unsigned *__restrict__ vmax_bits, const _Float16 *__restrict__ qp,
                                                               const float *__restrict__ isq, const float2 *__restrict__ diag,
                                                               const char *__restrict__ kimg,
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void oa_attn_f16x3_kernel(const float *__re
     const int head = bid % H, b = bid / H;
     const int D = H * FHD, cpad = nt * 32;
     const size_t base = (size_t)b * c * D + (size_t)head * FHD;
+    const size_t basev = (size_t)b * c * (size_t)ldkv + (size_t)head * FHD;
     const int q0 = qb * 128, qi = q0 + w * 32 + col;
     const int qc = qi < c ? qi : c - 1;
     constexpr float LOG2E = 1.4426950408889634f;
@@ -311,8 +315,8 @@ __global__ __launch_bounds__(256, 2) void oa_attn_f16x3_kernel(const float *__re
             if (qr_ < c && d < FHD) {
                 const float2 ov = *(const float2 *)(stg + ql_ * SLD + 2 * pp);
                 const float4 cf = *(const float4 *)(coef + 4 * ql_);
-                const size_t ro = base + (size_t)qr_ * D + d;
-                const float2 vv = *(const float2 *)(v + ro), vu = *(const float2 *)(v_u + ro);
+                const size_t ro = base + (size_t)qr_ * D + d, rv = basev + (size_t)qr_ * (size_t)ldkv + d;
+                const float2 vv = *(const float2 *)(v + rv), vu = *(const float2 *)(v_u + rv);
                 *(float2 *)(out + ro) = make_float2(fmaf(cf.y, vv.x, cf.x * ov.x), fmaf(cf.y, vv.y, cf.x * ov.y));
                 *(float2 *)(out_u + ro) = make_float2(fmaf(cf.w, vu.x, cf.z * ov.x), fmaf(cf.w, vu.y, cf.z * ov.y));
             }
@@ -330,9 +334,10 @@ extern "C" SCP_API int64_t scp_octattn_f16x3_ws_bytes(int32_t B, int32_t c, int3
 }
 
 extern "C" SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
-                                                   int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *workspace,
+                                                   int64_t ldkv, int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *workspace,
                                                    int64_t ws_bytes, void *stream) {
     if (!q_u || !k || !k_u || !v || !v_u || !out || !out_u || !workspace || B <= 0 || c <= 0 || c > 1024 || H <= 0 || hd != FHD || ((H * FHD) & 3) ||
+        ldkv < H * FHD || (ldkv & 3) || ((((uintptr_t)k_u | (uintptr_t)v_u) & 15) != 0) ||
         ((((uintptr_t)q_u | (uintptr_t)k | (uintptr_t)v) & 15) != 0) || ((uintptr_t)workspace & 1023) ||
         ws_bytes < scp_octattn_f16x3_ws_bytes(B, c, H))
         return SCP_EINVAL;
@@ -350,11 +355,11 @@ extern "C" SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float
     const int64_t n4 = (int64_t)B * c * H * FHD / 4;                 // 600 floats per token: a multiple of 4
     {
         SCP_PROF(SCP_PROF_OTHER, st, 0.0);             // operand preparation (planes, scales, diagonal terms)
-        hipLaunchKernelGGL(oa_absmax_kernel, dim3((unsigned)(n4 < 256 * 1024 ? (n4 + 255) / 256 : 1024)), dim3(256), 0, st, v, n4, vmax);
-        hipLaunchKernelGGL(oa_prep_kernel, dim3(B * nt, H), dim3(256), 0, st, q_u, k, k_u, v, c, H, nt, vmax, qp, isq, diag, kimg, vimg);
+        hipLaunchKernelGGL(oa_absmax_kernel, dim3((unsigned)(n4 < 256 * 1024 ? (n4 + 255) / 256 : 1024)), dim3(256), 0, st, v, n4, H * FHD / 4, ldkv, vmax);
+        hipLaunchKernelGGL(oa_prep_kernel, dim3(B * nt, H), dim3(256), 0, st, q_u, k, k_u, v, ldkv, c, H, nt, vmax, qp, isq, diag, kimg, vimg);
     }
     SCP_PROF(SCP_PROF_OA_ATTENTION, st, (double)B * 3.0 * 2.0 * c * (double)c * H * FHD);
-    hipLaunchKernelGGL(oa_attn_f16x3_kernel, dim3(B * H * ((c + 127) / 128)), dim3(256), 0, st, v, v_u, c, H, nt, vmax, qp, isq, diag,
+    hipLaunchKernelGGL(oa_attn_f16x3_kernel, dim3(B * H * ((c + 127) / 128)), dim3(256), 0, st, v, v_u, ldkv, c, H, nt, vmax, qp, isq, diag,
                        kimg, vimg, out, out_u);
     LAUNCH_CHECK();
     return SCP_OK;

@@ -1,6 +1,6 @@
 // Stable LSD radix sort of 64-bit Morton keys (gfx950, wave64).
 //
-// One pass = histogram -> exclusive scan of the [digit][tile] table -> scatter.  A tile is 4096
+// One pass = histogram -> scatter (which derives its bucket starts from the raw [digit][tile] table itself).  A tile is 4096
 // consecutive keys owned by one 256-thread workgroup; wave w of the workgroup owns the contiguous
 // quarter [w*1024, (w+1)*1024) and walks it in 16 rounds of 64 keys, so a key's stable rank inside its
 // (tile, digit) bucket is   sum over lower waves of their digit count  +  its rank inside its wave,
@@ -63,9 +63,10 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *__restrict__
 }
 
 __global__ __launch_bounds__(WG) void radix_scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                          int64_t n, int lo, int nb, const uint32_t *__restrict__ offs,
+                                                          int64_t n, int lo, int nb, const uint32_t *__restrict__ counts,
                                                           int ntiles) {
     __shared__ uint32_t wcnt[4][256];
+    __shared__ uint32_t wtot[4];
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
     const uint32_t mask = (1u << nb) - 1u;
 #pragma unroll
@@ -98,9 +99,30 @@ __global__ __launch_bounds__(WG) void radix_scatter_kernel(const uint64_t *__res
         rank[r] = prev + before;
     }
     __syncthreads();
-    // digit t: turn the four per-wave totals into start offsets (global bucket start + lower waves)
+    // digit t: global start of this tile's (digit t) bucket, straight from the RAW [digit][tile] counts (round 4: no scan kernel between
+    // the histogram and the scatter - a single-workgroup pass over 256 x tiles counters that cost 5 - 15 us per sort pass, a third of a
+    // build's kernel time; here every workgroup re-reads the table out of L2, 120 KB for a four-frame build):
+    //   start = sum over digits d' < t of (all tiles' counts of d')  +  sum over tiles t' < this one of counts[t][t']
     {
-        uint32_t g = offs[(int64_t)t * ntiles + blockIdx.x];
+        const uint32_t *row = counts + (int64_t)t * ntiles;
+        uint32_t tot = 0, pre = 0;
+        const int me = (int)blockIdx.x;
+        for (int j = 0; j < ntiles; ++j) {
+            const uint32_t v = row[j];
+            tot += v;
+            pre += j < me ? v : 0u;
+        }
+        // exclusive scan of `tot` over the 256 digits: inside a wave by shuffles, across the four waves through LDS
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t g = inc - tot + pre;
+        for (int i = 0; i < w; ++i) g += wtot[i];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint32_t c = wcnt[i][t];
@@ -147,8 +169,6 @@ int scp_radix_sort_u64(uint64_t *keys_a, uint64_t *keys_b, int64_t n, const int 
         if (nb < 1 || nb > 8) return SCP_EINVAL;
         if (!(p == 0 && first_hist_done))
             hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(WG), 0, st, src, n, lo, (1u << nb) - 1u, counts, ntiles);
-        LAUNCH_CHECK();
-        scp_launch_scan_u32(counts, (int64_t)256 * ntiles, st);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(WG), 0, st, src, dst, n, lo, nb, counts, ntiles);
         LAUNCH_CHECK();

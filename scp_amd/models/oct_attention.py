@@ -26,6 +26,20 @@ def linear(x, w, b=None, act=None, residual=None, scales=None):
     return _linear(x, w, b, act=act, residual=residual, precise=True, scales=scales)
 
 
+_KV_OFF = 640            # column of the value block inside the stacked key | value projection (600 rounded up to a multiple of 128)
+
+
+def _kv_cat(a, D):
+    """([2 * _KV_OFF, D] weight, [2 * _KV_OFF] bias) of the stacked key | value projection: rows [0, D) = key, [_KV_OFF, _KV_OFF + D) = value."""
+    w = torch.zeros((2 * _KV_OFF, D), dtype=torch.float32, device=a.mlp_key.weight.device)
+    b = torch.zeros((2 * _KV_OFF,), dtype=torch.float32, device=w.device)
+    w[:D] = a.mlp_key.weight.detach()
+    w[_KV_OFF:_KV_OFF + D] = a.mlp_value.weight.detach()
+    b[:D] = a.mlp_key.bias.detach()
+    b[_KV_OFF:_KV_OFF + D] = a.mlp_value.bias.detach()
+    return w, b
+
+
 class _PosEnc(nn.Module):
     def __init__(self, d_model, max_len):
         super().__init__()
@@ -152,8 +166,17 @@ class OctAttention(nn.Module):
                 # the three projections read the same rows: one pass for their power-of-two row scales (the query takes the unknown stream's half)
                 rs = native.RowScales(E2)
                 rsq = rs.rows(n, 2 * n)
-            key = lin(pa, E, a.mlp_key.weight, a.mlp_key.bias, scales=rs).reshape(2, B, c, D)
-            val = lin(pa, E, a.mlp_value.weight, a.mlp_value.bias, scales=rs).reshape(2, B, c, D)
+            if planes and D <= _KV_OFF:
+                # key | value as ONE product (round 4): the two [600, 600] weights stacked with 40 zero rows behind each (N = 1280 = five
+                # 256-wide tiles, 256 x 256 tile configuration - half the LDS fill per flop of the 128 x 128 one): 1 339 against 2 x 887 us
+                # at M = 262 144 (tools/mb_oa_cfg.py); same products in the same k order: identical bits.  The attention kernels take the
+                # two column slices with their row stride.
+                wkv, bkv = _ops.derived(a, "kv_cat", [a.mlp_key.weight, a.mlp_key.bias, a.mlp_value.weight, a.mlp_value.bias], lambda: _kv_cat(a, D))
+                kv = native.linear_split_f16(pa, _ops._split16(wkv), bkv, cfg=1).reshape(2, B, c, wkv.shape[0])
+                key, val = kv[..., :D], kv[..., _KV_OFF:_KV_OFF + D]
+            else:
+                key = lin(pa, E, a.mlp_key.weight, a.mlp_key.bias, scales=rs).reshape(2, B, c, D)
+                val = lin(pa, E, a.mlp_value.weight, a.mlp_value.bias, scales=rs).reshape(2, B, c, D)
             q_u = lin(pa, E[1], a.mlp_query.weight, a.mlp_query.bias, rows=(n, 2 * n), scales=rsq).reshape(B, c, D)
             att = torch.empty_like(E)
             native.octattn_attention(q_u, key[0], key[1], val[0], val[1], self.heads, out=att[0], out_u=att[1])

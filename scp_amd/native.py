@@ -111,7 +111,7 @@ def lib():
         "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
         "scp_octattn_f16x3_ws_bytes": (C.c_int64, [i32, i32, i32]),
         "scp_octattn_embed": (C.c_int, [_vp, _vp, i64, i32, _vp, i32, _vp, i32, i32, _vp, i32, _vp, _vp, i32, _vp, i32, _vp, _vp, _vp, i64, _vp, _vp, _vp]),
-        "scp_octattn_attention_f16x3": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp, i64, _vp]),
+        "scp_octattn_attention_f16x3": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i64, i32, i32, i32, i32, _vp, _vp, _vp, i64, _vp]),
         "scp_split_weight_bf16": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp, _vp]),
         "scp_linear_bf16x3": (C.c_int, [_vp, i64, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp]),
         "scp_split_weight_f16": (C.c_int, [_vp, i32, i32, i32, i32, _vp, _vp, _vp, _vp]),
@@ -1214,21 +1214,26 @@ OCTATTN_MODE = os.environ.get("SCP_OCTATTN", "f16x3")   # "f32": the fp32 MFMA k
 
 def octattn_attention(q_u, k, k_u, v, v_u, heads, out=None, out_u=None):
     """Dual-stream causal attention (models/attention_model.py:58-95).  Head width 150 (the reference configuration) runs on the
-    f16x3 kernel (22-bit operands on f16 MFMA, csrc/octattn_f16.hip); SCP_OCTATTN=f32 or any other width: the fp32 kernels."""
+    f16x3 kernel (22-bit operands on f16 MFMA, csrc/octattn_f16.hip); SCP_OCTATTN=f32 or any other width: the fp32 kernels.
+    k, k_u, v, v_u may be column slices of one key | value projection output (unit channel stride, one common row stride)."""
     B, c, D = q_u.shape
     if out is None:
         out, out_u = torch.empty_like(q_u), torch.empty_like(q_u)
     elif not (out.is_contiguous() and out_u.is_contiguous() and out.shape == q_u.shape and out_u.shape == q_u.shape):
         raise ScpError("octattn_attention: out / out_u must be contiguous [B, c, D] float32")
     hd = D // heads
-    if OCTATTN_MODE == "f16x3" and hd == 150 and (D & 3) == 0:
+    ld = k.stride(-2)
+    strided_ok = all(t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1 and t.stride(-2) == ld and (t.dim() == 2 or t.stride(0) == c * ld)
+                     for t in (k, k_u, v, v_u))
+    if OCTATTN_MODE == "f16x3" and hd == 150 and (D & 3) == 0 and strided_ok:
         nb = lib().scp_octattn_f16x3_ws_bytes(B, c, heads)
         ws = torch.empty((nb + 1024,), dtype=torch.uint8, device=q_u.device)
         off = (-ws.data_ptr()) % 1024
-        rc = lib().scp_octattn_attention_f16x3(_dev(q_u), _dev(k), _dev(k_u), _dev(v), _dev(v_u), B, c, heads, hd, _dev(out),
+        rc = lib().scp_octattn_attention_f16x3(_dev(q_u), k.data_ptr(), k_u.data_ptr(), v.data_ptr(), v_u.data_ptr(), ld, B, c, heads, hd, _dev(out),
                                                _dev(out_u), ws.data_ptr() + off, nb, _stream())
         _check(rc, "scp_octattn_attention_f16x3")
         return out, out_u
+    k, k_u, v, v_u = (t.contiguous() for t in (k, k_u, v, v_u))
     rc = lib().scp_octattn_attention(_dev(q_u), _dev(k), _dev(k_u), _dev(v), _dev(v_u), B, c, heads, hd,
                                      _dev(out), _dev(out_u), _stream())
     _check(rc, "scp_octattn_attention")

@@ -1413,3 +1413,18 @@ def test_pad_tiles_are_skipped_and_real_rows_keep_their_bits(dev):
         a = native.swin_attention_packed_planes(qkv[:, :256], kv, table, wtab, shift)
         bb = native.swin_attention_packed_planes(qkv[:, :256], kv, table, wtab, shift, valid=valid)
         assert torch.equal(a[rows], bb[rows])
+
+
+@pytest.mark.gpu
+def test_octattn_attention_takes_column_slices_of_one_projection(dev):
+    """scp_octattn_attention_f16x3 with k / v as column slices of one stacked key | value projection output (row stride 1280) gives the
+    bits of the call on dense copies (round 4: the projection is one N = 1280 product instead of two N = 600 ones)."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(5)
+    B, c, D = 3, 700, 600
+    kv = (torch.randn((2, B, c, 1280), generator=g) * 3).to(dev)
+    q_u = torch.randn((B, c, D), generator=g).to(dev)
+    key, val = kv[..., :D], kv[..., 640:640 + D]
+    a, au = native.octattn_attention(q_u, key[0], key[1], val[0], val[1], 4)
+    b, bu = native.octattn_attention(q_u, key[0].contiguous(), key[1].contiguous(), val[0].contiguous(), val[1].contiguous(), 4)
+    assert torch.equal(a, b) and torch.equal(au, bu)
