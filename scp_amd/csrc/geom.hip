@@ -704,7 +704,7 @@ __global__ __launch_bounds__(WG) void front_key_kernel(const float *__restrict__
         atomicAdd(&hist[(uint32_t)key & mask0], 1u);
     }
     __syncthreads();
-    counts[(int64_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+    counts[(int64_t)blockIdx.x * 256 + threadIdx.x] = hist[threadIdx.x];       // [tile][digit], the layout of radix_hist_kernel
 }
 
 // frames: nframes device arrays float32 [n_points[f]][3]; every frame is cut into nshell trees (shell s: step qs[s], rho-shell path of

@@ -84,6 +84,6 @@ struct DevBuf {
 struct RadixWorkspace { DevBuf counts; };
 int scp_radix_sort_u64(uint64_t *keys_a, uint64_t *keys_b, int64_t n, const int *pass_lo, const int *pass_bits,
                        int npass, RadixWorkspace *ws, hipStream_t st, uint64_t **result, bool first_hist_done = false);
-// the [256][ntiles] digit table of the sort's first pass (tile = 4096 consecutive keys), for a producer that fills it itself
+// the [ntiles][256] digit table of the sort's first pass (tile = 4096 consecutive keys), for a producer that fills it itself
 uint32_t *scp_radix_counts(RadixWorkspace *ws, int64_t n, int *ntiles_out);
 #define SCP_RADIX_TILE 4096

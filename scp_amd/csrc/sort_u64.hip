@@ -1,6 +1,6 @@
 // Stable LSD radix sort of 64-bit Morton keys (gfx950, wave64).
 //
-// One pass = histogram -> scatter (which derives its bucket starts from the raw [digit][tile] table itself).  A tile is 4096
+// One pass = histogram -> scatter (which derives its bucket starts from the raw [tile][digit] table itself).  A tile is 4096
 // consecutive keys owned by one 256-thread workgroup; wave w of the workgroup owns the contiguous
 // quarter [w*1024, (w+1)*1024) and walks it in 16 rounds of 64 keys, so a key's stable rank inside its
 // (tile, digit) bucket is   sum over lower waves of their digit count  +  its rank inside its wave,
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(WG) void radix_hist_kernel(const uint64_t *__restri
         if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> lo) & mask], 1u);
     }
     __syncthreads();
-    counts[(int64_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+    counts[(int64_t)blockIdx.x * 256 + threadIdx.x] = hist[threadIdx.x];     // [tile][digit]: coalesced here and in the scatter's column sums
 }
 
 // exclusive scan of `m` uint32 counters (16-byte aligned), single workgroup of 1024 threads.  A thread owns a run of
@@ -99,16 +99,16 @@ __global__ __launch_bounds__(WG) void radix_scatter_kernel(const uint64_t *__res
         rank[r] = prev + before;
     }
     __syncthreads();
-    // digit t: global start of this tile's (digit t) bucket, straight from the RAW [digit][tile] counts (round 4: no scan kernel between
+    // digit t: global start of this tile's (digit t) bucket, straight from the RAW [tile][digit] counts (round 4: no scan kernel between
     // the histogram and the scatter - a single-workgroup pass over 256 x tiles counters that cost 5 - 15 us per sort pass, a third of a
     // build's kernel time; here every workgroup re-reads the table out of L2, 120 KB for a four-frame build):
-    //   start = sum over digits d' < t of (all tiles' counts of d')  +  sum over tiles t' < this one of counts[t][t']
+    //   start = sum over digits d' < t of (all tiles' counts of d')  +  sum over tiles t' < this one of counts[t'][t]
     {
-        const uint32_t *row = counts + (int64_t)t * ntiles;
         uint32_t tot = 0, pre = 0;
         const int me = (int)blockIdx.x;
+#pragma unroll 8
         for (int j = 0; j < ntiles; ++j) {
-            const uint32_t v = row[j];
+            const uint32_t v = counts[(int64_t)j * 256 + t];      // [tile][digit]: the workgroup reads 1 KiB rows, all loads independent
             tot += v;
             pre += j < me ? v : 0u;
         }
@@ -146,7 +146,7 @@ void scp_launch_scan_u32(uint32_t *counts, int64_t m, hipStream_t st) {
     else hipLaunchKernelGGL(radix_scan_kernel<true>, dim3(1), dim3(1024), 0, st, counts, m);
 }
 
-// first_hist_done: the producer of keys_a has already written pass 0's [digit][tile] table into ws->counts (scp_radix_counts; the fused
+// first_hist_done: the producer of keys_a has already written pass 0's [tile][digit] table into ws->counts (scp_radix_counts; the fused
 // key kernel of geom.hip does, one workgroup per 4096-key tile like radix_hist_kernel): pass 0 starts at its scan.
 uint32_t *scp_radix_counts(RadixWorkspace *ws, int64_t n, int *ntiles_out) {
     const int ntiles = (int)cdiv64(n, TILE);
