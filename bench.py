@@ -39,7 +39,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md: aggregate L2 bandwidth
-PMC_PROFILE = "r4_pmc_traffic.json"     # profiles/: HBM bytes per launch / per frame from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+PMC_PROFILES = ("r4_pmc_traffic.json", "r4_pmc_traffic_octattn_L14_cylin.json")   # profiles/: HBM bytes per launch / per frame from separate rocprofv3 --pmc passes (tools/r4_profiles.sh), one file per configuration
 
 
 def parse():
@@ -249,14 +249,16 @@ def roofline_entry(tag, d):
 def pmc_traffic(config):
     """(HBM bytes per launch of the dominant kernel, HBM bytes per frame, source) from the committed PMC passes - only for the
     configuration they were collected on."""
-    try:
-        with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as f:
-            z = json.load(f)
-        if z.get("config") != config:
-            return None, None, None
-        return z.get("dominant_hbm_bytes_per_launch"), z.get("frame_hbm_bytes"), f"profiles/{PMC_PROFILE} (separate rocprofv3 --pmc passes over this configuration's frame; not measured by this run)"
-    except Exception:
-        return None, None, None
+    for name in PMC_PROFILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                z = json.load(f)
+        except Exception:
+            continue
+        if z.get("config") == config:
+            return (z.get("dominant_hbm_bytes_per_launch"), z.get("frame_hbm_bytes"),
+                    f"profiles/{name} (separate rocprofv3 --pmc passes over this configuration's frame, {z.get('dominant_kernel')}; not measured by this run)")
+    return None, None, None
 
 
 def cpu_baseline(cfg, xyz, full=False):

@@ -25,7 +25,7 @@ for k in tot["FETCH_SIZE"]:
     per[k] = {"launches": n, "hbm_bytes_per_launch": (fb + wb) / n, "fetch_bytes_corrected": fb, "write_bytes": wb}
 frame_bytes = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in per.values()) / frames
 big = dict(sorted(per.items(), key=lambda kv: -(kv[1]["fetch_bytes_corrected"] + kv[1]["write_bytes"]))[:16])
-dom = "rc_post_attn_kernel" if "ehem" in name else "void gemm_split_kernel<2, 2, 2, 0, false, true>"
+dom = "rc_post_attn_kernel" if "ehem" in name else "gemm_split_kernel"      # OctAttention: all variants of the plane GEMM
 g = [v for k, v in per.items() if k.startswith(dom) or dom in k]
 out = {"config": "ehem-L16-m" if "ehem" in name else "octattn-L14-cylin", "frames_profiled": frames,
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs (no tracing options beside --pmc) of " +
