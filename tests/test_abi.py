@@ -117,10 +117,11 @@ def test_model_kernel_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.scp_octattn_f16x3_ws_bytes(0, 1024, 4) == -1
     need = L.scp_octattn_f16x3_ws_bytes(2, 1024, 4)
     assert need > 2 * 32 * 4 * (22528 + 25600)
-    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 2, 1024, 4, 128, one, one, 4096, need, z) == -1
-    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 2, 2048, 4, 150, one, one, 4096, need, z) == -1
-    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 2, 1024, 4, 150, one, one, 4096, need - 1, z) == -1
-    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 2, 1024, 4, 150, one, one, 4097, need, z) == -1
+    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 600, 2, 1024, 4, 128, one, one, 4096, need, z) == -1
+    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 600, 2, 2048, 4, 150, one, one, 4096, need, z) == -1
+    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 600, 2, 1024, 4, 150, one, one, 4096, need - 1, z) == -1
+    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 600, 2, 1024, 4, 150, one, one, 4097, need, z) == -1
+    assert L.scp_octattn_attention_f16x3(one, one, one, one, one, 598, 2, 1024, 4, 150, one, one, 4096, need, z) == -1     # k / v row stride below the row width
 
 
 def test_numeric_profile_contexts_are_per_handle_and_per_thread():
@@ -164,7 +165,8 @@ def test_row_chain_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.scp_swin_ln_linear(one, 250, z, one, one, z, z, 1e-5, one, 768, 10, 768, z) == -1            # ldx < 256
     assert L.scp_swin_ln_linear(one, 256, z, one, one, z, z, 1e-5, one, 512, 10, 768, z) == -1            # ldo < N
     assert L.scp_swin_ln_linear(one, 256, z, one, one, z, z, 1e-5, one, 768, 0, 768, z) == -1             # M == 0
-    assert L.scp_swin_post_attn(one, one, 256, one, 256, z, one, one, one, 1e-5, one, 256, 10, z) == -1    # W NULL
-    assert L.scp_swin_post_attn(one, one, 250, one, 256, one, one, one, one, 1e-5, one, 256, 10, z) == -1  # ldo_in
-    assert L.scp_swin_post_attn(one, one, 256, one, 256, one, one, one, one, 1e-5, one, 254, 10, z) == -1  # ldc
-    assert L.scp_swin_post_attn(one, one, 256, one, 256, one, one, one, one, 1e-5, one, 256, -1, z) == -1  # M
+    assert L.scp_swin_post_attn(one, one, 256, one, 256, z, one, one, one, 1e-5, one, 256, 10, z, 0, z) == -1    # W NULL
+    assert L.scp_swin_post_attn(one, one, 250, one, 256, one, one, one, one, 1e-5, one, 256, 10, z, 0, z) == -1  # ldo_in
+    assert L.scp_swin_post_attn(one, one, 256, one, 256, one, one, one, one, 1e-5, one, 254, 10, z, 0, z) == -1  # ldc
+    assert L.scp_swin_post_attn(one, one, 256, one, 256, one, one, one, one, 1e-5, one, 256, -1, z, 0, z) == -1  # M
+    assert L.scp_swin_post_attn(one, one, 256, one, 256, one, one, one, one, 1e-5, one, 256, 300, one, 4, z) == -1  # more listed tiles than the rows hold
