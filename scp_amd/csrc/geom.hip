@@ -367,7 +367,12 @@ __global__ __launch_bounds__(WG) void tree_occ_kernel(const SegTab *__restrict__
     if (threadIdx.x < NLV) { smn[threadIdx.x] = INT32_MAX; smx[threadIdx.x] = INT32_MIN; }
     __syncthreads();
     const int D = s.depth;
-    for (int64_t r = (int64_t)blockIdx.x * WG + threadIdx.x; r < s.n_nodes; r += (int64_t)gridDim.x * WG) {
+    // a workgroup owns a CONTIGUOUS run of nodes (BFS order: one or two levels), at most 256 workgroups per segment: a level's two
+    // (min, max) words then take a few dozen same-address atomics instead of one per 256 nodes (~400 for a deep level of an L16-m frame -
+    // serialised, they were most of this kernel's 43 us).  (A look-before-atomic with non-temporal loads made it 146 us.)
+    const int64_t per = ((s.n_nodes + gridDim.x - 1) / gridDim.x + WG - 1) / WG * WG;
+    const int64_t r_end = ((int64_t)blockIdx.x + 1) * per < s.n_nodes ? ((int64_t)blockIdx.x + 1) * per : s.n_nodes;
+    for (int64_t r = (int64_t)blockIdx.x * per + threadIdx.x; r < r_end; r += WG) {
         const int64_t nd = s.node_base + r;
         const int L = level[nd];
         const int64_t lvl_end = s.level_off[L + 1];  // relative end of this level
@@ -510,7 +515,7 @@ static int geom_build_sorted(scp_geom *g, scp_segment_info *info, int dmax, hipS
     LAUNCH_CHECK();
     int64_t maxnodes = 0;
     for (int s = 0; s < nseg; ++s) if (g->segs[s].n_nodes > maxnodes) maxnodes = g->segs[s].n_nodes;
-    hipLaunchKernelGGL(tree_occ_kernel, dim3(grid_for(maxnodes), nseg), dim3(WG), 0, st, (const SegTab *)dtab, g->level.as<uint8_t>(),
+    hipLaunchKernelGGL(tree_occ_kernel, dim3(std::min(grid_for(maxnodes), 256), nseg), dim3(WG), 0, st, (const SegTab *)dtab, g->level.as<uint8_t>(),
                        g->octant.as<uint8_t>(), g->fchild.as<int32_t>(), g->leafoct.as<uint8_t>(), g->pos.as<int32_t>(), g->occ.as<uint8_t>(),
                        g->posmm.as<int32_t>());
     LAUNCH_CHECK();
