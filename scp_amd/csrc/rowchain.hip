@@ -658,6 +658,12 @@ __device__ __forceinline__ void rc_gemm_step(const RcLane &L, char *smem, int ha
 // MFMA gap, so the 48 instructions of a pair ride in the gaps of two slices.  st = (slice & 1) * 6 + gap.
 struct RcGelu { float ya, yb, za, zb, ca, cb, ua, ub, pa, pb, ga, gb; unsigned hw; };
 __device__ __forceinline__ void rc_gelu_stage(int st, RcGelu &g, float acc_a, float acc_b, float bias_a, float bias_b, unsigned &wh, unsigned &wl) {
+#ifdef RC_NOGELU   // timing probe (WRONG results): the activation reduced to bias + split - what the GELU's 10 arithmetic stages cost the launch
+    if (st == 0) { g.ga = acc_a + bias_a; g.gb = acc_b + bias_b; asm volatile("" : "+v"(g.ga), "+v"(g.gb)); }
+    if (st == 10) { g.hw = rc_pack2(g.ga, g.gb); wh = g.hw; asm volatile("" : "+v"(g.hw)); }
+    if (st == 11) wl = rc_pack2(g.ga - __builtin_bit_cast(float, g.hw << 16), g.gb - __builtin_bit_cast(float, g.hw & 0xffff0000u));
+    return;
+#endif
     switch (st) {
     case 0: g.ya = acc_a + bias_a; g.yb = acc_b + bias_b; g.za = g.ya * 0.70710678118654752f; g.zb = g.yb * 0.70710678118654752f; break;
     case 1: g.ca = fminf(fabsf(g.za), 3.5f); g.cb = fminf(fabsf(g.zb), 3.5f); g.ua = g.ca * g.ca; g.ub = g.cb * g.cb; break;
