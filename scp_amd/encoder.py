@@ -109,6 +109,11 @@ def chunk_windows(windows, max_tokens):
     return out
 
 
+class _PackedInts(list):
+    """Per-shell integer clouds that are consecutive views of ONE buffer (`.packed`: the shells back to back)."""
+    packed = None
+
+
 def _quant_of(infos):
     """Per shell the quantiser's (qs[3], offset[3]) as plain floats: what de-quantisation needs and the reference's file name cannot
     carry exactly (decoder.write_sidecar)."""
@@ -152,14 +157,34 @@ class FrameEncoder:
         from .data_preproc.data_preprocess import host_quantize_shells
         xyz = np.ascontiguousarray(xyz.cpu().numpy() if isinstance(xyz, torch.Tensor) else xyz, np.float32)
         out = host_quantize_shells(xyz, self.mode, [level_qs(self.data_type, lv) for _, lv in self.shells()], 0.0 if self.mullevel else self.cart_offset)
-        return [q for q, _ in out], [i for _, i in out]
+        # the shells' integers back to back in ONE pinned buffer (this runs on the reader / prefetch thread): the launch thread then issues a
+        # single asynchronous host -> device copy and no concatenation kernel; the list holds numpy views of the buffer
+        n = [q.shape[0] for q, _ in out]
+        buf = torch.empty((sum(n), 3), dtype=torch.int32, pin_memory=torch.cuda.is_available())
+        views, a = _PackedInts(), 0
+        for (q, _), k in zip(out, n):
+            v = buf[a:a + k].numpy()
+            v[...] = q
+            views.append(v)
+            a += k
+        views.packed = buf
+        return views, [i for _, i in out]
 
     def quantize(self, xyz_dev, ints=None):
         """xyz -> list of per-shell integer clouds (device int32 [P,3]) + (bin_num, z_offset)."""
         if self.host_transform or ints is not None:
             hq, infos = ints if ints is not None else self.host_ints(xyz_dev)
             self._infos = infos
-            qs = [torch.from_numpy(q).to(self.device, non_blocking=True) for q in hq]
+            packed = getattr(hq, "packed", None)
+            if packed is not None:       # one pinned buffer -> one async copy; the per-shell clouds are views of it
+                qcat = packed.to(self.device, non_blocking=True)
+                qs, a = _PackedInts(), 0
+                for q in hq:
+                    qs.append(qcat[a:a + q.shape[0]])
+                    a += q.shape[0]
+                qs.packed = qcat
+            else:
+                qs = [torch.from_numpy(np.ascontiguousarray(q, np.int32)).to(self.device, non_blocking=True) for q in hq]
             return qs, infos[0].bin_num, (infos[0].offset[2] if self.cylin else 0.0)
         qs, infos = [], []
         for path, lv in self.shells():
@@ -210,8 +235,8 @@ class FrameEncoder:
     def preprocess_ints(self, qs, bin_num, z_offset, n_points):
         """qs: per-shell quantised integer clouds (device int32 [P_s,3]) - the entry point for already-quantised input
         (the reference's --preproc_path flow).  -> ctx/pos/sym device tensors for all shells, level sizes, meta."""
-        L = self.lidar_level
-        q = torch.cat(qs) if len(qs) > 1 else qs[0]
+        packed = getattr(qs, "packed", None)
+        q = packed if packed is not None else (torch.cat(qs) if len(qs) > 1 else qs[0])
         segs, off = [], 0
         for (path, _), qq in zip(self.shells(), qs):
             segs.append((off, qq.shape[0], path, self.mullevel))
