@@ -616,7 +616,8 @@ def numeric_profile(model_name, profile="current"):
     knn = _MODES["knn"] if profile is None else ("f16x3" if profile.knn_f16x3 else "f32")
     attn = _MODES["attn"] if profile is None else ("bf16x3" if profile.attention_bf16x3 else "f32")
     # ehem/3: patch merging and the geometry generator's edge MLPs on row-chain kernels (other last bits than ehem/2)
-    return f"ehem/3:gemm={ops.MODE},knn={knn},attn={attn},concat={'hier' if packed.HIER else 'direct'},swin=rowchain"
+    # ehem/4: the bf16x3 attention sweeps against the fixed reference 0 with the bias as the products' start value (csrc/attn.hip: attn_tile)
+    return f"ehem/4:gemm={ops.MODE},knn={knn},attn={attn},concat={'hier' if packed.HIER else 'direct'},swin=rowchain"
 
 
 def edge_gather_max(u, v, idx, scale, shift, out=None):

@@ -1163,6 +1163,76 @@ def test_plane_fed_attention_is_bit_identical_to_the_fp32_fed_kernel(dev, shift)
     assert torch.equal(a.t.view(torch.int16), b.t.view(torch.int16))
 
 
+def _attn_f64(q, k, v, table, nwin, shift):
+    """models/swin_transformer.py:443-501, 603-652 for independent 512-token sequences of ONE window each, in float64."""
+    T = q.shape[0]
+    q, k, v = (t.double().reshape(nwin, 512, 4, 64).permute(0, 2, 1, 3) for t in (q, k, v))
+    if shift:
+        q, k, v = (torch.roll(t, -shift, 2) for t in (q, k, v))
+    idx = torch.arange(512, device=q.device)
+    bias = table.double()[(idx[:, None] - idx[None, :] + 511)].permute(2, 0, 1)            # [head][i][j]
+    s = q @ k.transpose(-1, -2) / 8.0 + bias[None]
+    if shift:
+        reg = (idx >= 512 - shift).long()
+        s = s + torch.where(reg[:, None] != reg[None, :], -100.0, 0.0)[None, None]
+    o = torch.softmax(s, -1) @ v
+    if shift:
+        o = torch.roll(o, shift, 2)
+    return o.permute(0, 2, 1, 3).reshape(T, 256)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [0, 256])
+def test_attention_fixed_reference_sweep_and_its_fallback(dev, shift):
+    """Round 4: every workgroup of the bf16x3 attention first sweeps its keys with P = exp2(S) against the FIXED reference 0 (no running
+    maximum, no rescale) and repeats the sweep in the standard online-softmax form only if a row sum left [2^-100, 2^100].
+    (a) ordinary scores: the default is as close to float64 as the standard form; (b) scores beyond 2^+-100: the result IS the standard
+    form's, bit for bit (the second sweep), in the plane-fed and in the rows-fed kernel; finite and right against float64."""
+    from scp_amd import native
+    L = native.lib()
+    g = torch.Generator().manual_seed(31 + shift)
+    nwin = 6
+    T = nwin * 512
+    table = (torch.randn((1023, 4), generator=g) * 0.5).to(dev)
+    wtab = torch.tensor([[w * 512, 512] for w in range(nwin)], dtype=torch.int32, device=dev)
+    try:
+        for scale, fallback in ((1.0, False), (2.0, False), (1.0, True)):
+            qkv = torch.randn((T, 768), generator=g).to(dev)
+            qkv[:, :512] *= scale
+            if fallback:
+                qkv[512:1024, :512] *= 40.0                     # window 1: scores of +-2000 (log2 domain): exp2 overflows
+                u = torch.full((1, 256), 3.0, device=dev)       # window 3: every score near -200: exp2 underflows to nothing
+                qkv[3 * 512:4 * 512, :256] = u + 0.05 * qkv[3 * 512:4 * 512, :256]
+                qkv[3 * 512:4 * 512, 256:512] = -2.0 * u + 0.05 * qkv[3 * 512:4 * 512, 256:512]
+            q, k, v = qkv[:, :256], qkv[:, 256:512], qkv[:, 512:]
+            kv = native.KvPlanes(k, v)
+            want = _attn_f64(q, k, v, table, nwin, shift)
+            out = {}
+            for var in (0, 1):
+                L.scp_set_attention_variant(var)
+                out[var] = (native.swin_attention_packed_planes(q, kv, table, wtab, shift), native.swin_attention_packed(q, k, v, table, wtab, shift))
+                assert torch.equal(out[var][0], out[var][1])                                    # plane-fed == rows-fed, either form
+                assert bool(torch.isfinite(out[var][0]).all())
+            plain = torch.ones(T, dtype=torch.bool, device=dev)
+            if fallback:
+                plain[512:1024] = False
+                plain[3 * 512:4 * 512] = False
+            e0, e1 = ((out[i][0].double() - want)[plain].abs().max().item() for i in (0, 1))
+            print(f"shift {shift} scale {scale}: |standard - f64| {e0:.2e}, |default - f64| {e1:.2e}, |out| max {want.abs().max().item():.2f}")
+            # bf16x3 carries 16 significant bits per operand and a score of magnitude m (log2 domain) is known to ulp(m): the error grows with the scale
+            tol = 5e-5 * scale ** 2
+            assert e0 < tol and e1 < tol and e1 < 1.5 * e0, (e0, e1)                          # and the default is as good as the standard form
+            assert not torch.equal(out[1][0][:512], out[0][0][:512])                             # other last bits: the first sweep was kept
+            if fallback:
+                for wdw in (1, 3):      # these went through the second sweep: the standard form's bits
+                    assert torch.equal(out[1][0][wdw * 512:(wdw + 1) * 512], out[0][0][wdw * 512:(wdw + 1) * 512])
+                e3 = (out[1][0].double() - want)[3 * 512:4 * 512].abs().max().item()
+                print(f"   window of scores near -200: |default - f64| {e3:.2e}")
+                assert e3 < 1e-2, e3
+    finally:
+        L.scp_set_attention_variant(1)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [1, 33, 128, 129, 1000, 70001])
 def test_swin_post_attn_vs_float64_and_the_launches_it_replaces(dev, M):
