@@ -461,6 +461,10 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bf16x3_kernel(const float *_
 // Round 4: the stages are DYNAMIC shared memory.  For a static array hipcc (ROCm 7.2) knows that the LDS-DMA writes it and puts an
 // s_waitcnt vmcnt(0) in front of the first ds_read of that array behind a DMA instruction - here the K reads of tile t, right behind the
 // request for tile t + 1: the "prefetch" was drained every tile.  The barrier macro carries the wait that is needed.
+// Measured and dropped (round 4, tools/src/mb_gap.cpp, mb_phase.cpp, profiles/r4k_attention_probes.md): a form with TWO query blocks per wave whose
+// instruction stream is written gap by gap (every product followed by four to six vector instructions of the other block's softmax, every LDS read
+// requested a phase ahead, K fragments shared by the blocks, 256-query workgroups: half the LDS-DMA traffic), bit-identical: 1 005 - 1 018 against
+// 1 032 - 1 063 us per 1 152 windows - 3 %, for 250 lines.  Also: 8- / 16-wave workgroups (a half / a quarter of the DMA traffic): 1 218 / 1 080 us.
 typedef __attribute__((address_space(3))) void *attn_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *attn_glb_ptr_t;
 #define PKT 32          // keys per tile

@@ -25,7 +25,7 @@ L = native.lib()
 L.scp_rc_debug_buffer.argtypes = [ctypes.c_void_p]
 buf = torch.zeros((256 * 4 * 8,), dtype=torch.int64, device=dev)
 print("probe  ms      cycles per tile and wave: barrier waits / steps (12 x 3072 MFMA floor) / LayerNorm / drain")
-for p in (16, 1, 2):
+for p in (16, 1, 2, 8, 10):
     os.environ["SCP_RC_PROBE"] = str(p)
     ms = t()
     L.scp_rc_debug_buffer(buf.data_ptr())

@@ -1,0 +1,81 @@
+// Do the PHASES of different waves of a SIMD overlap?  Each wave loops over "tiles": 12 dependent products, NV vector instructions (16 of them
+// v_exp_f32, sums as a dependent chain like a softmax), 12 products on two chains, optionally an LDS round trip in front of each product
+// phase and a workgroup barrier per tile.  256-thread workgroups, WPC workgroups per CU (= waves per SIMD), all CUs.
+//   hipcc --offload-arch=gfx950 -O3 -o mb_phase mb_phase.cpp && ./mb_phase
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <bool BARRIER, bool LDSRT>
+__global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, int iters, int lds_pad) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    bf16x8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.01f * (lane + j)); b[j] = (__bf16)(0.02f * (lane - j)); }
+    f32x16 s, o0, o1;
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; o0[r] = 0.f; o1[r] = 0.f; }
+    for (int i = threadIdx.x; i < 2048; i += 256) ((float *)lds)[i] = 0.001f * i;
+    __syncthreads();
+    float l = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if (BARRIER) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (LDSRT) { a = *(const bf16x8 *)(lds + lane * 16); asm volatile("" : "+v"(a)); }
+#pragma unroll
+        for (int c = 0; c < 12; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, s, 0, 0, 0);
+        // "softmax": 16 exp, a dependent sum, the hi / lo split (about 105 vector instructions)
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] * 1e-3f); ps += s[r]; }
+        l += ps;
+        bf16x8 ph[2], pl[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float x = s[8 * c + j]; const __bf16 hh = (__bf16)x; ph[c][j] = hh; pl[c][j] = (__bf16)(x - (float)hh); }
+        if (LDSRT) { b = *(const bf16x8 *)(lds + 4096 + lane * 16); asm volatile("" : "+v"(b)); }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ph[c], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, ph[c], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pl[c], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, pl[c], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, ph[c], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ph[c], o1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = o0[r] * 1e-6f;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float x = l;
+    for (int r = 0; r < 16; ++r) x += o0[r] + o1[r] + s[r];
+    out[blockIdx.x * 256 + threadIdx.x] = x;
+    if (lane == 0) cyc[blockIdx.x * 4 + w] = t1 - t0;
+}
+
+int main() {
+    float *out; unsigned long long *cyc;
+    (void)hipMalloc(&out, 4 * 1024 * 256); (void)hipMalloc(&cyc, 8 * 1024 * 4);
+    static unsigned long long h[1024 * 4];
+    const int iters = 400;
+    printf("shader cycles per tile (24 products = 768 of matrix pipe + ~120 vector instructions): per wave, and per SIMD (= / waves per SIMD)\n");
+    for (int wpc = 1; wpc <= 4; ++wpc) {
+        const int lds_bytes = 160 * 1024 / wpc - 1024;            // LDS limits the workgroups per CU to wpc
+        for (int mode = 0; mode < 4; ++mode) {
+            const bool bar = mode & 1, rt = mode & 2;
+            auto go = [&]() {
+#define GO(B, R) { (void)hipFuncSetAttribute((const void *)k<B, R>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); hipLaunchKernelGGL((k<B, R>), dim3(256 * wpc), dim3(256), lds_bytes, 0, out, cyc, iters, 0); }
+                if (bar && rt) GO(true, true) else if (bar) GO(true, false) else if (rt) GO(false, true) else GO(false, false)
+            };
+            go(); go();
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h, cyc, 8 * 256 * wpc * 4, hipMemcpyDeviceToHost);
+            double t = 0;
+            for (int i = 0; i < 256 * wpc * 4; ++i) t += (double)h[i];
+            t /= 256.0 * wpc * 4 * iters;
+            printf("%d wave(s) per SIMD, barrier per tile %d, LDS round trips %d: %7.0f per wave, %7.0f per SIMD\n", wpc, (int)bar, (int)rt, t, t / wpc);
+        }
+    }
+    return 0;
+}
