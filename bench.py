@@ -471,8 +471,18 @@ def main():
             for h in pending:
                 results += enc.finish_batch(h)
         else:
+            # the front part (stage G + plans) of frame i + 1 runs on the encoder's front thread while this thread enqueues the model part of
+            # frame i (FrameEncoder.front_async: the front part BLOCKS its host thread for 33 - 43 ms per frame - its small kernels queue
+            # behind the whole-GPU model kernels -, which with the strict transform in the same thread made that leg launch-bound)
+            ahead_front = hasattr(enc, "front_async")
+            start = lambda j: enc.front_async(frames[j], ints=ahead.get(j) if strict else None)
+            nxt = start(args.warmup) if ahead_front and args.warmup < total else None
             for i in range(args.warmup, total):
-                pending.append(enc.encode_async(frames[i], ints=ahead.get(i)) if strict else enc.encode_async(frames[i]))
+                if ahead_front:
+                    cur, nxt = nxt, (start(i + 1) if i + 1 < total else None)
+                    pending.append(enc.encode_async(frames[i], front=cur))
+                else:
+                    pending.append(enc.encode_async(frames[i]))
                 if len(pending) > args.depth:
                     results.append(enc.finish(pending.pop(0)))
             results += [enc.finish(h) for h in pending]

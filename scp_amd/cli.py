@@ -249,15 +249,29 @@ def main(argv=None, mullevel=False):
 
     if rank == 0:
         print("Encoding with", name)
+    def fetch(k):
+        d = reader.get(k)
+        return d if host_ints is not None else (d, None)
+
+    # the front part (stage G + window plans) of frame k + 1 runs on the encoder's front thread while this thread enqueues the model part of
+    # frame k (FrameEncoder.front_async: the front part blocks its host thread for most of a frame time)
+    front_ahead = pipelined and hasattr(enc, "front_async")
+    nxt = None
     for k, (i, cur) in enumerate(mine):
         print("Encoding ", cur, i, "/", len(files))
-        xyz = reader.get(k)
-        ints = None
-        if host_ints is not None:
-            xyz, ints = xyz
+        if front_ahead:
+            xyz, ints, fr = nxt if nxt is not None else (*fetch(k), None)
+            if fr is None:
+                fr = enc.front_async(xyz, ints)
+            nxt = None
+            if k + 1 < len(mine):
+                x2, i2 = fetch(k + 1)
+                nxt = (x2, i2, enc.front_async(x2, i2))
+        else:
+            xyz, ints = fetch(k)
         t0 = time.time()
         if pipelined:
-            pending.append((cur, enc.encode_async(xyz, ints) if ints is not None else enc.encode_async(xyz), t0))
+            pending.append((cur, enc.encode_async(xyz, ints, front=fr) if front_ahead else enc.encode_async(xyz), t0))
             if len(pending) > DEPTH:
                 c0, h0, ts = pending.pop(0)
                 report(c0, enc.finish(h0), ts)

@@ -125,3 +125,77 @@ extern "C" int scp_prof_read(int32_t cap, int32_t *tags, float *ms, double *work
     }
     return n;
 }
+
+// ---- scp_stream_wait, scp_d2h_async (scp_internal.h) -----------------------------------------------------------------------------------------
+#include <time.h>
+#include <string.h>
+#include <vector>
+namespace {
+struct PinStage {
+    char *p = nullptr;
+    size_t cap = 0, used = 0;
+    struct Item { void *dst; size_t off, bytes; };
+    std::vector<Item> items;
+};
+thread_local PinStage g_pin;
+constexpr size_t PIN_BYTES = 1 << 20;
+int pin_take(size_t bytes, void *dst, char **at) {
+    PinStage &s = g_pin;
+    if (!s.p) {
+        if (hipHostMalloc((void **)&s.p, PIN_BYTES, hipHostMallocDefault) != hipSuccess) return SCP_ENOMEM;
+        s.cap = PIN_BYTES;
+    }
+    const size_t off = (s.used + 63) & ~(size_t)63;
+    if (off + bytes > s.cap) return SCP_ESMALL;        // (a megabyte: the read-backs of a build are a few kilobytes)
+    s.items.push_back({dst, off, bytes});
+    s.used = off + bytes;
+    *at = s.p + off;
+    return SCP_OK;
+}
+}  // namespace
+
+int scp_d2h_async(void *dst, const void *src, size_t bytes, hipStream_t st) {
+    char *at;
+    const int rc = pin_take(bytes, dst, &at);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(at, src, bytes, hipMemcpyDeviceToHost, st));
+    return SCP_OK;
+}
+
+int scp_d2h_2d_async(void *dst, const void *src, size_t spitch, size_t width, size_t height, hipStream_t st) {
+    char *at;
+    const int rc = pin_take(width * height, dst, &at);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(at, width, src, spitch, width, height, hipMemcpyDeviceToHost, st));
+    return SCP_OK;
+}
+
+static int stream_wait_event(hipStream_t st) {
+    static thread_local hipEvent_t ev = nullptr;
+    static thread_local int ev_dev = -1;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (!ev || ev_dev != dev) {           // (an event belongs to the device that was current when it was made)
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ev_dev = dev;
+    }
+    HIP_TRY(hipEventRecord(ev, st));
+    for (int spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) { (void)hipGetLastError(); return SCP_OK; }      // (drop a recorded hipErrorNotReady: the next LAUNCH_CHECK must not see it)
+        if (q != hipErrorNotReady) { HIP_TRY(q); }
+        if (spins < 20) continue;          // a wait that is over within microseconds (the GPU was idle) costs no sleep
+        struct timespec ts = {0, 50000};
+        nanosleep(&ts, nullptr);
+    }
+}
+
+int scp_stream_wait(hipStream_t st) {
+    const int rc = stream_wait_event(st);
+    PinStage &s = g_pin;
+    if (!rc)
+        for (const auto &it : s.items) memcpy(it.dst, s.p + it.off, it.bytes);
+    s.items.clear();
+    s.used = 0;
+    return rc;
+}

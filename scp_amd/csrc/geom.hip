@@ -162,8 +162,8 @@ extern "C" int scp_quantize(const float *xyz, int64_t n, int32_t mode, double qs
     hipLaunchKernelGGL(transform_kernel, dim3(nb), dim3(WG), 0, st, xyz, n, mode, tr, red);
     LAUNCH_CHECK();
     uint32_t h[2];
-    HIP_TRY(hipMemcpyAsync(h, red, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    { const int rcd = scp_d2h_async(h, red, 8, st); if (rcd) return rcd; }
+    { const int rcw = scp_stream_wait(st); if (rcw) return rcw; }
     const float rho_max = ord2f_host(h[0]), z_min = ord2f_host(h[1]);
 
     QuantParams p;
@@ -185,8 +185,8 @@ extern "C" int scp_quantize(const float *xyz, int64_t n, int32_t mode, double qs
     hipLaunchKernelGGL(quantize_kernel, dim3(nb), dim3(WG), 0, st, (const float *)tr, n, p, q_out, (int32_t *)(red + 2));
     LAUNCH_CHECK();
     int32_t hm[2];
-    HIP_TRY(hipMemcpyAsync(hm, red + 2, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    { const int rcd = scp_d2h_async(hm, red + 2, 8, st); if (rcd) return rcd; }
+    { const int rcw = scp_stream_wait(st); if (rcw) return rcw; }
     info->max_coord = hm[0];
     info->min_coord = hm[1];
     return hm[1] < 0 ? SCP_EINVAL : SCP_OK;
@@ -458,9 +458,9 @@ static int geom_build_sorted(scp_geom *g, scp_segment_info *info, int dmax, hipS
     LAUNCH_CHECK();
     std::vector<SegTab> back(nseg);
     std::vector<uint32_t> lvl_first(lmax + 2, 0u);
-    HIP_TRY(hipMemcpyAsync(back.data(), dtab, sizeof(SegTab) * nseg, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpy2DAsync(lvl_first.data(), 4, blk, (size_t)nblk * 4, 4, lmax + 2, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    { const int rcd = scp_d2h_async(back.data(), dtab, sizeof(SegTab) * nseg, st); if (rcd) return rcd; }
+    { const int rcd = scp_d2h_2d_async(lvl_first.data(), blk, (size_t)nblk * 4, 4, lmax + 2, st); if (rcd) return rcd; }
+    { const int rcw = scp_stream_wait(st); if (rcw) return rcw; }
 
     // --- per-segment level tables (host, tiny) --------------------------------------------------------------
     int64_t node_base = 0, leaf_base = 0;
@@ -575,8 +575,8 @@ extern "C" int scp_geom_build(scp_geom *g, const int32_t *q, int64_t n, const sc
     HIP_TRY(hipMemcpyAsync(dtab, g->segs.data(), sizeof(SegTab) * nseg, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(seg_minmax_kernel, dim3(std::min(grid_for(maxcount * 3), 64), nseg), dim3(WG), 0, st, q, (const SegTab *)dtab, g->red.as<int32_t>());
     LAUNCH_CHECK();
-    HIP_TRY(hipMemcpyAsync(red.data(), g->red.p, red.size() * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    { const int rcd = scp_d2h_async(red.data(), g->red.p, red.size() * 4, st); if (rcd) return rcd; }
+    { const int rcw = scp_stream_wait(st); if (rcw) return rcw; }
     int dmax = 0;
     for (int s = 0; s < nseg; ++s) {
         const int32_t mx = red[2 * s], mn = red[2 * s + 1];
@@ -757,8 +757,8 @@ extern "C" int scp_geom_build_xyz(scp_geom *g, const float *const *frames, const
                            g->tr.as<float>(), dred);
     }
     LAUNCH_CHECK();
-    HIP_TRY(hipMemcpyAsync(red.data(), dred, red.size() * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));                 // read-back 1 of 2: the extrema fix the steps and the depths
+    { const int rcd = scp_d2h_async(red.data(), dred, red.size() * 4, st); if (rcd) return rcd; }
+    { const int rcw = scp_stream_wait(st); if (rcw) return rcw; }                 // read-back 1 of 2: the extrema fix the steps and the depths
 
     std::vector<FrontSeg> fs(nseg);
     int dmax = 0;

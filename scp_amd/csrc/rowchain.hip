@@ -296,6 +296,8 @@ __device__ __forceinline__ void rc_ll_step(const RcLane &L, const RcLnLinArgs &a
             if ((s == 10 || s == 13) && gap < 4 && !(PROBE & 8))  // ... and out
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ri32x4, rd[gap]), rs_prev, voff,
                                                        gap * 8 * ldo_bytes + (ch0_prev + 32 * (s == 13 ? 1 : 0)) * 4, RC_STORE_AUX);
+            // (Measured and dropped, round 4: the same 32 loads one per gap over slices 8 - 15 instead of four per gap in slices 14 and 15: they then
+            // collide with the deferred epilogue - 0.995 / 0.655 against 0.973 / 0.595 ms per 590 848 rows at N = 768 / 512.)
             if (LOADX && s >= 14 && gap < 4 && !(PROBE & 4)) {                      // the next tile's rows into the registers LayerNorm has freed
 #pragma unroll
                 for (int t = 8 * (s - 14) + 2 * gap; t < 8 * (s - 14) + 2 * gap + 2; ++t) {

@@ -21,6 +21,16 @@ extern int g_scp_last_hip_error;
 
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
+// hipStreamSynchronize without the spin: the runtime busy-waits, and the stage-G read-backs of the pipelined encoder wait for tens of
+// milliseconds per frame (their small kernels queue behind the whole-GPU model kernels of the frames in flight: 33 - 43 ms of one core per
+// frame).  An event per host thread, polled every 50 us.  (Defined in api.cpp.)
+int scp_stream_wait(hipStream_t st);
+// Small device -> host read-backs in front of such a wait: hipMemcpyAsync into PAGEABLE host memory does not return before the copy has run
+// (the runtime spins there instead), so the bytes go through a pinned staging buffer of the calling thread and scp_stream_wait hands them to
+// their destinations.  2-D form: `height` elements of `width` bytes, source pitch `spitch`, packed at the destination.
+int scp_d2h_async(void *dst, const void *src, size_t bytes, hipStream_t st);
+int scp_d2h_2d_async(void *dst, const void *src, size_t spitch, size_t width, size_t height, hipStream_t st);
+
 // scp_debug.h launch brackets (api.cpp): `SCP_PROF(tag, stream, work);` right in front of a launch records a hipEvent on the stream now
 // and another when the enclosing scope ends (i.e. after the launch).  One relaxed load when profiling is off.
 extern int g_scp_prof_on;

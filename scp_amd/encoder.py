@@ -344,6 +344,7 @@ class FrameEncoder:
         if hasattr(self, "_pool"):
             return
         self._pool = ThreadPoolExecutor(max_workers=2)
+        self._front_pool = ThreadPoolExecutor(max_workers=1)     # front_async: stage G + plans of the next frame (see there)
         self._copy_stream = torch.cuda.Stream(device=self.device)
         self._front_stream = torch.cuda.Stream(device=self.device, priority=-1)   # high priority: its tiny kernels slip in between the model's
         # Lanes: consecutive frames run their model part on alternating streams, so the launch gaps and tails of one frame's
@@ -352,31 +353,16 @@ class FrameEncoder:
         self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(os.environ.get("SCP_LANES", "2"))))]
         self._lane_i = 0
 
-    def encode_async(self, xyz, ints=None):
-        """Like encode(), but the D2H copy of the (c_low, c_high) pairs and the serial host range coder run on a worker
-        thread (ctypes releases the GIL) behind an event on a side stream, so the caller can enqueue the next frame while this
-        one is being coded.  Returns a handle; `finish(handle)` blocks and returns the usual result dict.
-        ints: the result of `host_ints(xyz)` when the caller has already computed it (strict-identity mode, CLI reader thread)."""
-        t0 = time.perf_counter()
+    def _front(self, xyz, ints, caller):
+        """Stage G and the window plans of one frame on the front stream (a side stream: launch-bound work with two small D2H syncs, which
+        runs under the previous frames' model kernels).  -> everything the model part needs + the event it waits for."""
+        torch.cuda.set_device(self.device)                     # (the current device is per host thread: this may be the front thread)
         if isinstance(xyz, np.ndarray):
             xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float32))
         if self.host_transform and ints is None:
             ints = self.host_ints(xyz)
-        self._init_streams()
-        # Front part on its own stream: stage G (with its small D2H syncs) and the window plans (one plan_kernel launch per chunk)
-        # are launch-bound; on a side stream they run under the previous frame's model kernels instead of in front of this
-        # frame's.  Everything allocated here stays referenced by the handle until finish(), i.e. past its last use on the
-        # main stream, so the caching allocator cannot hand it out again early.
-        caller = torch.cuda.current_stream(self.device)
-        if len(self._lanes) > 1:
-            main = self._lanes[self._lane_i % len(self._lanes)]
-            self._lane_i += 1
-            main.wait_stream(caller)                       # whatever produced `xyz` on the caller's stream
-        else:
-            main = caller
-        fills0 = native.CACHE_FILLS
         with torch.cuda.stream(self._front_stream):
-            self._front_stream.wait_stream(caller)
+            self._front_stream.wait_stream(caller)             # whatever produced `xyz` on the caller's stream
             pre = self.preprocess(xyz.to(self.device, non_blocking=True), ints)
             plan = EncodePlan(pre["level_sizes"], self.context_size)
             if self.packed:
@@ -384,6 +370,40 @@ class FrameEncoder:
             sym_coded = self._sym_coded(pre, plan)
             ready = torch.cuda.Event()
             ready.record()
+        return dict(pre=pre, plan=plan, sym_coded=sym_coded, ready=ready)
+
+    def front_async(self, xyz, ints=None):
+        """Start a frame's front part (stage G, plans) on the encoder's FRONT THREAD and return a future for `encode_async(..., front=)`.
+        The front part blocks its host thread for most of a frame time - its ~35 small dependent kernels each wait for a gap between the
+        whole-GPU model kernels of the frames in flight (33 - 43 ms per frame in `bench.py`, against 0.4 ms alone on the GPU) - so a loop that
+        calls this one frame ahead keeps the launch thread free for the model part (ctypes and torch release the GIL while they wait).
+        Call order = frame order: the front thread takes the frames one at a time (one `scp_geom` handle)."""
+        self._init_streams()
+        caller = torch.cuda.current_stream(self.device)
+        return self._front_pool.submit(self._front, xyz, ints, caller)
+
+    def encode_async(self, xyz, ints=None, front=None):
+        """Like encode(), but the D2H copy of the (c_low, c_high) pairs and the serial host range coder run on a worker
+        thread (ctypes releases the GIL) behind an event on a side stream, so the caller can enqueue the next frame while this
+        one is being coded.  Returns a handle; `finish(handle)` blocks and returns the usual result dict.
+        ints: the result of `host_ints(xyz)` when the caller has already computed it (strict-identity mode, CLI reader thread).
+        front: the future `front_async(xyz, ints)` returned for this frame (then xyz / ints are not looked at again)."""
+        t0 = time.perf_counter()
+        self._init_streams()
+        # Front part on its own stream: stage G (with its small D2H syncs) and the window plans (one plan_kernel launch per chunk)
+        # are launch-bound; on a side stream they run under the previous frame's model kernels instead of in front of this
+        # frame's.  Everything allocated there stays referenced by the handle until finish(), i.e. past its last use on the
+        # main stream, so the caching allocator cannot hand it out again early.
+        caller = torch.cuda.current_stream(self.device)
+        if len(self._lanes) > 1:
+            main = self._lanes[self._lane_i % len(self._lanes)]
+            self._lane_i += 1
+            main.wait_stream(caller)
+        else:
+            main = caller
+        fills0 = native.CACHE_FILLS
+        f = front.result() if front is not None else self._front(xyz, ints, caller)
+        pre, plan, sym_coded, ready = f["pre"], f["plan"], f["sym_coded"], f["ready"]
         main.wait_event(ready)
         with torch.cuda.stream(main):
             table = self.logits_in_coding_order(pre, plan)

@@ -101,6 +101,13 @@ def test_batched_windows_equal_single_windows(enc_parts):
     assert d < 1e-4, d
 
 
+def _ints_of(enc, xyz):
+    """arguments of FrameEncoder.encode_ints for the strict host transform of a frame"""
+    hq, infos = enc.host_ints(xyz)
+    qs = [torch.from_numpy(np.ascontiguousarray(q)).to(enc.device) for q in hq]
+    return qs, infos[0].bin_num, (infos[0].offset[2] if enc.cylin else 0.0), xyz.shape[0]
+
+
 def test_async_pipeline_equals_sync(enc_parts):
     from scp_amd.encoder import FrameEncoder, EncodePlan
     from scp_amd.synth import synth_frame
@@ -130,6 +137,19 @@ def test_two_lane_pipeline_full_size_frames_equal_sequential_encode(enc_parts):
     assert got == want
     hs = [enc.encode_async(f) for f in frames[::-1]]
     assert [enc.finish(h)["bytes"] for h in hs] == want[::-1]
+    # the front part (stage G + plans) one frame ahead on the encoder's front thread, as bench.py / the CLI drive it - device transform and
+    # the strict host transform
+    for strict in (False, True):
+        fut = enc.front_async(frames[0], enc.host_ints(frames[0]) if strict else None)
+        hs = []
+        for i, f in enumerate(frames):
+            cur, fut = fut, (enc.front_async(frames[i + 1], enc.host_ints(frames[i + 1]) if strict else None) if i + 1 < len(frames) else None)
+            hs.append(enc.encode_async(f, front=cur))
+        got = [enc.finish(h) for h in hs]
+        if strict:
+            assert [g["bytes"] for g in got] == [enc.encode_ints(*_ints_of(enc, f))["bytes"] for f in frames]
+        else:
+            assert [g["bytes"] for g in got] == want
 
 
 def test_determinism(enc_parts):

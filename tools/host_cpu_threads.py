@@ -23,24 +23,54 @@ def snap():
             pass
     return out
 
-nf = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+strict = "--strict" in sys.argv          # the strict-identity front end (host_ints on one prefetch thread, as bench.py's second leg)
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+nf = int(argv[0]) if argv else 24
 dev = torch.device("cuda:0")
 model = fill_weights(EHEM(ehem_cfg()), 0).to(dev)
 enc = FrameEncoder(model, "kitti", 16, spher=True, mullevel=True, device=dev)
-frames = [torch.from_numpy(synth_frame(i)).to(dev) for i in range(nf + 2)]
+for a_ in sys.argv:
+    if a_.startswith("--rc-grid="):         # persistent workgroups of the row-chain launches (default: one per CU)
+        from scp_amd import native
+        native.lib().scp_rc_set_grid(int(a_.split("=")[1]))
+frames_h = [synth_frame(i) for i in range(nf + 2)]
+frames = [torch.from_numpy(f).to(dev) for f in frames_h]
+from concurrent.futures import ThreadPoolExecutor
+pool = ThreadPoolExecutor(max_workers=1)
+futs, nxt = {}, 2
+def ints_of(i):
+    global nxt
+    if not strict:
+        return None
+    while nxt < nf + 2 and nxt <= i + 2:
+        futs[nxt] = pool.submit(enc.host_ints, frames_h[nxt]); nxt += 1
+    return futs.pop(i).result()
 for i in range(2):
     enc.finish(enc.encode_async(frames[i]))
 torch.cuda.synchronize()
+prof = None
+if "--cprofile" in sys.argv:
+    import cProfile
+    prof = cProfile.Profile(); prof.enable()
 a = snap(); t0 = time.perf_counter(); tt0 = time.thread_time()
 pending = []
+front = "--front" in sys.argv            # FrameEncoder.front_async one frame ahead (what bench.py does)
+nxt_f = enc.front_async(frames[2], ints=ints_of(2)) if front else None
 for i in range(2, nf + 2):
-    pending.append(enc.encode_async(frames[i]))
+    if front:
+        cur_f, nxt_f = nxt_f, (enc.front_async(frames[i + 1], ints=ints_of(i + 1)) if i + 1 < nf + 2 else None)
+        pending.append(enc.encode_async(frames[i], front=cur_f))
+    else:
+        pending.append(enc.encode_async(frames[i], ints=ints_of(i)))
     if len(pending) > 4:
         enc.finish(pending.pop(0))
 for h in pending:
     enc.finish(h)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0; tt = time.thread_time() - tt0
+if prof is not None:
+    import pstats
+    prof.disable(); pstats.Stats(prof).sort_stats("tottime").print_stats(18)
 b = snap()
 print(f"{nf / dt:.2f} frames/s, {1e3 * dt / nf:.1f} ms per frame; launch thread (this one, tid {threading.get_native_id()}): {1e3 * tt / nf:.1f} ms CPU per frame")
 rows = sorted(((b[t][1] - a.get(t, (None, 0.0))[1], t, b[t][0]) for t in b), reverse=True)
