@@ -27,9 +27,9 @@ SCP_API int scp_knn_debug_buffer(unsigned long long *dev_buf);
 /* the same for the row-chain kernels (scp_swin_ln_linear / scp_swin_post_attn): (workgroups * 4 * 8) u64, per wave the cycle sums of
  * the kernel's phases and its tile count (tools/mb_rowchain_probe.py, tools/mb_postattn.py) */
 SCP_API int scp_rc_debug_buffer(unsigned long long *dev_buf);
-/* A/B bracket of swin_attn_planes_kernel (bit-identical forms; tools/mb_attn_planes.py): 0 = the round-3 instruction order, 1 (default) =
- * K fragment reads requested in two pinned groups + v_permlane32_swap exchanges (1 096 against 1 103 us per 1 152 windows: the kernel is
- * bound by its VALU count per tile, not by these latencies - DESIGN.md 4.7) */
+/* test / A/B bracket of the bf16x3 window-attention kernels (tools/mb_attn_planes.py, tests/test_gpu_model.py): 1 (default) = every workgroup
+ * sweeps its keys against the fixed reference 0 first (P = exp2(S), no running maximum) and falls back to the standard online softmax only if a
+ * row sum left [2^-100, 2^100]; 0 = the standard form only (what the fallback computes).  The two differ in the last bits. */
 SCP_API int scp_set_attention_variant(int32_t v);
 /* persistent workgroups of the row-chain launches (0 = one per CU of the device): for launches on a stream created with a CU mask
  * (tools/mb_cumask.py), whose CU set is smaller than the device's */
