@@ -1008,6 +1008,9 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
                 for (int u = 0; u < 4; ++u) o[q][u] = Y[b][4 * q + u];
             rc_store_block(L, bounce, o, rs, ldc_bytes, voff, 32 * b);
         }
+        // (Measured and dropped, round 4: four blocks per pass through the ring half body 31 has just finished with - 16 KiB of bounce space per wave,
+        // 2 + 2 exposed LDS round trips for the stores and the transposition instead of 16 + 16, a barrier behind it - 2.167 - 2.184 against 2.158 ms per
+        // 590 848 rows: the epilogue's 20 k cycles are not LDS latency either.)
         transpose_o();                                             // the next tile's attention rows (requested in front of body 30) -> B fragments
         stamp(t_epi);
         ++n_tiles;
