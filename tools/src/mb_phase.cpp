@@ -7,8 +7,8 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <bool BARRIER, bool LDSRT>
-__global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, int iters, int lds_pad) {
+template <bool BARRIER, bool LDSRT, int NRD = 0, bool DMA = false>      // NRD: ds_read_b128 per product phase (the attention kernel: 8 + 8); DMA: 4 x 1 KiB LDS-DMA per wave and tile
+__global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, int iters, int lds_pad, const char *src = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     bf16x8 a, b;
@@ -21,7 +21,22 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, in
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         if (BARRIER) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (DMA) {
+            const char *g = src + ((size_t)blockIdx.x * 64 + (it & 63)) * 16384 + w * 4096 + lane * 16;
+            char *d = lds + 8192 + ((it + 1) & 1) * 16384 + w * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + i * 1024), (__attribute__((address_space(3))) void *)(d + i * 1024), 16, 0, 0);
+        }
         if (LDSRT) { a = *(const bf16x8 *)(lds + lane * 16); asm volatile("" : "+v"(a)); }
+        bf16x8 fr[8];
+        if (NRD) {
+#pragma unroll
+            for (int i = 0; i < NRD; ++i) fr[i & 7] = *(const bf16x8 *)(lds + 8192 + (it & 1) * 16384 + ((i * 1024 + lane * 16) & 16383));
+#pragma unroll
+            for (int i = 0; i < (NRD < 8 ? NRD : 8); ++i) asm volatile("" : "+v"(fr[i]));
+            a = fr[0];
+        }
 #pragma unroll
         for (int c = 0; c < 12; ++c) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, s, 0, 0, 0);
         // "softmax": 16 exp, a dependent sum, the hi / lo split (about 105 vector instructions)
@@ -35,6 +50,13 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, in
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float x = s[8 * c + j]; const __bf16 hh = (__bf16)x; ph[c][j] = hh; pl[c][j] = (__bf16)(x - (float)hh); }
         if (LDSRT) { b = *(const bf16x8 *)(lds + 4096 + lane * 16); asm volatile("" : "+v"(b)); }
+        if (NRD) {
+#pragma unroll
+            for (int i = 0; i < NRD; ++i) fr[i & 7] = *(const bf16x8 *)(lds + 8192 + (it & 1) * 16384 + ((8192 + i * 1024 + lane * 16) & 16383));
+#pragma unroll
+            for (int i = 0; i < (NRD < 8 ? NRD : 8); ++i) asm volatile("" : "+v"(fr[i]));
+            b = fr[1];
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ph[c], o0, 0, 0, 0);
@@ -76,6 +98,25 @@ int main() {
             t /= 256.0 * wpc * 4 * iters;
             printf("%d wave(s) per SIMD, barrier per tile %d, LDS round trips %d: %7.0f per wave, %7.0f per SIMD\n", wpc, (int)bar, (int)rt, t, t / wpc);
         }
+    }
+    // towards the attention kernel (4 workgroups per CU, barrier per tile): 8 + 8 fragment reads per tile, LDS-DMA of the next tile
+    {
+        char *src; (void)hipMalloc(&src, (size_t)1024 * 64 * 16384);
+        (void)hipMemset(src, 0, (size_t)1024 * 64 * 16384);
+        const int wpc = 4, lds_bytes = 160 * 1024 / wpc - 1024;
+        auto run = [&](const char *nm, auto kern) {
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kern, dim3(256 * wpc), dim3(256), lds_bytes, 0, out, cyc, iters, 0, (const char *)src);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h, cyc, 8 * 256 * wpc * 4, hipMemcpyDeviceToHost);
+            double t = 0;
+            for (int i = 0; i < 256 * wpc * 4; ++i) t += (double)h[i];
+            t /= 256.0 * wpc * 4 * iters;
+            printf("4 waves per SIMD, barrier per tile, %-44s %7.0f per wave, %7.0f per SIMD\n", nm, t, t / wpc);
+        };
+        run("+ 8 + 8 fragment reads per tile:", k<true, false, 8, false>);
+        run("+ LDS-DMA of the next tile (4 KiB per wave):", k<true, true, 0, true>);
+        run("+ both:", k<true, false, 8, true>);
     }
     return 0;
 }
