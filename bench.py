@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the second timed loop in strict-identity mode")
     ap.add_argument("--oa-batch", type=int, default=None, help="OctAttention: windows per forward (OctAttnFrameEncoder.max_batch)")
     ap.add_argument("--decode", action="store_true", help="time the decoder (FrameDecoder) on the configuration's frame instead of the encoder")
+    ap.add_argument("--decode-streams", type=int, default=1, help="with --decode: frames decoded CONCURRENTLY, each by its own FrameDecoder on its own host thread and "
+                    "HIP stream (a frame's decode is a chain of dependent launch sequences that uses a fraction of the GPU: independent frames overlap)")
     ap.add_argument("--all-configs", action="store_true", help="run every configuration of CONFIGS in turn (child processes), one JSON line each")
     ap.add_argument("--out-dir", default=None, help="with --all-configs: also write <out-dir>/<tag>_bench_<config>.json")
     ap.add_argument("--tag", default="r4", help="file-name prefix used with --out-dir")
@@ -364,12 +366,37 @@ def run_decode(args, cfg, enc, model, dev, frame_host):
     stage = {k: round(1e3 * v, 2) for k, v in dec.stats.items()}
     dec.stats = None
     torch.cuda.synchronize()
-    cpu0, t0 = time.process_time(), time.perf_counter()
-    for i in range(args.steps):
-        shells = dec.decode(res["bytes"], res["n_levels"], res["pos_mm"])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps
+    nstreams = min(8, max(1, args.decode_streams))           # (16 decoders did not fit next to each other: every decoder holds its own frame's tables)
+    if nstreams > 1:
+        # `nstreams` decoders, each on its own thread and stream, `steps` frames each (every weight cache is warm: decoder 0 has run)
+        import threading
+        decs = [dec] + [FrameDecoder(model, cfg["level"], mullevel=cfg["mullevel"], polar=cfg["mode"] != "cart", device=dev) for _ in range(nstreams - 1)]
+        outs = [None] * nstreams
+
+        def work(k, n):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                for _ in range(n):
+                    outs[k] = decs[k].decode(res["bytes"], res["n_levels"], res["pos_mm"])
+                torch.cuda.current_stream().synchronize()
+
+        ths = [threading.Thread(target=work, args=(k, 1)) for k in range(nstreams)]     # warm-up: every decoder's plans
+        [t.start() for t in ths]; [t.join() for t in ths]
+        torch.cuda.synchronize()
+        cpu0, t0 = time.process_time(), time.perf_counter()
+        ths = [threading.Thread(target=work, args=(k, args.steps)) for k in range(nstreams)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / nstreams          # per frame: nstreams x steps frames were decoded
+        cpu_ms = 1e3 * (time.process_time() - cpu0) / (args.steps * nstreams)
+        shells = outs[-1]
+    else:
+        cpu0, t0 = time.process_time(), time.perf_counter()
+        for i in range(args.steps):
+            shells = dec.decode(res["bytes"], res["n_levels"], res["pos_mm"])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps
     for (codes, _), w in zip(shells, want):
         got = torch.cat(codes).cpu().numpy()
         ok = ok and len(got) == len(w) and (np.array_equal(got[:-1], w[:-1]) if cfg["mullevel"] else np.array_equal(got, w))
@@ -382,7 +409,7 @@ def run_decode(args, cfg, enc, model, dev, frame_host):
            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (same kernels and numeric profile as the encoder)", "data": "synthetic",
            "config": {"workload": cfg["workload"] + ", seeded random weights; DECODER", "nodes_per_frame": int(res["n_nodes"]), "windows_per_frame": len(ws),
                       "levels": len(res["level_sizes"]), "phase1_launch_sequences_per_frame": len(res["level_sizes"]),
-                      "phase2_launch_sequences_per_frame": with_phase2},
+                      "phase2_launch_sequences_per_frame": with_phase2, "frames_decoded_concurrently": nstreams},
            "decoded_occupancy_equals_encoded": bool(ok), "host_cpu_ms_per_frame": cpu_ms, "stream_bytes": len(res["bytes"])}
     out["stage_ms"] = stage
     out["stage_ms_note"] = "one extra decode of the same stream with a device synchronisation after every stage (slower than the timed decodes)"
