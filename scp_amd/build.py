@@ -19,6 +19,8 @@ EXTRA = {"geom.hip": ["-ffp-contract=off"], "knn.hip": ["-ffp-contract=off"], "c
          "edge.hip": ["-ffp-contract=off"], "metrics.hip": ["-ffp-contract=off"], "octattn_embed.hip": ["-ffp-contract=off"]}
 if os.environ.get("SCP_ATTN_DEFS"):    # experiment builds of csrc/attn.hip (e.g. SCP_ATTN_DEFS="-DPNS=3")
     EXTRA["attn.hip"] = os.environ["SCP_ATTN_DEFS"].split()
+if os.environ.get("SCP_KNN_DEFS"):     # experiment builds of csrc/knn.hip (e.g. SCP_KNN_DEFS="-DKNN_INSERT_CHAIN")
+    EXTRA["knn.hip"] = EXTRA["knn.hip"] + os.environ["SCP_KNN_DEFS"].split()
 if os.environ.get("SCP_RC_DEFS"):      # experiment builds of csrc/rowchain.hip (e.g. SCP_RC_DEFS="-DRC_WAIT0")
     EXTRA["rowchain.hip"] = os.environ["SCP_RC_DEFS"].split()
 

@@ -79,6 +79,8 @@ __device__ __forceinline__ int knn_key_idx(kkey_t k) {
     return (hi == (int)0xFF800000 && lo == -1) ? INT_MAX : (lo ^ ~(hi >> 31));
 }
 
+// (Measured and dropped, round 4: the list without the chain of 20 dependent v_min_f64 - new[t] = max(key[t], min(key[t - 1], kc)), every slot from the OLD
+// neighbours, bottom up in place, identical lists - 4.62 / 5.69 against 4.60 - 4.64 / 5.67 - 5.68 ms per 70 windows of 8 192 at C = 144 / 192: not the insertion's latency either.)
 __device__ __forceinline__ void key_insert(kkey_t (&key)[TK], kkey_t kc) {
 #pragma unroll
     for (int t = 0; t < TK; ++t) {
