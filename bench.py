@@ -618,7 +618,7 @@ def main():
                          "validity_rule": "event-timed kernels of one frame (per-launch minimum over 3 frames) must sum to <= 1.02 x the synchronised wall "
                                           "time of the same frame's model stage; false = do not use these fractions",
                          "method": "hipEvents recorded inside libscp_hip.so around each launch (include/scp_debug.h), allocator-warm stream, per-launch minimum of 3 frames",
-                         "peak_note": "2500 TFLOP/s dense 16-bit MFMA / 3 products; the fp32 MFMA peak this replaces is 157.3.  With all 256 CUs multiplying the clock settles at 1.85 GHz (tools/src/mb_power.cpp): 1.95 PFLOP/s sustained, 650 per fp32-class product",
+                         "peak_note": "2500 TFLOP/s dense 16-bit MFMA / 3 products; the fp32 MFMA peak this replaces is 157.3.  With all 256 CUs multiplying the clock settles at 1.85 GHz (tools/src/mb_power.cpp): 1.95 PFLOP/s sustained, 650 per fp32-class product; this kernel runs at 1.91 GHz inside the frame (GRBM_GUI_ACTIVE / duration, profiles/r4k_kernel_clocks.md)",
                          "launches_per_frame": dom["launches_per_frame"], "avg_launch_us": dom["avg_launch_us"], "flops_per_launch": dom["flops_per_launch"]},
             # the whole frame against both roofs: algorithmic flop of what the reference's window loop computes (encode_mullevel.py:106-133;
             # SURVEY.md 8d formulas on the frame's real window lengths) / the bench's own ms_per_step
