@@ -156,7 +156,15 @@ def _check(rc, what):
     return rc
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The calling thread's current HIP stream as an integer handle.  torch.cuda.current_stream() builds a Stream object through four
+    Python frames - 8 us per call, 71 ms per decoded frame (8 900 launches); the raw accessor takes 0.3 us."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return _RAW_STREAM(_RAW_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 
