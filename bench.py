@@ -6,6 +6,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
     python bench.py --all-configs            (the five BASELINE.json configurations, one JSON line each, into profiles/ with --out-dir)
     python bench.py --decode                 (the decoder on the same configuration: frames/s, stage split)
+    python bench.py --no-legs                (the headline only: no side legs - see below)
+
+The headline `value` is measured in STRICT-IDENTITY mode (round 5): the float -> integer step is the reference's own numpy float32 arithmetic
+(data_preprocess.py:42-70,171-214) on a prefetch thread, inside the timed region, and the run asserts that 0 points of the seed-0 frame differ
+from the reference's integers (`transform_parity`); the device-transform rate is the extra key `device_transform`.
+After the headline (outside its timed region, N = 1 only) the default run adds short legs, each a child process running this file
+(5 warm-up + 10 timed frames): the other four BASELINE.json workloads and the decoder under `configs`, and a `cli` leg - `.bin` files on disk
+through the drop-in `encode_mullevel.py` (file read, parse, host -> device copy and the written `.bin` / `.dat` inside) - with `cli_over_bench`.
 
 One step = one synthetic 120 000-point frame through the whole hot path on one GPU: quantiser (3 shells) -> octree
 serialisation -> context tables -> EHEM over every <= 8192-node window -> softmax/integer CDF -> range coder.  The frame
@@ -53,9 +61,14 @@ def parse():
     ap.add_argument("--depth", type=int, default=4, help="frames in flight (encode_async handles not yet finished); 4 measured 1.2 % above 3, 5 no better")
     ap.add_argument("--batch", type=int, default=None, help="frames per stage-G / packed-forward / CDF launch (FrameEncoder.encode_batch_async); "
                     "default: 4 for the level-12 EHEM configuration (a 115 k-node frame is 22 windows), 1 elsewhere")
-    ap.add_argument("--host-transform", action="store_true", help="strict-identity mode as the HEADLINE: numpy float32 transform + quantiser on a "
-                    "prefetch thread one frame ahead (the default line reports it beside the device transform as `strict_identity`)")
-    ap.add_argument("--no-strict-leg", action="store_true", help="skip the second timed loop in strict-identity mode")
+    ap.add_argument("--host-transform", action="store_true", help="(default for the EHEM configurations since round 5) strict-identity mode as the "
+                    "HEADLINE: the reference's numpy float32 transform + quantiser on a prefetch thread one to two frames ahead")
+    ap.add_argument("--device-transform", action="store_true", help="headline with the device transform (rounds 1 - 4); the strict leg becomes the extra key")
+    ap.add_argument("--no-strict-leg", action="store_true", help="skip the second timed loop (the other transform mode)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the side legs (the other four workloads, the decoder, the CLI), which run as child processes "
+                    "after the headline, outside its timed region")
+    ap.add_argument("--leg-steps", type=int, default=10)
+    ap.add_argument("--leg-warmup", type=int, default=5)
     ap.add_argument("--oa-batch", type=int, default=None, help="OctAttention: windows per forward (OctAttnFrameEncoder.max_batch)")
     ap.add_argument("--decode", action="store_true", help="time the decoder (FrameDecoder) on the configuration's frame instead of the encoder")
     ap.add_argument("--decode-streams", type=int, default=1, help="with --decode: frames decoded CONCURRENTLY, each by its own FrameDecoder on its own host thread and "
@@ -167,7 +180,9 @@ KERNEL_OF = {   # launch-bracket tag -> (kernel name as rocprofv3 prints it, bou
     "gemm_f32": ("gemm_f32_kernel", "mfma_f32", "exact k-ordered fp32 layers feeding a kNN search"),
     "gemm_rows": ("gemm_bf16x3_kernel", "mfma", "dense layers reading fp32 rows (split in the tile)"),
     "oa_attention": ("oa_attn_f16x3_kernel", "mfma", "dual-stream causal attention, non-causal flop count (SURVEY.md 8d)"),
-    "edge_gather": ("edge_gather_max_kernel", "l2", "neighbour gather + max + BN + LeakyReLU: 20 gathered rows per point, served by L2 (priced against its 34.5 TB/s)"),
+    "edge_gather": ("edge_gather_max_kernel", "hbm", "neighbour gather + max + BN + LeakyReLU; algorithmic bytes = every u / v / output row once + the index lists; the 20 gathered "
+                    "rows per point are re-reads that fall out of L2: PMC 2.9 x the algorithmic bytes at 6.4 TB/s of HBM (profiles/r4_pmc_traffic.json) - the kernel runs at the achievable "
+                    "HBM ceiling on wasted traffic"),
     "cdf": ("cdf_kernel", "hbm", "softmax + serial fp32 cumsum -> (c_low, c_high)"),
     "geom": ("stage_G_front_and_context_kernels", "hbm", "front_transform_kernel, front_key_kernel, ctx_ehem_all_kernel (the sort and tree kernels between them are not bracketed)"),
     "split_rows": ("split_rows_kernel", "hbm", "fp32 rows -> hi / lo planes"),
@@ -342,8 +357,10 @@ def differing_points(enc, cfg, dev):
     keys = [f"{name}{lv}" for _, lv in enc.shells()]
     if any(k not in z.files for k in keys):
         return None
-    hq, _ = enc.host_ints(xyz)
-    host = [int((np.asarray(q) != z[k]).any(1).sum()) for q, k in zip(hq, keys)]
+    host = None
+    if hasattr(enc, "host_ints"):
+        hq, _ = enc.host_ints(xyz)
+        host = [int((np.asarray(q) != z[k]).any(1).sum()) for q, k in zip(hq, keys)]
     dq = enc.quantize(torch.from_numpy(xyz).to(dev))[0] if not enc.host_transform else None
     devc = None if dq is None else [int((q.cpu().numpy() != z[k]).any(1).sum()) for q, k in zip(dq, keys)]
     return dict(host_transform=host, device_transform=devc, reference="tests/golden/frame_ints.npz (the reference's proc_pc run on this frame)")
@@ -416,6 +433,79 @@ def run_decode(args, cfg, enc, model, dev, frame_host):
     print(json.dumps(out), flush=True)
 
 
+def _child_line(argv, timeout=900):
+    """Run this file as a CHILD process (the parent keeps its GPU context; nothing is exec'ed over it) and return its last JSON line."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
+    if line is None:
+        return {"error": f"exit code {r.returncode}: {r.stderr[-300:]}"}
+    return json.loads(line)
+
+
+def cli_leg(n_warm, n_timed):
+    """`.bin` files on disk -> `encode_mullevel.py --spher --lidar_level 16 --host_transform` -> `.bin` / `.dat` / side-info files written: the
+    reader (a1), the host -> device copy and the file writes are inside; frames/s from the per-frame `time(s)` lines (completion intervals of
+    the pipelined path) after the first `n_warm` frames."""
+    import subprocess
+    import tempfile
+    from scp_amd.synth import synth_frame, write_kitti_bin
+    n = n_warm + n_timed
+    with tempfile.TemporaryDirectory() as tmp:
+        seq = os.path.join(tmp, "seq00")
+        os.makedirs(seq)
+        for i in range(n):
+            write_kitti_bin(os.path.join(seq, f"{i:06d}.bin"), synth_frame(i))
+        cmd = [sys.executable, os.path.join(ROOT, "encode_mullevel.py"), "--test_files", os.path.join(seq, "*.bin"), "--type", "kitti", "--lidar_level", "16",
+               "--spher", "--random_weights", "0", "--out_dir", os.path.join(tmp, "out"), "--host_transform"]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp, timeout=900)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": r.stderr[-300:]}
+        times = [float(l.split(":")[1]) for l in r.stdout.splitlines() if l.startswith("time(s)")]
+        written = len([f for f in os.listdir(os.path.join(tmp, "out")) if f.endswith(".bin")])
+    steady = times[n_warm:]
+    fps = len(steady) / sum(steady)
+    return dict(fps=fps, ms_per_step=1e3 / fps, files=n, files_timed=len(steady), streams_written=written, process_wall_s=wall,
+                note="drop-in CLI (encode_mullevel.py -> scp_amd/cli.py), strict-identity transform on the reader thread, frames pipelined three deep; "
+                     "file read + parse + H2D + .bin / .dat / .scp.json writes inside; process start, weight preparation and the first frames excluded")
+
+
+def side_legs(args, out):
+    """The other four BASELINE.json workloads, the decoder and the CLI, after the headline and outside its timed region (N = 1 only)."""
+    torch.cuda.empty_cache()
+    common = ["--steps", str(args.leg_steps), "--warmup", str(args.leg_warmup), "--cpu-baseline", "none", "--no-legs", "--no-strict-leg"]
+
+    def brief(z):
+        if "error" in z:
+            return z
+        rf = z.get("roofline", {})
+        return dict(fps=z["value"], ms_per_step=z["ms_per_step"], steps=z["steps"], warmup=z["warmup"], bpp_mean=z.get("bpp_mean"),
+                    workload=z["config"]["workload"], transform=z["config"].get("transform"), frames_per_launch_sequence=z["config"].get("frames_per_launch_sequence"),
+                    nodes_per_frame=z["config"].get("nodes_per_frame"), strict_identity_verified=z.get("strict_identity_verified"),
+                    transform_parity=z.get("transform_parity"),
+                    roofline=dict(kernel=rf.get("kernel", "").split(":")[0], frac=rf.get("frac"), valid=rf.get("valid"), avg_launch_us=rf.get("avg_launch_us")),
+                    roofline_frame_frac_mfma=z.get("roofline_frame", {}).get("frac_mfma"))
+    rf = out["roofline"]
+    configs = {"ehem-L16-m": dict(fps=out["value"], ms_per_step=out["ms_per_step"], steps=out["steps"], warmup=out["warmup"], bpp_mean=out["bpp_mean"],
+                                  workload=out["config"]["workload"], transform=out["config"]["transform"], strict_identity_verified=out.get("strict_identity_verified"),
+                                  roofline=dict(kernel=rf["kernel"].split(":")[0], frac=rf["frac"], valid=rf["valid"], avg_launch_us=rf["avg_launch_us"]),
+                                  roofline_frame_frac_mfma=out["roofline_frame"]["frac_mfma"], note="the headline of this line")}
+    for name in ("ehem-L12-s", "ehem-F17-m", "octattn-L12-spher", "octattn-L14-cylin"):
+        extra = ["--steps", "16"] if name == "ehem-L12-s" else []      # BASELINE.json configs[1] is a batch of 16 frames
+        configs[name] = brief(_child_line(["--config", name] + common + extra))
+    out["configs"] = configs
+    z = _child_line(["--decode", "--steps", "3", "--warmup", "1"])
+    out["decode"] = z if "error" in z else dict(fps=z["value"], ms_per_step=z["ms_per_step"], steps=z["steps"], decoded_occupancy_equals_encoded=z["decoded_occupancy_equals_encoded"],
+                                               stage_ms=z.get("stage_ms"), host_cpu_ms_per_frame=z.get("host_cpu_ms_per_frame"), workload=z["config"]["workload"])
+    out["cli"] = cli_leg(args.leg_warmup, args.leg_steps)
+    if "fps" in out["cli"]:
+        out["cli_over_bench"] = out["cli"]["fps"] / out["value"]
+    out["legs_note"] = ("`configs` / `decode` / `cli`: child processes of this run, started after the headline's timed region; each is this file's own "
+                        "timed loop (barrier + synchronize on both sides) on that workload")
+
+
 def main():
     args = parse()
     if args.all_configs:
@@ -483,16 +573,17 @@ def main():
     def timed_loop(strict):
         """`--steps` frames through the pipelined encoder; strict: the reference's host transform one frame ahead on a worker thread.
         -> (dt of this rank before the barrier, dt after it, host CPU ms per frame, results)"""
-        ahead = IntsAhead(enc, frames_host, args.warmup, total) if strict else None
+        ahead = IntsAhead(enc, frames_host, args.warmup, total, ahead=max(2, 2 * batch)) if strict else None
         barrier()
         cpu0 = time.process_time()                      # CPU seconds of this rank, all threads (launch thread, coder worker, reader)
         t0 = time.perf_counter()
         # frame i is range-coded on a worker thread while frames i+1 .. i+depth run on the GPU; a handle pins its ~590 MB logits table,
         # so at most `depth` frames are in flight (memory stays O(depth), not O(steps))
         pending, results = [], []
-        if batch > 1 and not strict:      # `batch` frames per launch sequence, two batches in flight (the range coder of one under the kernels of the next)
+        if batch > 1:      # `batch` frames per launch sequence, two batches in flight (the range coder of one under the kernels of the next)
             for i in range(args.warmup, total, batch):
-                pending.append(enc.encode_batch_async(frames[i:min(total, i + batch)]))
+                j = min(total, i + batch)
+                pending.append(enc.encode_batch_async(frames[i:j], ints=[ahead.get(k) for k in range(i, j)] if strict else None))
                 if len(pending) > 1:
                     results += enc.finish_batch(pending.pop(0))
             for h in pending:
@@ -526,17 +617,20 @@ def main():
         enc.finish(enc.encode_async(frames[i]))
     if batch > 1:
         enc.finish_batch(enc.encode_batch_async(frames[:batch]))
-    headline_strict = bool(args.host_transform) and ehem
+    # Headline mode (round 5): STRICT IDENTITY for the EHEM configurations - the float -> integer step is the reference's own numpy arithmetic
+    # (enc.host_ints on a prefetch thread, inside the timed region), so the occupancy stream is the reference's bit for bit from the float
+    # frame on; `--device-transform` gives rounds 1 - 4's headline.  The other mode runs as a second timed loop and is reported beside it.
+    headline_strict = ehem and not args.device_transform
     dt_own, dt, cpu_ms, results = timed_loop(headline_strict)
-    strict = None
-    if ehem and world == 1 and not args.no_strict_leg and not headline_strict:
-        # the same frames once more with the reference's own float -> integer step (numpy, on a worker thread one frame ahead): what the
-        # strict-identity mode costs when it is overlapped the way cli.py overlaps it.  Per-frame launches (no --batch form).
-        s_own, s_dt, s_cpu, s_res = timed_loop(True)
-        strict = dict(fps=args.steps / s_dt, ms_per_step=1e3 * s_dt / args.steps, host_cpu_ms_per_frame=s_cpu,
-                      ratio_to_device_transform=(args.steps / s_dt) / (args.steps / dt), bpp_mean=float(np.mean([r["bpp"] for r in s_res])),
-                      note="enc.host_ints (numpy float32 transform + quantiser of data_preprocess.py:42-70,171-214) on one worker thread one to two "
-                           "frames ahead, inside the timed region; everything after the integers on the device as in the headline")
+    other = None
+    if ehem and world == 1 and not args.no_strict_leg:
+        s_own, s_dt, s_cpu, s_res = timed_loop(not headline_strict)
+        other = dict(fps=args.steps / s_dt, ms_per_step=1e3 * s_dt / args.steps, host_cpu_ms_per_frame=s_cpu,
+                     ratio_to_headline=(args.steps / s_dt) / (args.steps / dt), bpp_mean=float(np.mean([r["bpp"] for r in s_res])),
+                     note=("the same frames with the transform + quantiser on the device (front_transform_kernel: float64 atan2 / acos rounded once - more accurate "
+                           "than numpy's float32 routines, hence not always the reference's integers: see transform_parity)") if headline_strict else
+                          ("enc.host_ints (numpy float32 transform + quantiser of data_preprocess.py:42-70,171-214) on one worker thread one to two "
+                           "frames ahead, inside the timed region; everything after the integers on the device as in the headline"))
     rank_stats = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -603,8 +697,9 @@ def main():
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": cfg["workload"] + ", seeded random weights", "nodes_per_frame": int(n_nodes), "windows_per_frame": windows,
                        "frames_per_gpu": args.steps, "frames_in_flight": args.depth if batch == 1 else 2 * batch, "frames_per_launch_sequence": batch,
-                       "transform": "host-numpy on a prefetch thread (strict identity)" if (headline_strict or enc.host_transform) else "device",
-                       "parallelism": f"frame-sharded x{world}", "rank_cores": len(pinned) if pinned else None},
+                       "transform": "host-numpy on a prefetch thread (strict identity: the reference's integers)" if (headline_strict or enc.host_transform) else "device",
+                       "parallelism": f"frame-sharded x{world}", "rank_cores": len(pinned) if pinned else len(os.sched_getaffinity(0)),
+                       "rank_cores_pinned": bool(pinned)},
             "rccl_world": dist.get_world_size() if world > 1 else 1, "dist_backend": backend if world > 1 else None,
             "host_cpu_ms_per_frame": cpu_ms,
             "bpp_mean": float(summ[0] / summ[4]),
@@ -636,11 +731,25 @@ def main():
                       "frac": bytes_G / st["geom"] / 1e9 / HBM_PEAK_GBS, "bytes": bytes_G, "note": "host wall time of the whole stage incl. its small D2H syncs"},
                 "C": {"bound": "hbm", "achieved": bytes_C / st["cdf"] / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": bytes_C / st["cdf"] / 1e9 / HBM_PEAK_GBS, "bytes": bytes_C, "note": "includes the 4 B/node D2H copy"}}
-            if strict is not None:
-                out["strict_identity"] = strict
-                out["strict_identity_fps"] = strict["fps"]
+            if other is not None:
+                out["device_transform" if headline_strict else "strict_identity"] = other
+                out["strict_identity_fps"] = out["value"] if headline_strict else other["fps"]
+                out["device_transform_fps"] = other["fps"] if headline_strict else out["value"]
             try:
                 out["transform_parity"] = differing_points(enc, cfg, dev)
+            except Exception as e:
+                out["transform_parity"] = {"error": str(e)}
+            tp = out["transform_parity"]
+            if headline_strict and tp is not None and "host_transform" in tp:
+                # asserted in-run: the headline's integers ARE the reference's (tests/golden/frame_ints.npz, written by running the reference's proc_pc)
+                out["strict_identity_verified"] = all(v == 0 for v in tp["host_transform"])
+                if not out["strict_identity_verified"]:
+                    raise SystemExit(f"strict-identity headline, but the host transform's integers differ from the reference's: {tp}")
+            elif headline_strict:
+                out["strict_identity_verified"] = None      # no reference integers for this workload's frames (Ford-like) in tests/golden/
+        if not ehem:
+            try:
+                out["transform_parity"] = differing_points(enc, cfg, dev)     # OctAttention legs run the device transform: how many points it misses
             except Exception as e:
                 out["transform_parity"] = {"error": str(e)}
         if rank_stats:
@@ -654,6 +763,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(cfg, frames_host[-1], full=mode == "full")
             except Exception as e:   # the baseline is a reported number, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        if world == 1 and not args.no_legs and args.config == "ehem-L16-m":
+            try:
+                side_legs(args, out)
+            except Exception as e:     # a leg is extra information, never a reason to lose the headline
+                out["legs_error"] = repr(e)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -39,8 +39,10 @@ extern "C" {
  *        the process-wide numeric-profile setters and the debug hooks moved to scp_debug.h, scp_ctx replaces the setters.
  *   210  scp_mlp_split_fused is gone (round 4: the Swin blocks run on scp_swin_ln_linear / scp_swin_post_attn, which supersede it; two
  *        scp_linear_split calls give its bits); scp_geom_build takes float xyz through scp_geom_build_xyz as well (stage G in one
- *        launch sequence); scp_debug.h gained the launch brackets scp_prof_*. */
-#define SCP_ABI_VERSION 210
+ *        launch sequence); scp_debug.h gained the launch brackets scp_prof_*.
+ *   220  GELU (round 5, numeric profile ehem/5): max(y, 0) - |y| exp(-beta y^2) / P4(|y|) instead of the degree-12 erf polynomial, in every
+ *        kernel that applies it; scp_swin_post_attn expects fc1 scaled by scp_gelu_prescale() and fc2 by its inverse. */
+#define SCP_ABI_VERSION 220
 SCP_API int scp_version(void);
 SCP_API int scp_last_hip_error(void);
 /* number of HIP devices visible / name of device 0 (for bench reports) */
@@ -428,7 +430,8 @@ SCP_API int scp_packed_plan(const int64_t *lengths, int32_t W, int64_t *tables_d
  *                        scp_swin_post_attn_weight_bytes() bytes = tiled planes proj hi | fc1 hi | fc2 hi | proj lo | fc1 lo | fc2 lo,
  *                        proj [256][256], fc1 = (W1 diag(gamma))[:, P] [1024][256], fc2 = W2[:, P] [256][1024], P = inside every
  *                        16 columns, columns 4-7 and 8-11 change places (the order in which an MFMA accumulator holds a row's
- *                        channels); b1 = fc1 bias + W1 beta.
+ *                        channels); b1 = fc1 bias + W1 beta.  Since version 220 the kernel evaluates GELU in the variable s y
+ *                        (s = scp_gelu_prescale()): the caller multiplies fc1 (weight and b1) by s and divides fc2's weight by s.
  * Results are per row: independent of M, of the row's position and of what else is in the launch.
  * ----------------------------------------------------------------------------------------------  * tile_list (device int32 [n_tiles], ascending; may be NULL = every tile): the 128-row tiles to process.  The packed forward passes the
  * tiles that hold at least one real row: tiles of nothing but window padding (4.7 % of a level-16 multi-level frame) keep their old
@@ -439,6 +442,7 @@ SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int64_t ldo_in,
                                const float *b1, const float *b2, float eps, float *out, int64_t ldc, int32_t M, const int32_t *tile_list,
                                int32_t n_tiles, void *stream);
 SCP_API int64_t scp_swin_post_attn_weight_bytes(void);
+SCP_API double scp_gelu_prescale(void);
 
 /* SwinPatchMerging (swin_transformer.py:350-384) in one launch: out[m] = LayerNorm(cat(x[ia[m]], x[ib[m]])) . W^T for M merged rows (the
  * reduction has no bias).  x: fp32 [n_src][ldx] (256 channels; an index equal to n_src stands for a row of zeros - the pad of an odd

@@ -31,6 +31,7 @@ SCP_API int scp_rc_debug_buffer(unsigned long long *dev_buf);
  * sweeps its keys against the fixed reference 0 first (P = exp2(S), no running maximum) and falls back to the standard online softmax only if a
  * row sum left [2^-100, 2^100]; 0 = the standard form only (what the fallback computes).  The two differ in the last bits. */
 SCP_API int scp_set_attention_variant(int32_t v);
+SCP_API int scp_get_attention_variant(void);   /* 1 = default; anything else is written into the stream's numeric profile (attnv=) */
 /* persistent workgroups of the row-chain launches (0 = one per CU of the device): for launches on a stream created with a CU mask
  * (tools/mb_cumask.py), whose CU set is smaller than the device's */
 SCP_API int scp_rc_set_grid(int32_t workgroups);
@@ -53,7 +54,7 @@ enum {
     SCP_PROF_GEMM_SPLIT = 6,   /* gemm_split_kernel, all variants: 2 M N K flop                                         */
     SCP_PROF_EDGE_MLP = 7,     /* rc_edge_mlp_kernel: 2 M (448*256 + 2*256*256 + 512*256 + 256*256 + 256*128) flop      */
     SCP_PROF_MERGE = 8,        /* rc_merge_kernel: 2 M 512 256 flop                                                     */
-    SCP_PROF_EDGE_GATHER = 9,  /* edge_gather_max_kernel: n k C' 4 bytes                                                */
+    SCP_PROF_EDGE_GATHER = 9,  /* edge_gather_max_kernel: n (3 C' 4 + 4 k) bytes: u, v, out rows once + the index lists        */
     SCP_PROF_CDF = 10,         /* cdf_kernel: n (4 nsym + 4) bytes                                                      */
     SCP_PROF_GEMM_F32 = 11,    /* gemm_f32_kernel: 2 M N K flop                                                         */
     SCP_PROF_GEMM_ROWS = 12,   /* gemm_bf16x3_kernel (fp32 activation rows; F16 form too): 2 M N K flop                 */

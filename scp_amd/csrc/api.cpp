@@ -1,5 +1,6 @@
 // Library-level entry points of libscp_hip.so.
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -65,8 +66,9 @@ int scp_ctx_attention_mode() { return t_ctx ? t_ctx->attn_bf16x3 : -1; }
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Launch brackets (scp_debug.h): two hipEvents per bracketed launch, recorded inside the C ABI around the hipLaunchKernelGGL itself.
-int g_scp_prof_on = 0;
+std::atomic<int> g_scp_prof_on{0};
 namespace {
+unsigned g_prof_gen = 0;             // bumped whenever scp_prof_enable(1) clears the records: a scope that began before the clear ends nowhere
 struct ProfRec { int tag; double work; hipEvent_t e0, e1; bool ended; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
@@ -81,7 +83,7 @@ hipEvent_t prof_event() {
 
 void ScpProfScope::begin(int tag, double work) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (!g_scp_prof_on || g_prof.size() >= 65536) return;
+    if (!g_scp_prof_on.load(std::memory_order_relaxed) || g_prof.size() >= 65536) return;
     ProfRec r{tag, work, prof_event(), prof_event(), false};
     if (!r.e0 || !r.e1 || hipEventRecord(r.e0, st) != hipSuccess) {
         if (r.e0) g_prof_pool.push_back(r.e0);
@@ -89,10 +91,12 @@ void ScpProfScope::begin(int tag, double work) {
         return;
     }
     slot = (int)g_prof.size();
+    gen = g_prof_gen;
     g_prof.push_back(r);
 }
 void ScpProfScope::end() {
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (gen != g_prof_gen) return;      // the records this scope belongs to were cleared meanwhile (another thread's scp_prof_enable(1))
     if (slot < (int)g_prof.size() && !g_prof[slot].ended && hipEventRecord(g_prof[slot].e1, st) == hipSuccess) g_prof[slot].ended = true;
 }
 
@@ -101,8 +105,9 @@ extern "C" int scp_prof_enable(int32_t on) {
     if (on) {
         for (auto &r : g_prof) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
         g_prof.clear();
+        ++g_prof_gen;
     }
-    g_scp_prof_on = on ? 1 : 0;
+    g_scp_prof_on.store(on ? 1 : 0, std::memory_order_relaxed);
     return SCP_OK;
 }
 extern "C" int scp_prof_count(void) {
@@ -154,20 +159,37 @@ int pin_take(size_t bytes, void *dst, char **at) {
 }
 }  // namespace
 
+// The staging is transactional: an item is queued only once its copy has been enqueued (a failed copy takes its item back), and a caller that
+// leaves between a read-back and its scp_stream_wait drops what it queued with scp_d2h_abort (SCP_D2H_TRY in geom.hip) - the destinations are
+// stack and local-vector addresses, which the NEXT wait of this thread must never write to.
+static int pin_untake(int rc_hip) {
+    PinStage &s = g_pin;
+    s.used = s.items.back().off;
+    s.items.pop_back();
+    g_scp_last_hip_error = rc_hip;
+    return SCP_EHIP;
+}
+
 int scp_d2h_async(void *dst, const void *src, size_t bytes, hipStream_t st) {
     char *at;
     const int rc = pin_take(bytes, dst, &at);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(at, src, bytes, hipMemcpyDeviceToHost, st));
-    return SCP_OK;
+    const hipError_t e = hipMemcpyAsync(at, src, bytes, hipMemcpyDeviceToHost, st);
+    return e == hipSuccess ? SCP_OK : pin_untake((int)e);
 }
 
 int scp_d2h_2d_async(void *dst, const void *src, size_t spitch, size_t width, size_t height, hipStream_t st) {
     char *at;
     const int rc = pin_take(width * height, dst, &at);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy2DAsync(at, width, src, spitch, width, height, hipMemcpyDeviceToHost, st));
-    return SCP_OK;
+    const hipError_t e = hipMemcpy2DAsync(at, width, src, spitch, width, height, hipMemcpyDeviceToHost, st);
+    return e == hipSuccess ? SCP_OK : pin_untake((int)e);
+}
+
+void scp_d2h_abort() {
+    PinStage &s = g_pin;
+    s.items.clear();
+    s.used = 0;
 }
 
 static int stream_wait_event(hipStream_t st) {

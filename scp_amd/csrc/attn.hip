@@ -607,8 +607,11 @@ extern "C" SCP_API int scp_swin_kv_planes(const float *k, const float *v, int64_
     return SCP_OK;
 }
 
-static int g_attn_variant = 1;
-extern "C" SCP_API int scp_set_attention_variant(int32_t v) { g_attn_variant = v; return SCP_OK; }
+// process-wide test / A-B bracket (scp_debug.h).  It changes the logits' last bits, so the host writes a non-default value into the stream's
+// numeric profile (native.numeric_profile: ",attnv=0") and a decoder running the other variant refuses the stream.
+static std::atomic<int> g_attn_variant{1};
+extern "C" SCP_API int scp_set_attention_variant(int32_t v) { g_attn_variant.store(v ? 1 : 0, std::memory_order_relaxed); return SCP_OK; }
+extern "C" SCP_API int scp_get_attention_variant(void) { return g_attn_variant.load(std::memory_order_relaxed); }
 
 // packed window attention on those planes (q fp32 [rows][ldq]); out fp32 [rows][256] or (ohi, olo) planes [rows][ldo]
 extern "C" SCP_API int scp_swin_attention_packed_planes(const float *q, const void *khi, const void *klo, const void *vthi, const void *vtlo,
@@ -621,7 +624,7 @@ extern "C" SCP_API int scp_swin_attention_packed_planes(const float *q, const vo
     SCP_PROF(SCP_PROF_ATTENTION, stream, (double)total_windows * WIN * 2.0 * 2.0 * WIN * NH * HD);
 #define ATTN_GO(V) hipLaunchKernelGGL(swin_attn_planes_kernel<V>, dim3(total_windows * NH * (WIN / QT)), dim3(256), PNS * PST, (hipStream_t)stream, q, (const __bf16 *)khi, \
                                       (const __bf16 *)klo, (const __bf16 *)vthi, (const __bf16 *)vtlo, bias_table, shift, ldq, out, wtab, (__bf16 *)ohi, (__bf16 *)olo, ldo, valid)
-    if (g_attn_variant == 0) ATTN_GO(false); else ATTN_GO(true);
+    if (g_attn_variant.load(std::memory_order_relaxed) == 0) ATTN_GO(false); else ATTN_GO(true);
 #undef ATTN_GO
     LAUNCH_CHECK();
     return SCP_OK;
@@ -644,7 +647,7 @@ static int attn_packed(const float *q, const float *k, const float *v, const flo
         (ohi && (!olo || ldo < NH * HD || (ldo & 3) || (((uintptr_t)ohi | (uintptr_t)olo) & 7))))
         return SCP_EINVAL;
     SCP_PROF(SCP_PROF_ATTENTION, stream, (double)total_windows * WIN * 2.0 * 2.0 * WIN * NH * HD);
-    if (attn_bf16x3() && g_attn_variant == 0)
+    if (attn_bf16x3() && g_attn_variant.load(std::memory_order_relaxed) == 0)
         hipLaunchKernelGGL(swin_attn_bf16x3_kernel<false>, dim3(total_windows * NH * (WIN / QT)), dim3(256), 0, (hipStream_t)stream, q, k, v, bias_table,
                            0, shift, ldq, ldkv, out, wtab, ohi, olo, ldo);
     else if (attn_bf16x3())
@@ -678,7 +681,7 @@ extern "C" int scp_swin_attention(const float *q, const float *k, const float *v
         return SCP_EINVAL;
     const int nblk = B * (Lp / WIN) * NH * (WIN / QT);
     SCP_PROF(SCP_PROF_ATTENTION, stream, (double)B * Lp * 2.0 * 2.0 * WIN * NH * HD);
-    if (attn_bf16x3() && g_attn_variant == 0)
+    if (attn_bf16x3() && g_attn_variant.load(std::memory_order_relaxed) == 0)
         hipLaunchKernelGGL(swin_attn_bf16x3_kernel<false>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, q, k, v, bias_table, Lp, shift, ldq, ldkv, out,
                            (const int *)nullptr, (__bf16 *)nullptr, (__bf16 *)nullptr, (int64_t)0);
     else if (attn_bf16x3())

@@ -59,7 +59,9 @@ extern "C" SCP_API int scp_edge_gather_max_ld(const float *u, int64_t ldu, const
         (out_stride & 3) || ldu < Cout || ldv < Cout || (ldu & 3) || (ldv & 3) || (((uintptr_t)out | (uintptr_t)u | (uintptr_t)v) & 15))
         return SCP_EINVAL;
     const int64_t total = (int64_t)B * n * (Cout / 4);
-    SCP_PROF(SCP_PROF_EDGE_GATHER, stream, 4.0 * B * n * (double)k * Cout);
+    // algorithmic HBM bytes: every u row, every v row and every output row once, and the index lists (the 20 gathered rows per point are
+    // re-reads; PMC: the kernel pulls 2.9 x this through HBM at 6.4 TB/s, profiles/r4_pmc_traffic.json)
+    SCP_PROF(SCP_PROF_EDGE_GATHER, stream, (double)B * n * (12.0 * Cout + 4.0 * k));
     hipLaunchKernelGGL(edge_gather_max_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, u, v, idx, scale,
                        shift, n, Cout, k, out, out_stride, total, ldu, ldv);
     LAUNCH_CHECK();

@@ -31,31 +31,7 @@ enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_GELU = 2, ACT_RELU = 3 };
 template <int act>
 __device__ __forceinline__ float apply_act(float y) {
     if (act == ACT_LEAKY) return y > 0.f ? y : 0.01f * y;
-    if (act == ACT_GELU) {
-        // exact-erf GELU, 0.5 y (1 + erf(y / sqrt 2)).  erf(z) = z P(u), u = 2 z^2 / 3.5^2 - 1 on |z| <= 3.5 (clamped beyond: 1 - erf(3.5)
-        // = 7e-7), P = degree-12 minimax fit in the well-conditioned shifted variable: |erf error| < 5e-7, i.e. 2e-6 absolute on the
-        // activation - an order of magnitude below the bf16x3 product error.  15 FMA-class instructions and no transcendental
-        // (the rcp + exp form it replaces cost about twice that on the VALU, as much as the MFMA main loop of a K = 256 tile).
-        const float z = y * 0.70710678118654752f;
-        const float zc = fminf(fabsf(z), 3.5f);
-        const float u = fmaf(zc * zc, 2.0f / 12.25f, -1.0f);
-        float p = 1.480935152e-03f;
-        p = fmaf(p, u, -3.987360327e-03f);
-        p = fmaf(p, u, 4.474287011e-03f);
-        p = fmaf(p, u, -7.227925849e-03f);
-        p = fmaf(p, u, 1.704961757e-02f);
-        p = fmaf(p, u, -3.003174999e-02f);
-        p = fmaf(p, u, 4.501544287e-02f);
-        p = fmaf(p, u, -6.477065166e-02f);
-        p = fmaf(p, u, 8.840217622e-02f);
-        p = fmaf(p, u, -1.146127499e-01f);
-        p = fmaf(p, u, 1.467501802e-01f);
-        p = fmaf(p, u, -2.007010379e-01f);
-        p = fmaf(p, u, 4.038729840e-01f);
-        const float e = copysignf(p * zc, z);
-        const float hy = 0.5f * y;
-        return fmaf(hy, e, hy);
-    }
+    if (act == ACT_GELU) return scp_gelu(y);     // exact-erf GELU to 4.4e-7 absolute: scp_internal.h (round 5; the degree-12 erf polynomial of rounds 1 - 4 is gone)
     if (act == ACT_RELU) return y > 0.f ? y : 0.f;
     return y;
 }

@@ -149,6 +149,7 @@ static DevBuf g_qtmp;  // transform scratch for scp_quantize when the caller doe
 extern "C" int scp_quantize(const float *xyz, int64_t n, int32_t mode, double qs, double cart_offset, int32_t *q_out,
                             float *tr_out, scp_quant_info *info, void *stream) {
     if (!xyz || !q_out || !info || n <= 0 || mode < 0 || mode > 2 || !(qs > 0)) return SCP_EINVAL;
+    scp_d2h_abort();
     hipStream_t st = (hipStream_t)stream;
     int rc = g_qtmp.reserve((size_t)n * 12 + 64);
     if (rc) return rc;
@@ -162,8 +163,8 @@ extern "C" int scp_quantize(const float *xyz, int64_t n, int32_t mode, double qs
     hipLaunchKernelGGL(transform_kernel, dim3(nb), dim3(WG), 0, st, xyz, n, mode, tr, red);
     LAUNCH_CHECK();
     uint32_t h[2];
-    { const int rcd = scp_d2h_async(h, red, 8, st); if (rcd) return rcd; }
-    { const int rcw = scp_stream_wait(st); if (rcw) return rcw; }
+    SCP_D2H_TRY(scp_d2h_async(h, red, 8, st));
+    SCP_D2H_TRY(scp_stream_wait(st));
     const float rho_max = ord2f_host(h[0]), z_min = ord2f_host(h[1]);
 
     QuantParams p;
@@ -185,8 +186,8 @@ extern "C" int scp_quantize(const float *xyz, int64_t n, int32_t mode, double qs
     hipLaunchKernelGGL(quantize_kernel, dim3(nb), dim3(WG), 0, st, (const float *)tr, n, p, q_out, (int32_t *)(red + 2));
     LAUNCH_CHECK();
     int32_t hm[2];
-    { const int rcd = scp_d2h_async(hm, red + 2, 8, st); if (rcd) return rcd; }
-    { const int rcw = scp_stream_wait(st); if (rcw) return rcw; }
+    SCP_D2H_TRY(scp_d2h_async(hm, red + 2, 8, st));
+    SCP_D2H_TRY(scp_stream_wait(st));
     info->max_coord = hm[0];
     info->min_coord = hm[1];
     return hm[1] < 0 ? SCP_EINVAL : SCP_OK;
@@ -458,9 +459,9 @@ static int geom_build_sorted(scp_geom *g, scp_segment_info *info, int dmax, hipS
     LAUNCH_CHECK();
     std::vector<SegTab> back(nseg);
     std::vector<uint32_t> lvl_first(lmax + 2, 0u);
-    { const int rcd = scp_d2h_async(back.data(), dtab, sizeof(SegTab) * nseg, st); if (rcd) return rcd; }
-    { const int rcd = scp_d2h_2d_async(lvl_first.data(), blk, (size_t)nblk * 4, 4, lmax + 2, st); if (rcd) return rcd; }
-    { const int rcw = scp_stream_wait(st); if (rcw) return rcw; }
+    SCP_D2H_TRY(scp_d2h_async(back.data(), dtab, sizeof(SegTab) * nseg, st));
+    SCP_D2H_TRY(scp_d2h_2d_async(lvl_first.data(), blk, (size_t)nblk * 4, 4, lmax + 2, st));
+    SCP_D2H_TRY(scp_stream_wait(st));
 
     // --- per-segment level tables (host, tiny) --------------------------------------------------------------
     int64_t node_base = 0, leaf_base = 0;
@@ -562,6 +563,7 @@ static inline int depth_of(int32_t mx) {
 extern "C" int scp_geom_build(scp_geom *g, const int32_t *q, int64_t n, const scp_segment *segs, int32_t nseg,
                               scp_segment_info *info, void *stream) {
     if (!g || !q || !segs || !info || n <= 0 || nseg <= 0 || nseg > SCP_MAX_SEGMENTS) return SCP_EINVAL;
+    scp_d2h_abort();                           // nothing a failed earlier call of this thread queued may land in this call's buffers
     hipStream_t st = (hipStream_t)stream;
     int64_t maxcount = 0;
     int rc = geom_take_segments(g, segs, nseg, n, &maxcount);
@@ -575,8 +577,8 @@ extern "C" int scp_geom_build(scp_geom *g, const int32_t *q, int64_t n, const sc
     HIP_TRY(hipMemcpyAsync(dtab, g->segs.data(), sizeof(SegTab) * nseg, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(seg_minmax_kernel, dim3(std::min(grid_for(maxcount * 3), 64), nseg), dim3(WG), 0, st, q, (const SegTab *)dtab, g->red.as<int32_t>());
     LAUNCH_CHECK();
-    { const int rcd = scp_d2h_async(red.data(), g->red.p, red.size() * 4, st); if (rcd) return rcd; }
-    { const int rcw = scp_stream_wait(st); if (rcw) return rcw; }
+    SCP_D2H_TRY(scp_d2h_async(red.data(), g->red.p, red.size() * 4, st));
+    SCP_D2H_TRY(scp_stream_wait(st));
     int dmax = 0;
     for (int s = 0; s < nseg; ++s) {
         const int32_t mx = red[2 * s], mn = red[2 * s + 1];
@@ -721,6 +723,7 @@ extern "C" int scp_geom_build_xyz(scp_geom *g, const float *const *frames, const
     if (!g || !frames || !n_points || !qs || !shells || !qinfo || !info || nframes <= 0 || nshell <= 0 || mode < 0 || mode > 2 ||
         (int64_t)nframes * nshell > SCP_MAX_SEGMENTS)
         return SCP_EINVAL;
+    scp_d2h_abort();
     const int nseg = nframes * nshell;
     hipStream_t st = (hipStream_t)stream;
     int64_t npts = 0, maxn = 0;
@@ -757,8 +760,8 @@ extern "C" int scp_geom_build_xyz(scp_geom *g, const float *const *frames, const
                            g->tr.as<float>(), dred);
     }
     LAUNCH_CHECK();
-    { const int rcd = scp_d2h_async(red.data(), dred, red.size() * 4, st); if (rcd) return rcd; }
-    { const int rcw = scp_stream_wait(st); if (rcw) return rcw; }                 // read-back 1 of 2: the extrema fix the steps and the depths
+    SCP_D2H_TRY(scp_d2h_async(red.data(), dred, red.size() * 4, st));
+    SCP_D2H_TRY(scp_stream_wait(st));                 // read-back 1 of 2: the extrema fix the steps and the depths
 
     std::vector<FrontSeg> fs(nseg);
     int dmax = 0;

@@ -218,6 +218,55 @@ struct RcLnLinArgs {
 // All LDS traffic of the loop is inline asm with hand-counted waits: the compiler's wait insertion cannot see across asm, and what it
 // inserts for its own LDS reads drains the read-ahead.
 #define RC_SB __builtin_amdgcn_sched_barrier(0)
+// Behind a step's barrier the four waves of a workgroup run the same instruction stream in lockstep, one per SIMD - and reach every one of the
+// next step's 16 LDS-DMA pieces (1 KiB each: 16 cycles of the CU's one 64 B / cycle address path) in the same cycle: a piece then holds its wave's
+// issue until the three in front of it are through.  RC_SKEW > 0 delays wave w by w x RC_SKEW rounds of ~16 cycles right behind the barrier
+// (a scalar loop inside the barrier's own asm statement: the step stays one basic block for the compiler), so the waves' pieces arrive in turn.
+#ifndef RC_SKEW
+#define RC_SKEW 0
+#endif
+#if RC_SKEW > 0
+#define RC_STEP_BARRIER(WAITS, w)                                                                                                          \
+    do {                                                                                                                                   \
+        int _rc_n;                                                                                                                         \
+        asm volatile("s_waitcnt " WAITS "\n\ts_barrier\n\ts_mov_b32 %0, %1\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lrcskew_done%=\n"          \
+                     ".Lrcskew_loop%=:\n\ts_nop 7\n\ts_sub_u32 %0, %0, 1\n\ts_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 .Lrcskew_loop%=\n"              \
+                     ".Lrcskew_done%=:"                                                                                                   \
+                     : "=&s"(_rc_n) : "s"((w) * RC_SKEW) : "memory", "scc");                                                                \
+    } while (0)
+#else
+#ifdef RC_PROBE_NOBAR
+#define RC_STEP_BARRIER(WAITS, w) asm volatile("s_waitcnt " WAITS ::: "memory")
+#else
+#define RC_STEP_BARRIER(WAITS, w) asm volatile("s_waitcnt " WAITS "\n\ts_barrier" ::: "memory")
+#endif
+#endif
+// Timing probes of the post-attention kernel's steps (WRONG results; tools/r5_step_probe.sh): RC_PROBE_NODMA no LDS-DMA pieces inside the steps,
+// RC_PROBE_NOFRAG no fragment reads (and no waits for them) inside the steps, RC_PROBE_NOBAR no workgroup barrier per step
+#ifdef RC_PROBE_NODMA
+#define RC_PROBE_DMA_ON 0
+#else
+#define RC_PROBE_DMA_ON 1
+#endif
+#ifdef RC_PROBE_NOFRAG
+#define RC_PROBE_FRAG_ON 0
+#else
+#define RC_PROBE_FRAG_ON 1
+#endif
+// RC_DMA_SPREAD: the 16 pieces of a step over slices 0 - 11 (two per slice in slices 0 - 3, one per slice afterwards; the barrier of slice 15
+// must find them landed) instead of two per slice over the first eight
+#ifdef RC_DMA_SPREAD
+#define RC_DMA_P(s, gap) ((s) < 4 ? 2 * (s) + ((gap) == 3) : (s) + 4)
+#define RC_DMA_HERE(s, gap) (((s) < 4 && ((gap) == 1 || (gap) == 3)) || ((s) >= 4 && (s) < 12 && (gap) == 1))
+#define RC_DMA_SLOT(s, gap) (RC_DMA_P(s, gap) >> 3)
+#define RC_DMA_IDX(s, gap) ((RC_DMA_P(s, gap) >> 1) & 3)
+#define RC_DMA_PLANE(s, gap) (RC_DMA_P(s, gap) & 1)
+#else
+#define RC_DMA_HERE(s, gap) ((s) < 8 && ((gap) == 1 || (gap) == 3))
+#define RC_DMA_SLOT(s, gap) ((s) >> 2)
+#define RC_DMA_IDX(s, gap) ((s) & 3)
+#define RC_DMA_PLANE(s, gap) ((gap) >> 1)
+#endif
 #ifdef RC_WAIT0
 #define RC_FRAG_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #else
@@ -248,9 +297,9 @@ __device__ __forceinline__ void rc_ll_step(const RcLane &L, const RcLnLinArgs &a
         if (st && (s == 1 || s == 8 || s == 15)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); st[s == 1 ? 0 : s == 8 ? 1 : 2] += t - ts0; ts0 = t; }
         if (s == 15) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              // next step's slots landed; every wave is done reading this half's
-            if (PROBE) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            else if (LOADX) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            if (PROBE) RC_STEP_BARRIER("vmcnt(0)", L.w);
+            else if (LOADX) RC_STEP_BARRIER("vmcnt(24)", L.w);
+            else RC_STEP_BARRIER("vmcnt(8)", L.w);
             if (st) { const unsigned long long t = __builtin_amdgcn_s_memtime(); st[3] += t - ts0; ts0 = t; }
         }
         RC_SB;
@@ -558,8 +607,8 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
 //   then          Y += x + bp  (x1 = the new residual stream), LayerNorm statistics, normalised rows -> hi/lo B fragments IN PLACE of O
 //   step 4        P1(0), P1(1)   acc1[c] = W1'[32 c .. 32 c + 31][:] . X^T              (hidden chunk c = 32 hidden units)
 //   steps 5 - 36  body(c), c = 0 .. 31: per slice one k-step of P1(c + 2) (chain acc1[c & 1]) and one of P2(c): Y[blk] += W2[32 blk ..]
-//                 [hidden chunk c] . H(c)^T (chain Y[blk], blk = slice >> 1), and in the gaps GELU(c + 1): acc1[(c + 1) & 1] + b1' ->
-//                 exact-erf GELU -> hi/lo split -> the B fragments of P2(c + 1).  The accumulator layout IS the fragment layout (lane =
+//                 [hidden chunk c] . H(c)^T (chain Y[blk], blk = slice >> 1), and in the gaps GELU(c + 1): acc1[(c + 1) & 1] (started from
+//                 b1') -> GELU (rc_gelu_stage) -> hi/lo split -> the B fragments of P2(c + 1).  The accumulator layout IS the fragment layout (lane =
 //                 row, 8 consecutive registers = one k-step) up to a fixed permutation of each 16 channels (rc_perm16), which the caller
 //                 applies to the K axis of W1' and to the hidden axis of W2 when it tiles them.
 //   then          Y + b2 -> fp32 rows out (bounce buffer, whole 128-byte lines).
@@ -569,8 +618,9 @@ struct RcPostArgs {
     const __bf16 *Ohi, *Olo; int64_t ldo_in;    // attention output planes [M][ldo_in] (256 columns)
     const float *x; int64_t ldx;                // residual stream in, fp32 [M][ldx]
     const void *W;                              // ONE buffer: tiled planes proj hi | fc1 hi | fc2 hi | proj lo | fc1 lo | fc2 lo (RC_W_*):
-                                                //   proj [256][256]; fc1 = (W1 diag(gamma))[:, perm16] [1024][256]; fc2 = W2[:, perm16] [256][1024]
-    const float *bp, *b1, *b2;                  // [256], [1024] (= b1 + W1 beta), [256]
+                                                //   proj [256][256]; fc1 = s (W1 diag(gamma))[:, perm16] [1024][256]; fc2 = W2[:, perm16] / s [256][1024]
+                                                //   (s = scp_gelu_prescale(): the activation is evaluated in the variable s y, scp_internal.h)
+    const float *bp, *b1, *b2;                  // [256], [1024] (= s (b1 + W1 beta)), [256]
     float *out; int64_t ldc;                    // residual stream out, fp32 [M][ldc] (may be x)
     int M;
     float eps;
@@ -627,12 +677,12 @@ __device__ __forceinline__ void rc_gemm_step(const RcLane &L, char *smem, int ha
     char *nxt = smem + (half ^ 1) * (2 * RC_SLOT);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        if (s == 15) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s == 15) RC_STEP_BARRIER("vmcnt(0) lgkmcnt(0)", L.w);
         RC_SB;
         const int nb = (s + 1) & 1, ns = (s + 1) & 15;
 #pragma unroll
         for (int gap = 0; gap < 6; ++gap) {
-            if (gap < 4) { RC_FRAG_WAIT(); RC_SB; }   // the fragment this MFMA is the first to use (see rc_ll_step)
+            if (gap < 4 && RC_PROBE_FRAG_ON) { RC_FRAG_WAIT(); RC_SB; }   // the fragment this MFMA is the first to use (see rc_ll_step)
             if (gap == 0) RC_MFMA_AVA(c0, A[s & 1][1], Bh[s]);
             if (gap == 1) RC_MFMA_AVA(c1, A[s & 1][3], Bh[s]);
             if (gap == 2) RC_MFMA_AVV(c0, A[s & 1][0], Bl[s]);
@@ -640,14 +690,14 @@ __device__ __forceinline__ void rc_gemm_step(const RcLane &L, char *smem, int ha
             if (gap == 4) RC_MFMA_AVA(c0, A[s & 1][0], Bh[s]);
             if (gap == 5) RC_MFMA_AVA(c1, A[s & 1][2], Bh[s]);
             RC_SB;
-            if (s < 15) {
+            if (s < 15 && RC_PROBE_FRAG_ON) {
                 const unsigned ra = (ns & 1) ? f.r1 : f.r0;
                 if (gap == 0) RC_DS_READ(A[nb][1], ra, 16384 + (ns >> 1) * 1024);
                 if (gap == 1) RC_DS_READ(A[nb][3], ra, RC_SLOT + 16384 + (ns >> 1) * 1024);
                 if (gap == 2) RC_DS_READ(A[nb][0], ra, (ns >> 1) * 1024);
                 if (gap == 3) RC_DS_READ(A[nb][2], ra, RC_SLOT + (ns >> 1) * 1024);
             }
-            if (s < 8 && (gap == 1 || gap == 3)) rc_dma_piece(L, wr, (s >> 2) ? n1 : n0, nxt + (s >> 2) * RC_SLOT, s, gap >> 1);
+            if (RC_DMA_HERE(s, gap) && RC_PROBE_DMA_ON) rc_dma_piece(L, wr, RC_DMA_SLOT(s, gap) ? n1 : n0, nxt + RC_DMA_SLOT(s, gap) * RC_SLOT, RC_DMA_IDX(s, gap), RC_DMA_PLANE(s, gap));
             RC_SB;
         }
     }
@@ -656,55 +706,54 @@ __device__ __forceinline__ void rc_gemm_step(const RcLane &L, char *smem, int ha
     else RC_DS_READ4_WAIT(A[0][1], fn.r0, 16384, A[0][3], fn.r0, RC_SLOT + 16384, A[0][0], fn.r0, 0, A[0][2], fn.r0, RC_SLOT);
 }
 
-// exact-erf GELU of gemm_split.hip (same polynomial), two elements at a time, cut into 12 stages of 4 VALU instructions: one stage per
-// MFMA gap, so the 48 instructions of a pair ride in the gaps of two slices.  st = (slice & 1) * 6 + gap.
-struct RcGelu { float ya, yb, za, zb, ca, cb, ua, ub, pa, pb, ga, gb; unsigned hw; };
-__device__ __forceinline__ void rc_gelu_stage(int st, RcGelu &g, float acc_a, float acc_b, float bias_a, float bias_b, unsigned &wh, unsigned &wl) {
-#ifdef RC_NOGELU   // timing probe (WRONG results): the activation reduced to bias + split - what the GELU's 10 arithmetic stages cost the launch
-    if (st == 0) { g.ga = acc_a + bias_a; g.gb = acc_b + bias_b; asm volatile("" : "+v"(g.ga), "+v"(g.gb)); }
+// GELU (scp_internal.h: scp_gelu_scaled - max(y', 0) - |y'| exp2(-y'^2) / P4(|y'|); fc1 arrives scaled by s, fc2 by 1 / s), two elements at
+// a time, cut into 12 stages: one stage per MFMA gap, so the 26 instructions of a pair (20 of the activation, 6 of the hi / lo split)
+// ride in the gaps of two slices.  st = (slice & 1) * 6 + gap.  The accumulator already holds fc1's bias (its start value).
+// Rounds 3 - 4 ran the degree-12 erf polynomial here: 48 instructions per pair, 384 of the ~470 vector instructions that shared a
+// step's 96 MFMA gaps; the two transcendentals of this form (v_exp_f32, v_rcp_f32) sit six and three stages in front of
+// their first use.
+struct RcGelu { float ea, eb, pa, pb, wa, wb, xa, xb, ga, gb; unsigned hw; };
+__device__ __forceinline__ void rc_gelu_stage(int st, RcGelu &g, float ya, float yb, unsigned &wh, unsigned &wl) {
+#ifdef RC_NOGELU   // timing probe (WRONG results): the activation reduced to the split - what the GELU's 10 arithmetic stages cost the launch
+    if (st == 0) { g.ga = ya; g.gb = yb; asm volatile("" : "+v"(g.ga), "+v"(g.gb)); }
     if (st == 10) { g.hw = rc_pack2(g.ga, g.gb); wh = g.hw; asm volatile("" : "+v"(g.hw)); }
     if (st == 11) wl = rc_pack2(g.ga - __builtin_bit_cast(float, g.hw << 16), g.gb - __builtin_bit_cast(float, g.hw & 0xffff0000u));
     return;
 #endif
     switch (st) {
-    case 0: g.ya = acc_a + bias_a; g.yb = acc_b + bias_b; g.za = g.ya * 0.70710678118654752f; g.zb = g.yb * 0.70710678118654752f; break;
-    case 1: g.ca = fminf(fabsf(g.za), 3.5f); g.cb = fminf(fabsf(g.zb), 3.5f); g.ua = g.ca * g.ca; g.ub = g.cb * g.cb; break;
-    case 2: g.ua = fmaf(g.ua, 2.0f / 12.25f, -1.0f); g.ub = fmaf(g.ub, 2.0f / 12.25f, -1.0f);
-            g.pa = fmaf(1.480935152e-03f, g.ua, -3.987360327e-03f); g.pb = fmaf(1.480935152e-03f, g.ub, -3.987360327e-03f); break;
-    case 3: g.pa = fmaf(g.pa, g.ua, 4.474287011e-03f); g.pb = fmaf(g.pb, g.ub, 4.474287011e-03f);
-            g.pa = fmaf(g.pa, g.ua, -7.227925849e-03f); g.pb = fmaf(g.pb, g.ub, -7.227925849e-03f); break;
-    case 4: g.pa = fmaf(g.pa, g.ua, 1.704961757e-02f); g.pb = fmaf(g.pb, g.ub, 1.704961757e-02f);
-            g.pa = fmaf(g.pa, g.ua, -3.003174999e-02f); g.pb = fmaf(g.pb, g.ub, -3.003174999e-02f); break;
-    case 5: g.pa = fmaf(g.pa, g.ua, 4.501544287e-02f); g.pb = fmaf(g.pb, g.ub, 4.501544287e-02f);
-            g.pa = fmaf(g.pa, g.ua, -6.477065166e-02f); g.pb = fmaf(g.pb, g.ub, -6.477065166e-02f); break;
-    case 6: g.pa = fmaf(g.pa, g.ua, 8.840217622e-02f); g.pb = fmaf(g.pb, g.ub, 8.840217622e-02f);
-            g.pa = fmaf(g.pa, g.ua, -1.146127499e-01f); g.pb = fmaf(g.pb, g.ub, -1.146127499e-01f); break;
-    case 7: g.pa = fmaf(g.pa, g.ua, 1.467501802e-01f); g.pb = fmaf(g.pb, g.ub, 1.467501802e-01f);
-            g.pa = fmaf(g.pa, g.ua, -2.007010379e-01f); g.pb = fmaf(g.pb, g.ub, -2.007010379e-01f); break;
-    case 8: g.pa = fmaf(g.pa, g.ua, 4.038729840e-01f); g.pb = fmaf(g.pb, g.ub, 4.038729840e-01f); g.pa *= g.ca; g.pb *= g.cb; break;
-    case 9: g.pa = copysignf(g.pa, g.za); g.pb = copysignf(g.pb, g.zb); g.ya *= 0.5f; g.yb *= 0.5f; break;
-    case 10: g.ga = fmaf(g.ya, g.pa, g.ya); g.gb = fmaf(g.yb, g.pb, g.yb); g.hw = rc_pack2(g.ga, g.gb); wh = g.hw; break;
+    case 0: g.ea = -ya * ya; g.eb = -yb * yb; break;
+    case 1: g.ea = __builtin_amdgcn_exp2f(g.ea); g.eb = __builtin_amdgcn_exp2f(g.eb); break;
+    case 2: g.pa = fmaf(SCP_GELU_C4, __builtin_fabsf(ya), SCP_GELU_C3); g.pb = fmaf(SCP_GELU_C4, __builtin_fabsf(yb), SCP_GELU_C3); break;
+    case 3: g.pa = fmaf(g.pa, __builtin_fabsf(ya), SCP_GELU_C2); g.pb = fmaf(g.pb, __builtin_fabsf(yb), SCP_GELU_C2); break;
+    case 4: g.pa = fmaf(g.pa, __builtin_fabsf(ya), SCP_GELU_C1); g.pb = fmaf(g.pb, __builtin_fabsf(yb), SCP_GELU_C1); break;
+    case 5: g.pa = fmaf(g.pa, __builtin_fabsf(ya), SCP_GELU_C0); g.pb = fmaf(g.pb, __builtin_fabsf(yb), SCP_GELU_C0); break;
+    case 6: g.pa = __builtin_amdgcn_rcpf(g.pa); g.pb = __builtin_amdgcn_rcpf(g.pb); break;
+    case 7: g.wa = __builtin_fabsf(ya) * g.ea; g.wb = __builtin_fabsf(yb) * g.eb; break;
+    case 8: asm("v_max_f32_e32 %0, 0, %1" : "=v"(g.xa) : "v"(ya)); asm("v_max_f32_e32 %0, 0, %1" : "=v"(g.xb) : "v"(yb)); break;   // (fmaxf: + a canonicalising v_max per operand)
+    case 9: g.ga = fmaf(-g.wa, g.pa, g.xa); g.gb = fmaf(-g.wb, g.pb, g.xb); break;
+    case 10: g.hw = rc_pack2(g.ga, g.gb); wh = g.hw; break;
     default: wl = rc_pack2(g.ga - __builtin_bit_cast(float, g.hw << 16), g.gb - __builtin_bit_cast(float, g.hw & 0xffff0000u)); break;
     }
     // Pin the stage where it is written: the values are pure arithmetic, and without this the optimiser sinks all twelve stages of a pair
-    // to the last one's gap (and packs them into v_pk_fma_f32, which is dearer beside MFMAs) - one gap of 30 VALU instructions with the
-    // matrix pipe idle instead of 4 in each of 12 gaps.  An empty asm that "modifies" the live state ends every stage.
+    // to the last one's gap (and packs them into v_pk_fma_f32, which is dearer beside MFMAs) - one gap of 26 VALU instructions with the
+    // matrix pipe idle instead of 2 - 3 in each of 12 gaps.  An empty asm that "modifies" the live state ends every stage.
     switch (st) {
-    case 0: asm volatile("" : "+v"(g.ya), "+v"(g.yb), "+v"(g.za), "+v"(g.zb)); break;
-    case 1: asm volatile("" : "+v"(g.ca), "+v"(g.cb), "+v"(g.ua), "+v"(g.ub)); break;
-    case 2: asm volatile("" : "+v"(g.ua), "+v"(g.ub), "+v"(g.pa), "+v"(g.pb)); break;
-    case 3: case 4: case 5: case 6: case 7: case 8: case 9: asm volatile("" : "+v"(g.pa), "+v"(g.pb)); break;
+    case 0: case 1: asm volatile("" : "+v"(g.ea), "+v"(g.eb)); break;
+    case 2: case 3: case 4: case 5: case 6: asm volatile("" : "+v"(g.pa), "+v"(g.pb)); break;
+    case 7: asm volatile("" : "+v"(g.wa), "+v"(g.wb)); break;
+    case 8: asm volatile("" : "+v"(g.xa), "+v"(g.xb)); break;
+    case 9: asm volatile("" : "+v"(g.ga), "+v"(g.gb)); break;
     case 10: asm volatile("" : "+v"(g.ga), "+v"(g.gb), "+v"(g.hw)); break;
     default: break;
     }
 }
 
 // Body step c: slot 0 = W1' rows [32 (c + 2), +32) (row chunk), slot 1 = W2 hidden slab c (k chunk).
-//   HAS_P1: P1(c + 2) -> a1n (false for the last two bodies);  GELU of a1g (= P1(c + 1)) + bias bg -> Hn (fragments of P2(c + 1));
+//   HAS_P1: P1(c + 2) -> a1n (false for the last two bodies; a1n arrives holding its bias);  GELU of a1g (= P1(c + 1)) -> Hn (fragments of P2(c + 1));
 //   P2(c): Y[blk] += W2 . Hc.   NEXT: 0 = next step is a body, 1 = next step is a GEMM step (phase 0 of the next tile).
 template <bool HAS_P1, bool HAS_GELU, int NEXT>
 __device__ __forceinline__ void rc_body_step(const RcLane &L, char *smem, int half, rf32x16 (&Y)[8], rf32x16 &a1n, const rf32x16 &a1g,
-                                             const rf32x4 (&bg)[4], const ru32x4 (&Hch)[2], const ru32x4 (&Hcl)[2], ru32x4 (&Hnh)[2],
+                                             const ru32x4 (&Hch)[2], const ru32x4 (&Hcl)[2], ru32x4 (&Hnh)[2],
                                              ru32x4 (&Hnl)[2], const rbf16x8 (&Xh)[16], const rbf16x8 (&Xl)[16], rbf16x8 (&A)[2][4],
                                              __amdgpu_buffer_rsrc_t wr, const RcSlotSrc &n0, const RcSlotSrc &n1) {
     const RcFragAddr f = rc_frag_addr(L, smem + half * (2 * RC_SLOT)), fn = rc_frag_addr(L, smem + (half ^ 1) * (2 * RC_SLOT));
@@ -712,7 +761,7 @@ __device__ __forceinline__ void rc_body_step(const RcLane &L, char *smem, int ha
     RcGelu g;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        if (s == 15) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s == 15) RC_STEP_BARRIER("vmcnt(0) lgkmcnt(0)", L.w);
         RC_SB;
         const int nb = (s + 1) & 1, ns = (s + 1) & 15;
         const int blk = s >> 1, t = s & 1;
@@ -720,8 +769,8 @@ __device__ __forceinline__ void rc_body_step(const RcLane &L, char *smem, int ha
         for (int gap = 0; gap < 6; ++gap) {
             // the fragment this MFMA is the first to use (see rc_ll_step); where P1 is over only the two W2 fragments are read per slice -
             // a read nothing uses is a register the compiler hands to the next VALU instruction while the read is still in flight
-            if (HAS_P1 && gap < 4) { RC_FRAG_WAIT(); RC_SB; }
-            if (!HAS_P1 && (gap == 1 || gap == 3)) { asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); RC_SB; }
+            if (HAS_P1 && gap < 4 && RC_PROBE_FRAG_ON) { RC_FRAG_WAIT(); RC_SB; }
+            if (!HAS_P1 && (gap == 1 || gap == 3) && RC_PROBE_FRAG_ON) { asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); RC_SB; }
             // P1 k-step s on chain a1n (fragments A[.][0] hi, A[.][1] lo) and P2 (blk, t) on chain Y[blk] (A[.][2] hi, A[.][3] lo), alternating
             if (gap == 0 && HAS_P1) RC_MFMA_AVA(a1n, A[s & 1][1], Xh[s]);
             if (gap == 1) RC_MFMA_AVV(Y[blk], A[s & 1][3], Hch[t]);
@@ -730,17 +779,17 @@ __device__ __forceinline__ void rc_body_step(const RcLane &L, char *smem, int ha
             if (gap == 4 && HAS_P1) RC_MFMA_AVA(a1n, A[s & 1][0], Xh[s]);
             if (gap == 5) RC_MFMA_AVV(Y[blk], A[s & 1][2], Hch[t]);
             RC_SB;
-            if (s < 15) {
+            if (s < 15 && RC_PROBE_FRAG_ON) {
                 if (gap == 0 && HAS_P1) RC_DS_READ(A[nb][1], (ns & 1) ? f.r1 : f.r0, 16384 + (ns >> 1) * 1024);
                 if (gap == 1) RC_DS_READ(A[nb][3], (ns & 1) ? f.k1 : f.k0, RC_SLOT + 16384 + (ns >> 1) * 2048);
                 if (gap == 2 && HAS_P1) RC_DS_READ(A[nb][0], (ns & 1) ? f.r1 : f.r0, (ns >> 1) * 1024);
                 if (gap == 3) RC_DS_READ(A[nb][2], (ns & 1) ? f.k1 : f.k0, RC_SLOT + (ns >> 1) * 2048);
             }
-            if (s < 8 && (gap == 1 || gap == 3)) rc_dma_piece(L, wr, (s >> 2) ? n1 : n0, nxt + (s >> 2) * RC_SLOT, s, gap >> 1);
+            if (RC_DMA_HERE(s, gap) && RC_PROBE_DMA_ON) rc_dma_piece(L, wr, RC_DMA_SLOT(s, gap) ? n1 : n0, nxt + RC_DMA_SLOT(s, gap) * RC_SLOT, RC_DMA_IDX(s, gap), RC_DMA_PLANE(s, gap));
             if (HAS_GELU) {   // element pair (2 k, 2 k + 1) of the finished P1 chain, k = s >> 1: registers 2 k, 2 k + 1 = fragment (k >> 2), elements 2 (k & 3), + 1
                 const int k = s >> 1, st = (s & 1) * 6 + gap;
                 unsigned wh = 0, wl = 0;
-                rc_gelu_stage(st, g, a1g[2 * k], a1g[2 * k + 1], bg[k >> 1][(2 * k) & 3], bg[k >> 1][(2 * k + 1) & 3], wh, wl);
+                rc_gelu_stage(st, g, a1g[2 * k], a1g[2 * k + 1], wh, wl);
                 if (st == 10) Hnh[k >> 2][k & 3] = wh;
                 if (st == 11) Hnl[k >> 2][k & 3] = wl;
             }
@@ -939,20 +988,24 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
                     Y[b][r] = (a.dbg_mode == 1) ? (float)Bh[2 * b + t][i] + (float)Bl[2 * b + t][i] : (r == 0 ? mean : rstd);
                 }
         }
-        // ---- P1(0), P1(1) -----------------------------------------------------------------------------------------------------------
+        // ---- P1(0), P1(1): every P1 chain starts from its 32 biases (b1' = s (b1 + W1 beta), accumulator order: register 4 q + u =
+        // channel 8 q + 4 h + u of the chunk) ----------------------------------------------------------------------------------------
         rf32x16 a1[2];
+        auto bias_into = [&](rf32x16 &acc, int c) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { a1[0][r] = 0.f; a1[1][r] = 0.f; }
+            for (int q = 0; q < 4; ++q) {
+                const rf32x4 bq = *(const rf32x4 *)(sb1 + 32 * c + 8 * q + 4 * L.h);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[4 * q + u] = bq[u];
+            }
+        };
+        bias_into(a1[0], 0);
+        bias_into(a1[1], 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!a.dbg_mode) {
         rc_gemm_step<true>(L, smem, gstep & 1, a1[0], a1[1], Bh, Bl, A, wr, src_1(2), src_2(0)); ++gstep;
         // ---- GELU(0) (nothing to hide it behind yet) -----------------------------------------------------------------------------------
         ru32x4 Hh[1][2], Hl[1][2];                                     // H(c): hi / lo fragments (bf16 pairs) of the two k-steps of a hidden chunk
-        rf32x4 bg[4];
-        auto load_bias = [&](int c) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bg[q] = *(const rf32x4 *)(sb1 + 32 * c + 8 * q + 4 * L.h);
-        };
-        load_bias(0);
         {
             RcGelu g;
 #pragma unroll
@@ -961,7 +1014,7 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
                 for (int st = 0; st < 12; ++st)
                 {
                     unsigned wh = 0, wl = 0;
-                    rc_gelu_stage(st, g, a1[0][2 * k], a1[0][2 * k + 1], bg[k >> 1][(2 * k) & 3], bg[k >> 1][(2 * k + 1) & 3], wh, wl);
+                    rc_gelu_stage(st, g, a1[0][2 * k], a1[0][2 * k + 1], wh, wl);
                     if (st == 10) Hh[0][k >> 2][k & 3] = wh;
                     if (st == 11) Hl[0][k >> 2][k & 3] = wl;
                 }
@@ -969,12 +1022,10 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
         // ---- bodies: H(c) in (Hch, Hcl), P1(c + 1) in a1g; body c leaves H(c + 1) in (Hnh, Hnl) and P1(c + 2) in a1n; then they swap -----
         ru32x4 Hnh[2], Hnl[2];
         for (int c = 0; c < 30; ++c) {
-            load_bias(c + 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             rf32x16 a1n;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a1n[r] = 0.f;
-            rc_body_step<true, true, 0>(L, smem, gstep & 1, Y, a1n, a1[1], bg, Hh[0], Hl[0], Hnh, Hnl, Bh, Bl, A, wr,
+            bias_into(a1n, c + 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            rc_body_step<true, true, 0>(L, smem, gstep & 1, Y, a1n, a1[1], Hh[0], Hl[0], Hnh, Hnl, Bh, Bl, A, wr,
                                         c + 3 < 32 ? src_1(c + 3) : src_2(c + 1), src_2(c + 1));
             ++gstep;
             a1[1] = a1n;
@@ -984,13 +1035,11 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
         // body 30: no P1 left; GELU(31).  The fragment registers are free: the next tile's attention rows are requested here.  (They cost 7 k
         // cycles per tile - probe without them: MLP phase 144.8 k against 151.9 k.  Requested INSIDE the step behind its DMA pieces, one per
         // MFMA gap of slices 8 - 15 with the barrier leaving them in flight, they cost 7.5 k more: 159.4 k.)
-        load_bias(31);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         load_o(tile_next);
-        rc_body_step<false, true, 0>(L, smem, gstep & 1, Y, a1[0], a1[1], bg, Hh[0], Hl[0], Hnh, Hnl, Bh, Bl, A, wr, src_2(31), src_2(31));
+        rc_body_step<false, true, 0>(L, smem, gstep & 1, Y, a1[0], a1[1], Hh[0], Hl[0], Hnh, Hnl, Bh, Bl, A, wr, src_2(31), src_2(31));
         ++gstep;
         // body 31: P2 only; the step after it is phase 0 of the next tile
-        rc_body_step<false, false, 1>(L, smem, gstep & 1, Y, a1[0], a1[1], bg, Hnh, Hnl, Hh[0], Hl[0], Bh, Bl, A, wr, src_p(0), src_p(1));
+        rc_body_step<false, false, 1>(L, smem, gstep & 1, Y, a1[0], a1[1], Hnh, Hnl, Hh[0], Hl[0], Bh, Bl, A, wr, src_p(0), src_p(1));
         ++gstep;
         }
         stamp(t_mlp);
@@ -1290,6 +1339,8 @@ __global__ __launch_bounds__(256, 1) void rc_edge_mlp_kernel(const RcEdgeArgs a)
     }
     SCP_WAIT_DMA(0);
 }
+
+extern "C" SCP_API double scp_gelu_prescale(void) { return (double)SCP_GELU_S; }
 
 static unsigned long long *g_rc_dbg = nullptr;   // diagnostic only (tools/mb_rowchain_probe.py): [workgroup][wave][8] cycle sums
 extern "C" SCP_API int scp_rc_debug_buffer(unsigned long long *dev_buf) { g_rc_dbg = dev_buf; return SCP_OK; }

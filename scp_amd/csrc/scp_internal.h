@@ -1,6 +1,7 @@
 // Internal helpers shared by the libscp_hip translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/scp.h"
@@ -30,14 +31,23 @@ int scp_stream_wait(hipStream_t st);
 // their destinations.  2-D form: `height` elements of `width` bytes, source pitch `spitch`, packed at the destination.
 int scp_d2h_async(void *dst, const void *src, size_t bytes, hipStream_t st);
 int scp_d2h_2d_async(void *dst, const void *src, size_t spitch, size_t width, size_t height, hipStream_t st);
+// Drop what this thread has queued and not yet waited for.  Every early return between a read-back and its scp_stream_wait goes through
+// it (SCP_D2H_TRY), and the builds call it on entry: a queued destination is a stack / local-vector address of the function that queued it.
+void scp_d2h_abort();
+#define SCP_D2H_TRY(expr)                                   \
+    do {                                                    \
+        const int _rc = (expr);                             \
+        if (_rc) { scp_d2h_abort(); return _rc; }           \
+    } while (0)
 
 // scp_debug.h launch brackets (api.cpp): `SCP_PROF(tag, stream, work);` right in front of a launch records a hipEvent on the stream now
 // and another when the enclosing scope ends (i.e. after the launch).  One relaxed load when profiling is off.
-extern int g_scp_prof_on;
+extern std::atomic<int> g_scp_prof_on;
 struct ScpProfScope {
     int slot;
+    unsigned gen;
     hipStream_t st;
-    ScpProfScope(int tag, hipStream_t s, double work) : slot(-1), st(s) { if (__builtin_expect(g_scp_prof_on, 0)) begin(tag, work); }
+    ScpProfScope(int tag, hipStream_t s, double work) : slot(-1), gen(0), st(s) { if (__builtin_expect(g_scp_prof_on.load(std::memory_order_relaxed), 0)) begin(tag, work); }
     ~ScpProfScope() { if (__builtin_expect(slot >= 0, 0)) end(); }
     void begin(int tag, double work);
     void end();
@@ -71,6 +81,32 @@ __device__ __forceinline__ void scp_pow2_scale(float mx, float &sc, float &isc) 
     sc = __uint_as_float((unsigned)(127 + e) << 23);
     isc = __uint_as_float((unsigned)(127 - e) << 23);
 }
+
+// GELU, 0.5 y (1 + erf(y / sqrt 2)) (swin_transformer.py:543-571: HF ACT2FN["gelu"]), round 5 form, ten vector instructions:
+//     GELU(y) = max(y, 0) - T(|y|),   T(a) = a Phi(-a) ~= a exp(-beta a^2) / P4(a)
+// P4 = a degree-4 minimax fit on [0, 6.5] with the exponent's scale beta free (0.50920: tools/fit_gelu.py), positive on the whole axis;
+// beyond 6.5 both T and its stand-in are < 1e-8.  Everything is written in y' = s y with s = sqrt(beta log2 e), so that the exponential
+// is v_exp_f32 of -y'^2: one multiplication.  Maximum absolute error of the activation 4.4e-7 (5.8e-7 with float32 rounding,
+// at |y| ~ 2.4 where an ulp is 2.4e-7) on |y| <= 20 - the degree-12 erf polynomial of rounds 1 - 4 (24 instructions) had 4.8e-6 in its
+// clamped tails and 8.1e-7 inside.  scp_gelu_scaled maps y' to s GELU(y'/ s): the row-chain kernel has s folded into fc1 (weights and
+// bias) and 1/s into fc2 on the host (scp_gelu_prescale); the tile epilogues use scp_gelu.
+#define SCP_GELU_S 0.857099074f
+#define SCP_GELU_INV_S 1.166726264f
+#define SCP_GELU_C0 2.000079870223999f
+#define SCP_GELU_C1 1.8606146574020386f
+#define SCP_GELU_C2 0.35269710421562195f
+#define SCP_GELU_C3 -0.11188109964132309f
+#define SCP_GELU_C4 0.008278189226984978f
+__device__ __forceinline__ float scp_gelu_scaled(float yp) {
+    const float a = __builtin_fabsf(yp);
+    const float e = __builtin_amdgcn_exp2f(-yp * yp);
+    float p = fmaf(SCP_GELU_C4, a, SCP_GELU_C3);
+    p = fmaf(p, a, SCP_GELU_C2);
+    p = fmaf(p, a, SCP_GELU_C1);
+    p = fmaf(p, a, SCP_GELU_C0);
+    return fmaf(-(a * e), __builtin_amdgcn_rcpf(p), fmaxf(yp, 0.f));
+}
+__device__ __forceinline__ float scp_gelu(float y) { return scp_gelu_scaled(y * SCP_GELU_S) * SCP_GELU_INV_S; }
 
 // growable device buffer owned by a handle
 struct DevBuf {

@@ -95,11 +95,15 @@ def pin_rank_threads(local, local_world, numa=True):
     """Give every rank of a node its own PHYSICAL cores (launch thread, range-coder worker, file reader: ~3 busy threads), taken
     from the NUMA node its GPU hangs on when sysfs tells (ranks whose GPUs share a node split that node's cores; SMT siblings stay
     with one rank).  Threads that already exist are moved too.  Nothing is changed for a single rank, with fewer than two cores per
-    rank, or with SCP_PIN=0.  Returns the CPU list of this rank or None."""
+    rank, or with SCP_PIN=0.  Returns the CPU list of this rank or None.
+    The NUMA exchange is a WORLD collective: every rank of an initialised process group enters it FIRST, before any condition that can
+    differ between ranks or nodes (SCP_PIN, a node that runs a single rank, a missing sched_setaffinity, a failing sysfs read) - a rank that
+    skipped it would leave all the others hanging in it."""
+    nodes = _local_nodes(local, local_world) if numa else None
     if os.environ.get("SCP_PIN", "1") == "0" or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
     try:
-        return _pin_rank_threads(local, local_world, numa)
+        return _pin_rank_threads(local, local_world, nodes)
     except Exception:               # pinning is an optimisation: an unexpected sysfs layout or a refused affinity call never costs a rank
         return None
 
@@ -111,7 +115,11 @@ def _local_nodes(local, local_world):
     rank could not resolve its node - then every rank takes the plain split, so two schemes can never hand out overlapping cores."""
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return None
-    mine = (int(os.environ.get("GROUP_RANK", "0")), local, _gpu_numa_node(torch.cuda.current_device()) if torch.cuda.is_available() else None)
+    try:                            # nothing in front of the collective may raise on one rank only
+        node = _gpu_numa_node(torch.cuda.current_device()) if torch.cuda.is_available() else None
+    except Exception:
+        node = None
+    mine = (int(os.environ.get("GROUP_RANK", "0")), int(local), node)
     everyone = [None] * dist.get_world_size()
     dist.all_gather_object(everyone, mine)
     here = sorted((l, n) for g, l, n in everyone if g == mine[0])
@@ -120,10 +128,9 @@ def _local_nodes(local, local_world):
     return [n for _, n in here]
 
 
-def _pin_rank_threads(local, local_world, numa):
+def _pin_rank_threads(local, local_world, nodes):
     allowed = set(os.sched_getaffinity(0))
     peers, slot, pool = local_world, local, allowed
-    nodes = _local_nodes(local, local_world) if numa else None
     if nodes is not None:
         mine_node = nodes[local]
         cpus_of = {n: _node_cpus(n) for n in set(nodes)}

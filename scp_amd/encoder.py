@@ -428,19 +428,26 @@ class FrameEncoder:
         return dict(future=fut, pre=pre, plan=plan, t0=t0, keep=(sym_coded, table, lohi))
 
     # ------------------------------------------------------------------------------------------ batches of small frames
-    def preprocess_batch(self, frames):
+    def preprocess_batch(self, frames, ints=None):
         """Stage G of k frames at once: one scp_geom_build with every (frame, shell) as a segment - one radix sort, one tree pass - and
         the frames' context tables back to back.  Frames share nothing (encode.py:274-291 rebuilds everything per frame): the batch is
         ONE sequence of levels - the frames' level lists one after the other - for the window plan, the packed forward and the CDF
-        kernel, and is cut into frames again in front of the range coder.  Returns (combined `pre`, per-frame meta)."""
+        kernel, and is cut into frames again in front of the range coder.  Returns (combined `pre`, per-frame meta).
+        ints: per frame the result of `host_ints(frame)` when the caller has computed it already (strict-identity mode, a prefetch thread)."""
         ns = len(self.shells())
         if len(frames) * ns > 62:
             raise native.ScpError("a batch holds at most 62 (frame, shell) trees (SCP_MAX_SEGMENTS)")
-        if self.host_transform:
+        if self.host_transform or ints is not None:
             qs_all, infos = [], []
-            for xyz_dev in frames:
-                hq, inf = self.host_ints(xyz_dev)
-                qs_all += [torch.from_numpy(q).to(self.device, non_blocking=True) for q in hq]
+            for f, xyz_dev in enumerate(frames):
+                hq, inf = ints[f] if ints is not None else self.host_ints(xyz_dev)
+                # copy from the PINNED TENSOR itself, as quantize() does: torch's host allocator records the stream use of a tensor it knows,
+                # so the block is not handed to the next frame's host_ints while this asynchronous copy still reads it (a from_numpy view of
+                # the same memory is invisible to the allocator: the next frame's integers could overwrite an earlier frame's in flight)
+                qcat, a = hq.packed.to(self.device, non_blocking=True), 0
+                for q in hq:
+                    qs_all.append(qcat[a:a + q.shape[0]])
+                    a += q.shape[0]
                 infos += inf
             segs, off = [], 0
             for f in range(len(frames)):
@@ -465,10 +472,11 @@ class FrameEncoder:
             mm0 += nl
         return dict(ctx=pre["ctx"], pos=pre["pos"], sym_coded=pre["sym_coded"], level_sizes=sizes), metas
 
-    def encode_batch_async(self, frames):
+    def encode_batch_async(self, frames, ints=None):
         """k frames through ONE stage G, ONE packed forward and ONE CDF launch (the small-frame configurations: a level-12 frame has
         22 windows, far too few for an MI355X - BASELINE.json configs[1] is a batch of 16 of them).  The streams are byte-identical
-        to the per-frame path (every kernel is per window / per row).  Returns a handle for finish_batch()."""
+        to the per-frame path (every kernel is per window / per row).  Returns a handle for finish_batch().
+        ints: [host_ints(frame) for every frame] when the caller has them already (strict-identity mode)."""
         t0 = time.perf_counter()
         self._init_streams()
         # the same stream structure as encode_async: stage G + plans on the high-priority front stream, the model part on the next lane
@@ -484,7 +492,7 @@ class FrameEncoder:
             self._front_stream.wait_stream(caller)
             dev_frames = [(torch.from_numpy(np.ascontiguousarray(x, np.float32)) if isinstance(x, np.ndarray) else x).to(self.device, non_blocking=True)
                           for x in frames]
-            pre, metas = self.preprocess_batch(dev_frames)
+            pre, metas = self.preprocess_batch(dev_frames, ints)
             plan = EncodePlan(pre["level_sizes"], self.context_size)
             if self.packed:
                 pre["packed_plans"] = self.packed_plans(plan)

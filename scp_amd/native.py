@@ -42,7 +42,7 @@ _lib = None
 _vp = C.c_void_p
 
 
-ABI_VERSION = 210      # include/scp.h: SCP_ABI_VERSION
+ABI_VERSION = 220      # include/scp.h: SCP_ABI_VERSION
 
 
 def lib():
@@ -85,6 +85,8 @@ def lib():
         "scp_swin_attention_packed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp]),
         "scp_swin_attention_packed_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, i64, _vp]),
         "scp_set_attention_mode": (C.c_int, [i32]),
+        "scp_set_attention_variant": (C.c_int, [i32]),
+        "scp_get_attention_variant": (C.c_int, []),
         "scp_ctx_create": (C.c_int, [C.POINTER(_vp)]),
         "scp_ctx_destroy": (C.c_int, [_vp]),
         "scp_ctx_set": (C.c_int, [_vp, i32, i32]),
@@ -121,6 +123,7 @@ def lib():
         "scp_swin_ln_linear": (C.c_int, [_vp, i64, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, i32, _vp]),
         "scp_swin_post_attn": (C.c_int, [_vp, _vp, i64, _vp, i64, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, _vp, i32, _vp]),
         "scp_swin_post_attn_weight_bytes": (C.c_int64, []),
+        "scp_gelu_prescale": (C.c_double, []),
         "scp_split_rows": (C.c_int, [_vp, i64, i64, _vp, i32, _vp, _vp, i64, i64, _vp]),
         "scp_linear_split_scatter": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_linear_split_gather": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
@@ -614,7 +617,8 @@ def numeric_profile(model_name, profile="current"):
     """The arithmetic variants that decide the logits' last bits - hence the integer CDFs a decoder must reproduce - as a string.  The
     encoder writes it into its side-info file and the decoder refuses a stream coded under another profile.  `profile`: a
     NumericProfile, None (process default) or "current" (this thread's).  The remaining fields are constants since round 4 (the
-    superseded launch forms they once named are gone); they stay in the string so that round-3 streams keep decoding."""
+    superseded launch forms they once named are gone).  The generation prefix (ehem/N) moves whenever a kernel's last bits do, and the
+    decoder compares the whole string: streams of an older generation are refused by design, not decoded to garbage."""
     from . import ops
     from .models import packed
     if model_name == "OctAttention":
@@ -625,7 +629,10 @@ def numeric_profile(model_name, profile="current"):
     attn = _MODES["attn"] if profile is None else ("bf16x3" if profile.attention_bf16x3 else "f32")
     # ehem/3: patch merging and the geometry generator's edge MLPs on row-chain kernels (other last bits than ehem/2)
     # ehem/4: the bf16x3 attention sweeps against the fixed reference 0 with the bias as the products' start value (csrc/attn.hip: attn_tile)
-    return f"ehem/4:gemm={ops.MODE},knn={knn},attn={attn},concat={'hier' if packed.HIER else 'direct'},swin=rowchain"
+    # ehem/5: GELU as max(y, 0) - |y| exp(-beta y^2) / P4(|y|) (csrc/scp_internal.h) instead of the degree-12 erf polynomial
+    L = lib()
+    attnv = "" if L.scp_get_attention_variant() == 1 else f",attnv={L.scp_get_attention_variant()}"     # process-wide test bracket (scp_debug.h)
+    return f"ehem/5:gemm={ops.MODE},knn={knn},attn={attn},concat={'hier' if packed.HIER else 'direct'},swin=rowchain{attnv}"
 
 
 def edge_gather_max(u, v, idx, scale, shift, out=None):
@@ -1114,22 +1121,24 @@ def rc_perm16(n, device):
 class PostAttnWeights:
     """Weights of a Swin block's post-attention half in the form scp_swin_post_attn streams (built once per block): proj as it is;
     fc1 with layernorm_after's affine folded in (W1 diag(gamma), b1 + W1 beta) and its K axis in accumulator order; fc2 with its
-    hidden axis in accumulator order."""
+    hidden axis in accumulator order.  The kernel evaluates GELU in the variable s y (s = scp_gelu_prescale(), csrc/scp_internal.h): fc1
+    (weight and bias) carries the factor s, fc2's weight 1 / s."""
 
     def __init__(self, wp, bp, gamma, beta, w1, b1, w2, b2):
         dev = wp.device
         perm_k, perm_h = rc_perm16(256, dev), rc_perm16(w1.shape[0], dev)
         w1d = w1.detach().double()
+        s = float(lib().scp_gelu_prescale())
         swp = SplitWeight(wp.detach().float().contiguous())
-        sw1 = SplitWeight((w1d * gamma.detach().double()[None, :]).float()[:, perm_k].contiguous())
-        sw2 = SplitWeight(w2.detach().float()[:, perm_h].contiguous())
+        sw1 = SplitWeight((w1d * gamma.detach().double()[None, :] * s).float()[:, perm_k].contiguous())
+        sw2 = SplitWeight((w2.detach().double() / s).float()[:, perm_h].contiguous())
         # one buffer for the kernel's single buffer resource: the tiled planes proj hi | fc1 hi | fc2 hi | proj lo | fc1 lo | fc2 lo
         tiles = [_tiled_planes_always(w) for w in (swp, sw1, sw2)]
         self.packed = torch.cat([t[0].reshape(-1) for t in tiles] + [t[1].reshape(-1) for t in tiles]).contiguous()
         if self.packed.numel() * 2 != lib().scp_swin_post_attn_weight_bytes():
             raise ScpError("swin_post_attn: 256 -> 1024 -> 256 blocks only")
         self.bp = bp.detach().float().contiguous()
-        self.b1 = (b1.detach().double() + w1d @ beta.detach().double()).float().contiguous()
+        self.b1 = ((b1.detach().double() + w1d @ beta.detach().double()) * s).float().contiguous()
         self.b2 = b2.detach().float().contiguous()
         note_cache_fill()
 

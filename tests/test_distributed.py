@@ -32,6 +32,16 @@ def _worker(rank, world, port, q):
     both = D._local_nodes(r, w)
     D._gpu_numa_node = (lambda i: None) if r == 1 else (lambda i: 0)
     one_missing = D._local_nodes(r, w)
+    # conditions that differ between ranks must not split the ranks around the exchange: rank 1 runs with SCP_PIN=0 and
+    # believes it is alone on its node; both calls return (no rank is left hanging in all_gather_object), then one more collective works
+    D._gpu_numa_node = lambda i: 0
+    if r == 1:
+        os.environ["SCP_PIN"] = "0"
+    os.sched_setaffinity = lambda pid, cpus: None
+    pinned = D.pin_rank_threads(r, w if r == 0 else 1)
+    os.environ.pop("SCP_PIN", None)
+    after = D.reduce_summary([1, 0, 0, 0, 1])
+    assert after[0] == 2.0 and (pinned is None or r == 0)
     q.put((r, [i for i, _ in mine], total, both, one_missing))
     D.finalize()
 

@@ -57,10 +57,41 @@ def test_bench_single_rank_line_has_the_contract_fields():
         assert k["launches_per_frame"] >= 1 and k["avg_launch_us"] > 0 and ("frac" not in k or 0 < k["frac"] < 1)
     f = out["roofline_frame"]
     assert f["flops"] > 1e12 and 0 < f["frac_mfma"] < 1 and f["attention_flops"] < f["flops"]
-    s = out["strict_identity"]
-    assert s["fps"] > 0 and out["strict_identity_fps"] == s["fps"] and abs(s["bpp_mean"] - out["bpp_mean"]) < 0.05 * out["bpp_mean"]
+    # round 5: the headline runs in strict-identity mode (the reference's own float -> integer arithmetic, 0 differing points asserted in the run),
+    # the device transform is the second leg
+    assert "strict identity" in out["config"]["transform"] and out["strict_identity_verified"] is True and out["strict_identity_fps"] == out["value"]
+    s = out["device_transform"]
+    assert s["fps"] > 0 and out["device_transform_fps"] == s["fps"] and abs(s["bpp_mean"] - out["bpp_mean"]) < 0.05 * out["bpp_mean"]
     tp = out["transform_parity"]
-    assert tp["host_transform"] == [0] and tp["device_transform"][0] > 0       # L12 --spher: the strict mode has the reference's integers, the device one misses 853 points
+    assert tp["host_transform"] == [0] and tp["device_transform"][0] > 0       # L12 --spher: the device transform misses 853 of the reference's points
+    assert out["config"]["rank_cores"] >= 1
+    k = out["roofline_kernels"]["edge_gather_max_kernel"]
+    assert k["bound"] == "hbm" and 0 < k["frac"] < 1
+    assert "configs" not in out                                                 # side legs belong to the headline configuration only
+
+
+def test_bench_device_transform_headline_and_strict_leg():
+    out = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--config", "ehem-L12-s", "--device-transform"])
+    assert out["config"]["transform"] == "device" and out["strict_identity"]["fps"] == out["strict_identity_fps"] and out["device_transform_fps"] == out["value"]
+    tp = out["transform_parity"]
+    assert tp["host_transform"] == [0] and tp["device_transform"][0] > 0       # L12 --spher: the device transform misses 853 of the reference's points
+
+
+def test_bench_side_legs_fill_configs_decode_and_cli():
+    """The default run of the headline configuration adds the other four BASELINE.json workloads, the decoder and the drop-in CLI as child
+    processes behind the headline: five `configs` entries, `decode`, `cli`, `cli_over_bench`."""
+    out = _run(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-strict-leg", "--leg-steps", "3", "--leg-warmup", "2"], timeout=2400)
+    assert out["strict_identity_verified"] is True and out["transform_parity"]["host_transform"] == [0, 0, 0]
+    assert set(out["configs"]) == {"ehem-L16-m", "ehem-L12-s", "ehem-F17-m", "octattn-L12-spher", "octattn-L14-cylin"}, out.get("legs_error")
+    for name, c in out["configs"].items():
+        assert "error" not in c, (name, c)
+        assert c["fps"] > 0 and c["ms_per_step"] > 0 and 0 < c["roofline"]["frac"] < 1 and c["roofline"]["valid"] is True, (name, c)
+    assert out["configs"]["ehem-L12-s"]["steps"] == 16 and out["configs"]["ehem-L12-s"]["strict_identity_verified"] is True
+    assert out["configs"]["ehem-L16-m"]["fps"] == out["value"]
+    d = out["decode"]
+    assert d["decoded_occupancy_equals_encoded"] is True and d["fps"] > 0
+    c = out["cli"]
+    assert c["streams_written"] == c["files"] == 5 and c["fps"] > 0 and abs(out["cli_over_bench"] - c["fps"] / out["value"]) < 1e-9
 
 
 def test_bench_decode_mode_times_the_decoder_and_checks_the_round_trip():
@@ -74,7 +105,7 @@ def test_four_ranks_on_one_gpu_keep_the_aggregate_rate():
     pools, four HIP runtimes - share ONE GPU (SCP_FORCE_DEVICE=0, gloo).  The GPU is the bottleneck either way, so the aggregate rate must
     stay at the one-rank rate; it falls when the ranks' host sides get in each other's way (cores, allocator locks, the GIL of one
     process is not shared here).  Each rank also reports its host CPU per frame: about 80 ms (1.2 cores) since round 4."""
-    common = ["--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-strict-leg", "--config", "ehem-L16-m"]
+    common = ["--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-strict-leg", "--no-legs", "--config", "ehem-L16-m"]
     one = _run(common)
     four = _run(["--gpus", "4"] + common, {"SCP_FORCE_DEVICE": "0", "SCP_DIST_BACKEND": "gloo"})
     assert four["n_gpus"] == 4 and four["ranks"]["shared_frame_streams_identical"]

@@ -927,3 +927,26 @@ def test_batched_frames_give_the_per_frame_streams(enc_parts, mul, level):
     again = enc.finish_batch(enc.encode_batch_async(frames[::-1]))
     assert [r["bytes"] for r in again] == [r["bytes"] for r in single[::-1]]
     assert enc.finish_batch(enc.encode_batch_async(frames[:1]))[0]["bytes"] == single[0]["bytes"]
+
+
+@pytest.mark.parametrize("mul", [False, True])
+def test_batched_frames_with_the_host_transform_give_the_per_frame_streams(enc_parts, mul):
+    """encode_batch_async with host_transform=True and k > 1: every frame's integers come out of their own pinned buffer by
+    an asynchronous copy of the PINNED TENSOR (a numpy view of it is invisible to torch's host allocator, which may hand the block to the
+    next frame while the copy is still reading it).  Several rounds, so that freed pinned blocks do get reused while copies are in
+    flight; streams must equal the per-frame encodes."""
+    from scp_amd.encoder import FrameEncoder
+    from scp_amd.synth import synth_frame
+    model, dev = enc_parts
+    enc = FrameEncoder(model, "kitti", 12, spher=True, mullevel=mul, device=dev, host_transform=True)
+    frames = [synth_frame(30 + i)[::7 + 3 * i].copy() for i in range(6)]
+    single = [enc.encode(f)["bytes"] for f in frames]
+    for rnd in range(3):
+        order = frames if rnd % 2 == 0 else frames[::-1]
+        want = single if rnd % 2 == 0 else single[::-1]
+        got = enc.finish_batch(enc.encode_batch_async(order))
+        assert [r["bytes"] for r in got] == want, f"round {rnd}"
+    # the caller may hand the integers in (bench.py / cli.py compute them on a prefetch thread): same streams, whatever the encoder's own mode
+    dev_enc = FrameEncoder(model, "kitti", 12, spher=True, mullevel=mul, device=dev, host_transform=False)
+    got = dev_enc.finish_batch(dev_enc.encode_batch_async(frames, ints=[enc.host_ints(f) for f in frames]))
+    assert [r["bytes"] for r in got] == single

@@ -1,6 +1,5 @@
 import os, sys, numpy as np, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
-ROOT=os.environ.get('GRAFT_REPO_ROOT','/root/repo'); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT+'/tests')
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT+'/tests')
 from cfgs import ehem_cfg
 from scp_amd.models import EHEM
 from scp_amd.weights import fill_weights

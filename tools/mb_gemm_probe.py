@@ -2,7 +2,7 @@
 on the frame's K = 256 shapes and OctAttention's K = 600 shapes (bf16 planes: the F16 instantiation shares the loop)."""
 import os, sys, torch
 os.environ["SCP_GEMM_PROBE"] = "1"
-sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scp_amd import native
 dev = torch.device('cuda:0')
 def timeit(f, reps=10, warm=3):

@@ -1,6 +1,6 @@
 """scp_linear_split_f16 tile configurations on OctAttention's shapes: python tools/mb_oa_cfg.py"""
 import os, sys, torch
-sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scp_amd import native
 dev = torch.device('cuda:0')
 def timeit(f, reps=10, warm=3):

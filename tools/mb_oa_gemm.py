@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scp_amd import native
 dev = torch.device('cuda:0')
 def timeit(f, reps=10, warm=3):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/pmc_clock.sh   -> the clock every hot kernel of the L16-m frame runs at: GRBM_GUI_ACTIVE / (End - Start) per dispatch
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/clockpmc; mkdir -p $O
+R=${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=the repository root)}; O=$R/gpurun_out/clockpmc; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/p -- python3 $R/tools/run_frame.py 16 1 3 > $O/log.txt 2>&1
 python3 - <<EOF

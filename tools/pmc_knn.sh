@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): bash tools/pmc_knn.sh <tag> <shape>   -> FETCH_SIZE pass and SQ wave-state pass over the frame's kNN searches in one shape
-R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=the repository root)}; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmck_$1_fetch -- python3 $R/tools/run_knn.py $2 > $R/gpurun_out/pmck_$1.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $R/gpurun_out/pmck_$1_sq -- python3 $R/tools/run_knn.py $2 >> $R/gpurun_out/pmck_$1.log 2>&1
 python3 - <<PY

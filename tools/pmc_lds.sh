@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ldspmc; mkdir -p $O
+R=${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=the repository root)}; O=$R/gpurun_out/ldspmc; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/p -- python3 $R/tools/run_frame.py 16 1 3 > $O/log.txt 2>&1
 ls $O/p/*/ | head

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/pmc_rowchain.sh   -- SQ counter passes over tools/run_rowchain.py (no tracing options next to --pmc)
-R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=the repository root)}; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $R/gpurun_out/pmc_rc1 -- python3 $R/tools/${RC_SCRIPT:-run_rowchain.py} > $R/gpurun_out/pmc_rc1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d $R/gpurun_out/pmc_rc2 -- python3 $R/tools/${RC_SCRIPT:-run_rowchain.py} > $R/gpurun_out/pmc_rc2.log 2>&1
 rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_IFETCH SQ_WAVES --output-format csv -d $R/gpurun_out/pmc_rc3 -- python3 $R/tools/${RC_SCRIPT:-run_rowchain.py} > $R/gpurun_out/pmc_rc3.log 2>&1

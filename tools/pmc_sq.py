@@ -1,7 +1,7 @@
 """Summarise tools/pmc_sq.sh: per kernel, wave-state fractions (SQ_* counters count quad-cycles; MFMA busy counts cycles)."""
 import csv, glob, sys, collections, os
 tag = sys.argv[1]
-root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 f = max(glob.glob(f"{root}/gpurun_out/pmc_{tag}_sq/*/*counter_collection.csv"), key=os.path.getmtime)   # newest run
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(f)):

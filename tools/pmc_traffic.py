@@ -4,7 +4,7 @@ import csv, glob, json, os, sys, collections
 tag = sys.argv[1]
 tot = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = max(glob.glob(f"/root/repo/gpurun_out/pmc_{tag}_{c}/*/*counter_collection.csv"), key=os.path.getmtime)   # newest run
+    f = max(glob.glob(f"{ROOT}/gpurun_out/pmc_{tag}_{c}/*/*counter_collection.csv"), key=os.path.getmtime)   # newest run
     acc = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != c:
@@ -33,7 +33,7 @@ frames = 2
 out["frame_hbm_bytes"] = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in out["per_kernel"].values()) / frames
 big = dict(sorted(out["per_kernel"].items(), key=lambda kv: -(kv[1]["fetch_bytes_corrected"] + kv[1]["write_bytes"]))[:14])
 out["per_kernel"] = big
-json.dump(out, open(f"/root/repo/profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+json.dump(out, open(f"{ROOT}/profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out["gemm_split_all_variants"]), "frame HBM traffic %.1f GB" % (out["frame_hbm_bytes"] / 1e9))
 for k, v in big.items():
     print(f"{k[:60]:60s} {v['launches']:5d} {v['hbm_bytes_per_launch']/1e6:10.1f} MB/launch")

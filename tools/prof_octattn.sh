@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/prof_octattn.sh <tag> [level] [cylin]  -> gpurun_out/prof_<tag>/ kernel stats of 3 OctAttention frames
-R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=the repository root)}; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$1 -- python3 $R/tools/run_octattn.py ${2:-12} ${3:-0} > $R/gpurun_out/prof_$1.log 2>&1
 grep frame $R/gpurun_out/prof_$1.log
 python3 - <<PY

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/r4_check.sh <tag> : GPU tests, the default bench line, the decoder line, rocprofv3 kernel stats of 4 frames
-R=$GRAFT_REPO_ROOT; T=$1; O=$R/gpurun_out/$T; mkdir -p $O
+R=${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=the repository root)}; T=$1; O=$R/gpurun_out/$T; mkdir -p $O
 cd $R
 timeout 1200 python3 -m pytest tests -q -m gpu > $O/${T}_gpu_tests.txt 2>&1; tail -15 $O/${T}_gpu_tests.txt
 timeout 600 python3 bench.py > $O/${T}_bench.log 2>&1; grep '^{' $O/${T}_bench.log | tail -1 > $O/${T}_bench.json; cut -c1-400 $O/${T}_bench.json; tail -5 $O/${T}_bench.log | grep -v '^{' | cut -c1-300

@@ -3,7 +3,7 @@
 # Everything the round's profiles/ entries come from, into gpurun_out/<tag>/ : rocprofv3 kernel stats, PMC traffic (two separate --pmc
 # passes, no tracing options beside them), SQ wave states - for the EHEM L16-m frame AND for the OctAttention L14 --cylin frame -, the
 # stage-G pass tables (L12 x1 / x4, L16-m, F17-m) and the five bench lines.
-R=$GRAFT_REPO_ROOT; T=$1; shift; W=${@:-ehem octattn stageg bench}; O=$R/gpurun_out/$T; mkdir -p $O
+R=${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=the repository root)}; T=$1; shift; W=${@:-ehem octattn stageg bench}; O=$R/gpurun_out/$T; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 prof() {   # name, script args...
   local name=$1; shift

@@ -2,7 +2,8 @@
 build's: an arithmetic decoder needs the encoder's integer CDFs bit for bit, and logits that agree to 1e-5 still round to different integers
 somewhere in 100k symbols (first differing byte: 19 / 14).  What IS pinned: symbols, bit counts, CDF integers given PMFs, coder bytes given CDFs."""
 import sys, os, numpy as np, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 from cfgs import ehem_cfg
 from conftest import golden
 from scp_amd.models import EHEM

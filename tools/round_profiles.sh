@@ -2,7 +2,7 @@
 # usage (on the GPU box): bash tools/round_profiles.sh <tag>
 # Everything the round's profiles/ entries come from, into gpurun_out/<tag>/: the GPU test log, the default bench line (with the CPU
 # baseline), rocprofv3 --kernel-trace --stats of the same bench command, and the five configuration lines of `bench.py --all-configs`.
-R=$GRAFT_REPO_ROOT; T=$1; O=$R/gpurun_out/$T; mkdir -p $O
+R=${GRAFT_REPO_ROOT:?run under gpurun (or export GRAFT_REPO_ROOT=the repository root)}; T=$1; O=$R/gpurun_out/$T; mkdir -p $O
 cd $R
 timeout 1500 python3 -m pytest tests -q -m gpu -x > $O/${T}_gpu_tests.txt 2>&1; tail -2 $O/${T}_gpu_tests.txt
 timeout 600 python3 bench.py > $O/${T}_bench.log 2>&1; grep '^{' $O/${T}_bench.log | tail -1 > $O/${T}_bench.json; cut -c1-300 $O/${T}_bench.json

@@ -1,5 +1,6 @@
 import os, sys, time, torch, numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests')
 from cfgs import ehem_cfg
 from scp_amd.models import EHEM
 from scp_amd.weights import fill_weights
