@@ -328,10 +328,10 @@ class IntsAhead:
     data_preprocess.py:42-70,171-214) of frame i + 1 ... i + ahead on ONE worker thread while frame i is enqueued - what cli.py does with
     `Prefetch(post=enc.host_ints)`.  All of it inside the timed region."""
 
-    def __init__(self, enc, frames_host, lo, hi, ahead=2):
+    def __init__(self, enc, frames_host, lo, hi, ahead=2, workers=1):
         from concurrent.futures import ThreadPoolExecutor
         self.enc, self.frames, self.hi, self.ahead = enc, frames_host, hi, ahead
-        self.pool = ThreadPoolExecutor(max_workers=1)
+        self.pool = ThreadPoolExecutor(max_workers=workers)
         self.futs, self.next = {}, lo
 
     def get(self, i):
@@ -450,7 +450,8 @@ def cli_leg(n_warm, n_timed):
     import subprocess
     import tempfile
     from scp_amd.synth import synth_frame, write_kitti_bin
-    n = n_warm + n_timed
+    tail = 4                         # the last frames complete while the pipeline drains (nothing new competes for the GPU): not counted
+    n = n_warm + n_timed + tail
     with tempfile.TemporaryDirectory() as tmp:
         seq = os.path.join(tmp, "seq00")
         os.makedirs(seq)
@@ -465,11 +466,12 @@ def cli_leg(n_warm, n_timed):
             return {"error": r.stderr[-300:]}
         times = [float(l.split(":")[1]) for l in r.stdout.splitlines() if l.startswith("time(s)")]
         written = len([f for f in os.listdir(os.path.join(tmp, "out")) if f.endswith(".bin")])
-    steady = times[n_warm:]
+    steady = times[n_warm:n_warm + n_timed]
     fps = len(steady) / sum(steady)
     return dict(fps=fps, ms_per_step=1e3 / fps, files=n, files_timed=len(steady), streams_written=written, process_wall_s=wall,
                 note="drop-in CLI (encode_mullevel.py -> scp_amd/cli.py), strict-identity transform on the reader thread, frames pipelined three deep; "
-                     "file read + parse + H2D + .bin / .dat / .scp.json writes inside; process start, weight preparation and the first frames excluded")
+                     "file read + parse + H2D + .bin / .dat / .scp.json writes inside; process start, weight preparation, the first frames and the last four "
+                     "(pipeline drain) excluded")
 
 
 def side_legs(args, out):
@@ -522,7 +524,10 @@ def main():
     backend = os.environ.get("SCP_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    # SCP_DIST_FORCE=1: run every distributed step of this file (process group, barriers, the all-reduces, the per-rank gather) in a world of
+    # ONE too - what a one-GPU box can exercise of the RCCL path (tests/test_gpu_dist.py)
+    dist_on = world > 1 or os.environ.get("SCP_DIST_FORCE", "0") == "1"
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -562,7 +567,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -573,7 +578,7 @@ def main():
     def timed_loop(strict):
         """`--steps` frames through the pipelined encoder; strict: the reference's host transform one frame ahead on a worker thread.
         -> (dt of this rank before the barrier, dt after it, host CPU ms per frame, results)"""
-        ahead = IntsAhead(enc, frames_host, args.warmup, total, ahead=max(2, 2 * batch)) if strict else None
+        ahead = IntsAhead(enc, frames_host, args.warmup, total, ahead=max(2, 2 * batch), workers=2 if batch > 1 else 1) if strict else None
         barrier()
         cpu0 = time.process_time()                      # CPU seconds of this rank, all threads (launch thread, coder worker, reader)
         t0 = time.perf_counter()
@@ -632,7 +637,7 @@ def main():
                           ("enc.host_ints (numpy float32 transform + quantiser of data_preprocess.py:42-70,171-214) on one worker thread one to two "
                            "frames ahead, inside the timed region; everything after the integers on the device as in the headline"))
     rank_stats = None
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -647,7 +652,7 @@ def main():
 
     # end-of-run summary reduction (encode.py:293-305): [sum bpp, sum psnr, sum chamfer, sum time, count] over all ranks
     summ = torch.tensor([sum(r["bpp"] for r in results), 0.0, 0.0, dt, len(results)], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(summ, op=dist.ReduceOp.SUM)
     summ = summ.cpu().numpy()
 
@@ -700,7 +705,7 @@ def main():
                        "transform": "host-numpy on a prefetch thread (strict identity: the reference's integers)" if (headline_strict or enc.host_transform) else "device",
                        "parallelism": f"frame-sharded x{world}", "rank_cores": len(pinned) if pinned else len(os.sched_getaffinity(0)),
                        "rank_cores_pinned": bool(pinned)},
-            "rccl_world": dist.get_world_size() if world > 1 else 1, "dist_backend": backend if world > 1 else None,
+            "rccl_world": dist.get_world_size() if dist_on else 1, "dist_backend": backend if dist_on else None,
             "host_cpu_ms_per_frame": cpu_ms,
             "bpp_mean": float(summ[0] / summ[4]),
             "stage_ms": {k: round(1e3 * v, 3) for k, v in st.items()},
@@ -769,7 +774,7 @@ def main():
             except Exception as e:     # a leg is extra information, never a reason to lose the headline
                 out["legs_error"] = repr(e)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <type_traits>
 #include "../../include/scp.h"
 
 namespace {
@@ -127,20 +128,33 @@ extern "C" int scp_ac_encode_lohi(const uint32_t *lohi, int64_t n, uint8_t *out,
     return s.overflow ? SCP_ESMALL : SCP_OK;
 }
 
+// Decoder state.  The reference (numpyAc_backend.cpp:134-217) shifts `low`, `high` and `value` one bit per loop iteration and fetches the
+// next stream bit through a byte cache; here the bits wait in a 64-bit window and every renormalisation is two bursts, the mirror image of
+// Coder::step above: (1) the k leading bits low and high share leave together, (2) the u underflow positions (low = 01.., high = 10..) leave
+// together - u single steps of value = ((value - 2^30) << 1) | bit amount to (value << u) with the top bit flipped, plus u new bits.  The
+// cases cannot interleave (after (2) the top bits differ and no underflow position is left), so a symbol costs at most two bursts.
+// Bits behind the end of the stream read as zero, like the reference's get().
 struct scp_ac_dec {
     uint8_t *in = nullptr;
     size_t len = 0, ptr = 0;
-    uint8_t cache = 0, cached_bits = 0;
+    uint64_t win = 0;       // the next `nwin` stream bits, left-aligned (bit 63 first)
+    int nwin = 0;
     uint32_t low = 0, high = 0xFFFFFFFFu, value = 0;
     int32_t Lp = 0;
-    inline void get() {
-        if (cached_bits == 0) {
-            if (ptr == len) { value <<= 1; return; }
-            cache = in[ptr++];
-            cached_bits = 8;
+    inline void refill() {  // keep at least 32 bits in the window (zeros behind the end of the stream)
+        while (nwin <= 56) {
+            const uint64_t b = ptr < len ? in[ptr] : 0u;
+            ++ptr;
+            win |= b << (56 - nwin);
+            nwin += 8;
         }
-        value = (value << 1) | ((cache >> (cached_bits - 1)) & 1u);
-        --cached_bits;
+    }
+    inline uint32_t take(int k) {   // the next k (1 .. 31) bits, MSB first
+        if (nwin < k) refill();
+        const uint32_t v = (uint32_t)(win >> (64 - k));
+        win <<= k;
+        nwin -= k;
+        return v;
     }
 };
 
@@ -153,47 +167,107 @@ extern "C" int scp_ac_dec_new(scp_ac_dec **d, const uint8_t *stream, size_t len,
     if (len) memcpy(p->in, stream, len);
     p->len = len;
     p->Lp = Lp;
-    for (int i = 0; i < 32; ++i) p->get();
+    p->refill();
+    p->value = (p->take(16) << 16) | p->take(16);
     *d = p;
     return SCP_OK;
 }
 
-extern "C" int scp_ac_dec_next(scp_ac_dec *d, const uint16_t *row) {
-    if (!d || !row) return SCP_EINVAL;
-    const int max_symbol = d->Lp - 2;
-    const uint64_t span = (uint64_t)d->high - (uint64_t)d->low + 1;
-    const uint16_t count = (uint16_t)((((uint64_t)d->value - (uint64_t)d->low + 1) * 0x10000ull - 1) / span);
-    // largest s with cdf[s] <= count, searched over [0, max_symbol] like the reference's binsearch
+// largest s with cdf[s] <= count, searched over [0, max_symbol] exactly like the reference's binsearch (numpyAc_backend.cpp:100-131)
+static inline int ac_search_ref(const uint16_t *row, uint16_t count, int max_symbol) {
     uint32_t left = 0, right = (uint32_t)max_symbol + 1;
-    int sy = -1;
     while (left + 1 < right) {
         const uint32_t mid = (left + right) / 2;
         const uint16_t v = row[mid];
-        if (v < count) left = mid; else if (v > count) right = mid; else { sy = (int)mid; break; }
+        if (v < count) left = mid; else if (v > count) right = mid; else return (int)mid;
     }
-    if (sy < 0) sy = (int)left;
+    return (int)left;
+}
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+// 256-entry rows (255 symbols): on a non-decreasing row the answer is (number of entries <= count among the first 255) - 1: sixteen
+// unsigned 16-bit vector compares and popcounts, no data-dependent branch (the binary search mispredicts every other step).  The result is
+// CHECKED (row[s] <= count < row[s + 1]); a row that is not monotone there falls back to the reference's search, so any table decodes as before.
+__attribute__((target("avx2,popcnt"))) static inline int ac_search_256_avx2(const uint16_t *row, uint16_t count) {
+    const __m256i c = _mm256_set1_epi16((short)count);
+    unsigned le = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)(row + 16 * i));
+        const __m256i m = _mm256_cmpeq_epi16(_mm256_min_epu16(v, c), v);          // v <= count (unsigned)
+        unsigned bits = (unsigned)_mm256_movemask_epi8(m);                        // two bits per entry
+        if (i == 15) bits &= 0x3FFFFFFFu;                                         // entry 255 is not a symbol
+        le += (unsigned)_mm_popcnt_u32(bits);
+    }
+    const int s = (int)(le >> 1) - 1;
+    if (s < 0 || row[s] > count || (s < 254 && row[s + 1] <= count)) return -1;
+    return s;
+}
+static const bool g_ac_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt");
+#endif
+
+template <bool FAST256>
+static inline int ac_dec_step(scp_ac_dec *d, const uint16_t *row, int max_symbol) {
+    uint32_t low = d->low, high = d->high, value = d->value;
+    const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+    const uint16_t count = (uint16_t)((((uint64_t)value - (uint64_t)low + 1) * 0x10000ull - 1) / span);
+    int sy = -1;
+#if defined(__x86_64__)
+    if (FAST256) sy = ac_search_256_avx2(row, count);
+#endif
+    if (sy < 0) sy = ac_search_ref(row, count, max_symbol);
     const uint32_t c_low = row[sy], c_high = sy == max_symbol ? 0x10000u : (uint32_t)row[sy + 1];
-    d->high = (d->low - 1) + (uint32_t)((span * (uint64_t)c_high) >> 16);
-    d->low = d->low + (uint32_t)((span * (uint64_t)c_low) >> 16);
-    for (;;) {
-        if (d->low >= 0x80000000u || d->high < 0x80000000u) {
-            d->low <<= 1; d->high = (d->high << 1) | 1u; d->get();
-        } else if (d->low >= 0x40000000u && d->high < 0xC0000000u) {
-            d->low = (d->low << 1) & 0x7FFFFFFFu; d->high = (d->high << 1) | 0x80000001u;
-            d->value -= 0x40000000u; d->get();
-        } else break;
+    high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> 16);
+    low = low + (uint32_t)((span * (uint64_t)c_low) >> 16);
+    const uint32_t diff = low ^ high;
+    if (!(diff & 0x80000000u)) {                           // (1) k shared leading bits (k <= 31: low < high)
+        const int k = __builtin_clz(diff);
+        low <<= k;
+        high = (high << k) | ((1u << k) - 1u);
+        value = (value << k) | d->take(k);
     }
+    if (low >= 0x40000000u && high < 0xC0000000u) {        // (2) u underflow positions
+        const uint32_t l1 = ~(low << 1), h1 = high << 1;
+        const int a = l1 ? __builtin_clz(l1) : 32, b = h1 ? __builtin_clz(h1) : 32;
+        int u = a < b ? a : b;
+        if (u > 31) u = 31;
+        low = (low << u) & 0x7FFFFFFFu;
+        high = (high << u) | 0x80000000u | ((1u << u) - 1u);
+        value = ((value << u) ^ 0x80000000u) | d->take(u);
+    }
+    d->low = low; d->high = high; d->value = value;
     return sy;
+}
+
+extern "C" int scp_ac_dec_next(scp_ac_dec *d, const uint16_t *row) {
+    if (!d || !row) return SCP_EINVAL;
+    return ac_dec_step<false>(d, row, d->Lp - 2);
 }
 
 // decode n consecutive symbols, row i of the [n][Lp] table being the CDF of symbol i
 extern "C" int scp_ac_dec_run(scp_ac_dec *d, const uint16_t *cdf, int64_t n, int16_t *out) {
     if (!d || !cdf || !out || n < 0) return SCP_EINVAL;
-    for (int64_t i = 0; i < n; ++i) {
-        const int s = scp_ac_dec_next(d, cdf + i * d->Lp);
-        if (s < 0) return s;
-        out[i] = (int16_t)s;
-    }
+    const int Lp = d->Lp, max_symbol = Lp - 2;
+    // the table arrives by DMA (pinned memory, not in any cache) and the search touches 4 - 5 scattered lines of a 512-byte row: the rows a
+    // few symbols ahead are prefetched whole (without it a symbol costs two to three exposed memory latencies)
+    const int64_t ahead = 6;
+    const int lines = (Lp * 2 + 63) / 64;
+    bool fast = false;
+#if defined(__x86_64__)
+    fast = g_ac_avx2 && Lp == 256;
+#endif
+    auto run = [&](auto tag) {
+        constexpr bool F = decltype(tag)::value;
+        for (int64_t i = 0; i < n; ++i) {
+            if (i + ahead < n) {
+                const char *p = (const char *)(cdf + (i + ahead) * Lp);
+                for (int l = 0; l < lines; ++l) __builtin_prefetch(p + 64 * l, 0, 0);
+            }
+            out[i] = (int16_t)ac_dec_step<F>(d, cdf + i * Lp, max_symbol);
+        }
+    };
+    if (fast) run(std::true_type()); else run(std::false_type());
     return SCP_OK;
 }
 

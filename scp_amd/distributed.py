@@ -15,10 +15,14 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+def init(backend=None, force=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process, unless `force` / SCP_DIST_FORCE=1: then a
+    world of ONE is initialised too - RCCL library load, communicator creation and the device all-reduce path can be exercised on a
+    one-GPU box, tests/test_gpu_dist.py)."""
     rank, world, local = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("SCP_DIST_FORCE", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
@@ -156,7 +160,7 @@ def shard(items, rank, world):
 def reduce_summary(sums, device=None):
     """sums: [sum_bpp, sum_psnr, sum_chamfer, sum_time, count] of this rank -> the same five numbers over all ranks."""
     t = torch.tensor([float(x) for x in sums], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():          # (a world of one - init(force=True) - runs the collective too)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().tolist()
 

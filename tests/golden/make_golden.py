@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE in this container.
 
-    python tests/golden/make_golden.py [group ...]      # groups: xform oct kseq ctx e2e logits logits_tiefree swin cdf ac facts
+    python tests/golden/make_golden.py [group ...]      # groups: xform oct kseq ctx e2e logits logits_tiefree logits_full swin cdf ac facts
 
 Only data (inputs + expected outputs) is written; no reference source travels.  Every
 fixture records which reference call produced it.  The script needs
@@ -835,8 +835,43 @@ def gen_trainset():
              data=np.stack([it[0] for it in items]), pos=np.stack([it[1] for it in items]), label=np.stack([it[2] for it in items]))
 
 
+def gen_logits_full():
+    """Value checks of the model output at the sizes of BASELINE.json configs[3] / configs[4]: one FULL 8192-node window of the
+    Ford-like level-17 multi-level frame through the reference EHEM, and one full 1024-row window of the level-14 --cylin frame through the
+    reference OctAttention - rows sub-sampled to keep the fixtures small.  The windows' inputs come from the repository's CPU oracle (its tables are
+    pinned against the reference's datasets by the ctx_* fixtures); the expected outputs are the REFERENCE models' own."""
+    print("[logits_full]")
+    from oracle import scp_oracle as orc
+    # --- EHEM, Ford-like L17 multi-level: the last full window of the deepest level of shell 0
+    xyz = ford_like(synth_frame(0))
+    shells = orc.mullevel_shells(xyz, 17, "spher", data_type="ford")
+    ids, poss, pos_mm, data, _ = orc.ehem_mullevel_context([s["records"] for s in shells], 17)
+    sizes = [len(d) for d in data]
+    windows, _ = orc.ehem_coding_plan(sizes, 8192, True)
+    full = [(l, i, j) for (l, i, j) in windows if j - i == 8192]
+    l, i, j = full[len(full) // 2]
+    d8, p8 = data[l][i:j].astype(np.int64), np.ascontiguousarray(poss[l][:, i:j])
+    m = build_ref_ehem(0)
+    with torch.no_grad():
+        o1, o2 = m(torch.from_numpy(d8)[None].clone(), torch.from_numpy(p8)[None].clone(), enc=True)
+    save("logits_ehem_f17m_c8192", data=d8.astype(np.int16), pos=p8, out1_sub=o1[0, ::16].numpy(), out2_sub=o2[0, ::16].numpy(),
+         out1_sha=np.array(sha(o1.numpy())), seed=np.int32(0), stride=np.int32(16), level_index=np.int32(l), window_start=np.int32(i),
+         level_sizes=np.asarray(sizes, np.int64))
+    # --- OctAttention, L14 --cylin: a full window from the middle of the padded sequence
+    rec = orc.proc_pc(synth_frame(0), orc.kitti_qs(14), "cylin")["records"]
+    ids, pos, data, _ = orc.octattn_context(rec, 1024)
+    w0 = (len(data) // 2048) * 1024
+    d, p = data[w0:w0 + 1024].astype(np.int64), pos[w0:w0 + 1024]
+    mo = build_ref_octattn(0)
+    with torch.no_grad():
+        o = mo(torch.from_numpy(d)[None].clone(), torch.from_numpy(p)[None].clone())
+    save("logits_octattn_L14cylin_c1024", data=d.astype(np.int16), pos=p, out=o[0].numpy(), seed=np.int32(0), window_start=np.int32(w0),
+         n_rows=np.int32(len(data)))
+
+
 GROUPS = {"trainset": gen_trainset, "metrics": gen_metrics, "keys": gen_keys, "xform": gen_xform, "oct": gen_oct, "ctx": gen_ctx, "logits": gen_logits, "logits_tiefree": gen_logits_tiefree, "swin": gen_swin,
-          "cdf": gen_cdf, "ac": gen_ac, "e2e": gen_e2e, "e2e_octattn_mul": gen_e2e_octattn_mul, "facts": gen_facts, "frame_ints": gen_frame_ints}
+          "cdf": gen_cdf, "ac": gen_ac, "e2e": gen_e2e, "e2e_octattn_mul": gen_e2e_octattn_mul, "facts": gen_facts, "frame_ints": gen_frame_ints,
+          "logits_full": gen_logits_full}
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

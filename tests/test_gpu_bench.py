@@ -91,7 +91,7 @@ def test_bench_side_legs_fill_configs_decode_and_cli():
     d = out["decode"]
     assert d["decoded_occupancy_equals_encoded"] is True and d["fps"] > 0
     c = out["cli"]
-    assert c["streams_written"] == c["files"] == 5 and c["fps"] > 0 and abs(out["cli_over_bench"] - c["fps"] / out["value"]) < 1e-9
+    assert c["streams_written"] == c["files"] == 9 and c["files_timed"] == 3 and c["fps"] > 0 and abs(out["cli_over_bench"] - c["fps"] / out["value"]) < 1e-9
 
 
 def test_bench_decode_mode_times_the_decoder_and_checks_the_round_trip():

@@ -494,6 +494,12 @@ def test_ehem_tiefree_exact_knn_mode(dev, ehem, monkeypatch):
     assert e.max() <= LOGIT_TOL
 
 
+# fixtures on which no tie at rank 20 / 21 changes a row beyond the tolerance: there the bound against the reference's golden logits is ASSERTED
+# (logits_ehem_c8192: 9.3e-4 on sub-sampled rows of a full window, measured in rounds 3 - 5); on the others it is recorded and every row beyond
+# it must be explained by a tie (the two tests at the end of this file)
+EVERY_ROW_VS_REFERENCE = {"logits_ehem_c1", "logits_ehem_c7", "logits_ehem_lvl1_c6", "logits_ehem_c8192"}
+
+
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_ehem_*.npz"))))
 def test_ehem_logits_vs_reference_packed_path(dev, ehem, name):
     """The lattice-position goldens through forward_packed (the kernels the bench / CLI / decoder run: layernorm_rows,
@@ -514,6 +520,8 @@ def test_ehem_logits_vs_reference_packed_path(dev, ehem, name):
         models_ref.KNN_OVERRIDE = None
     d = max(np.abs(o1 - r1.numpy()).max(), np.abs(o2 - r2.numpy()).max() if o2.size else 0.0)
     parity_record(f"{name}/packed", max_dlogit_vs_reference=e.max(), rows_within_1e3_vs_reference=rows_ok, max_dlogit_vs_oracle_same_knn=d)
+    if name in EVERY_ROW_VS_REFERENCE:
+        assert e.max() <= LOGIT_TOL, e.max()
     # (the fraction is a recorded number, not a criterion: test_every_out_of_tolerance_lattice_row_is_explained_by_a_knn_tie and
     # test_given_the_reference_neighbour_choice_every_lattice_row_matches are the proof)
     assert d <= LOGIT_TOL, d
@@ -549,6 +557,8 @@ def test_ehem_logits_vs_reference(dev, ehem, name):
     print(f"{name}: vs reference (its own CPU top-k tie-breaking): max|dlogit| = {e.max():.3e}, "
           f"rows within 1e-3: {100 * rows_ok:.2f}%")
     parity_record(f"{name}/window", max_dlogit_vs_reference=e.max(), rows_within_1e3_vs_reference=rows_ok)
+    if name in EVERY_ROW_VS_REFERENCE:        # asserted against the REFERENCE's own logits, on the product's own neighbour lists
+        assert e.max() <= LOGIT_TOL, e.max()
     # The reference's neighbour choice among EXACTLY tied distances is an artefact of its top-k implementation
     # (std::partial_sort on CPU, radix-select on CUDA); rows whose 20th/21st neighbours tie can differ: the fraction of rows that
     # agree is recorded (profiles/parity_r3.json), the proof that every other row is a tie is in the two tests at the end of this file.
@@ -1302,13 +1312,14 @@ def _tied_points(feat, c, dev, rel=4e-6):
     return tied.cpu().numpy()
 
 
-@pytest.mark.parametrize("name", ["logits_ehem_b2_c256", "logits_ehem_c600", "logits_ehem_c1024", "logits_ehem_c8192", "logits_ehem_c7"])
+@pytest.mark.parametrize("name", ["logits_ehem_b2_c256", "logits_ehem_c600", "logits_ehem_c1024", "logits_ehem_c8192", "logits_ehem_c7", "logits_ehem_f17m_c8192"])
 def test_every_out_of_tolerance_lattice_row_is_explained_by_a_knn_tie(dev, ehem, monkeypatch, name):
     """Octree positions are lattice points: exactly tied distances at the 20th / 21st neighbour are common, and which of the tied
     candidates the reference keeps is decided by its top-k implementation.  Every row of the lattice fixtures that misses the 1e-3
     tolerance against the reference must be EXPLAINED by such a tie: the row itself, or a row in one of its three neighbour lists, has
     its 20th and 21st candidates tied in one of the three searches (float64 distances of the features the kernel saw).  unexplained == 0
-    is asserted; the fraction of rows inside the tolerance is only recorded."""
+    is asserted; the fraction of rows inside the tolerance is only recorded.  A window WITHOUT any tied point has nothing to explain: there
+    the bound against the reference itself is asserted - every row within 1e-3 (round 5; logits_ehem_c8192 is such a window)."""
     z = golden(name)
     data, pos = _ehem_case(z)
     B, c = data.shape[:2]
@@ -1323,8 +1334,6 @@ def test_every_out_of_tolerance_lattice_row_is_explained_by_a_knn_tie(dev, ehem,
         e2 = np.abs(o2[b, ::st] - w2[b]).max(1) if o2.shape[1] else np.zeros(0)
         bad_tok = np.concatenate([2 * st * np.where(e1 > LOGIT_TOL)[0], 2 * st * np.where(e2 > LOGIT_TOL)[0] + 1]).astype(np.int64)
         total_bad += len(bad_tok)
-        if not len(bad_tok):
-            continue
         ce = c + (c & 1)                                       # the window as the model sees it (ehem.py:92-99 pads odd windows)
         tied = np.zeros(ce, bool)
         lists = []
@@ -1337,12 +1346,17 @@ def test_every_out_of_tolerance_lattice_row_is_explained_by_a_knn_tie(dev, ehem,
             ok = tied[t] or any(tied[np.clip(ix[t], 0, ce - 1)].any() for ix in lists)
             unexplained += 0 if ok else 1
     rows = sum(len(np.abs(o1[b, ::st])) + len(np.abs(o2[b, ::st])) for b in range(B))
-    parity_record(f"{name}/tie proof", rows=rows, rows_outside_1e3=total_bad, unexplained=unexplained, tied_points=tied_pts)
-    print(f"{name}: {total_bad} of {rows} rows outside 1e-3, unexplained {unexplained} (points with a tie at rank 20 / 21: {tied_pts})")
+    worst = max(float(np.abs(o1[b, ::st] - w1[b]).max()) for b in range(B))
+    if o2.shape[1]:
+        worst = max(worst, max(float(np.abs(o2[b, ::st] - w2[b]).max()) for b in range(B)))
+    parity_record(f"{name}/tie proof", rows=rows, rows_outside_1e3=total_bad, unexplained=unexplained, tied_points=tied_pts, max_dlogit_vs_reference=worst)
+    print(f"{name}: {total_bad} of {rows} rows outside 1e-3, unexplained {unexplained} (points with a tie at rank 20 / 21: {tied_pts}), max|dlogit| vs reference {worst:.2e}")
     assert unexplained == 0
+    if tied_pts == 0:                 # tie-free window: the product's own neighbour lists are the reference's, so is every logit row
+        assert total_bad == 0 and worst <= LOGIT_TOL, (total_bad, worst)
 
 
-@pytest.mark.parametrize("name", ["logits_ehem_b2_c256", "logits_ehem_c600", "logits_ehem_c1024", "logits_ehem_c8192"])
+@pytest.mark.parametrize("name", ["logits_ehem_b2_c256", "logits_ehem_c600", "logits_ehem_c1024", "logits_ehem_c8192", "logits_ehem_f17m_c8192"])
 def test_given_the_reference_neighbour_choice_every_lattice_row_matches(dev, ehem, monkeypatch, name):
     """The constructive half of the proof: the CPU oracle (the reference's algorithm, torch.topk's own tie-breaking - its logits ARE the
     fixture's) records the neighbour lists of its three searches; the product forward (packed path, every kernel of the encoder) is
