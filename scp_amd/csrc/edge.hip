@@ -13,7 +13,11 @@ __global__ __launch_bounds__(256) void edge_gather_max_kernel(const float *__res
                                                              const float *__restrict__ shift, int n, int Cout, int k,
                                                              float *__restrict__ out, int out_stride, int64_t total /* B*n*Cout/4 */,
                                                              int64_t ldu, int64_t ldv) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // XCD-affine block order (round 5): workgroup b runs on XCD b & 7; give every XCD one contiguous eighth of the points, so that the u rows
+    // a window's points gather (2 - 8 MB per 8192-point window) are fetched into ONE XCD's L2 instead of all eight (PMC before: 2.9 x the
+    // unique bytes from HBM, at the achievable HBM ceiling).  The grid is a multiple of 8 (launcher), so the map is a bijection.
+    const int64_t blk = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t g = blk * 256 + threadIdx.x;
     if (g >= total) return;
     const int c4 = Cout >> 2;
     const int64_t pt = g / c4;          // global point index b*n + i
@@ -62,7 +66,7 @@ extern "C" SCP_API int scp_edge_gather_max_ld(const float *u, int64_t ldu, const
     // algorithmic HBM bytes: every u row, every v row and every output row once, and the index lists (the 20 gathered rows per point are
     // re-reads; PMC: the kernel pulls 2.9 x this through HBM at 6.4 TB/s, profiles/r4_pmc_traffic.json)
     SCP_PROF(SCP_PROF_EDGE_GATHER, stream, (double)B * n * (12.0 * Cout + 4.0 * k));
-    hipLaunchKernelGGL(edge_gather_max_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, u, v, idx, scale,
+    hipLaunchKernelGGL(edge_gather_max_kernel, dim3((unsigned)(cdiv64(cdiv64(total, 256), 8) * 8)), dim3(256), 0, (hipStream_t)stream, u, v, idx, scale,
                        shift, n, Cout, k, out, out_stride, total, ldu, ldv);
     LAUNCH_CHECK();
     return SCP_OK;

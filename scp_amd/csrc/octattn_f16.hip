@@ -62,12 +62,18 @@ __global__ __launch_bounds__(256) void oa_absmax_kernel(const float *__restrict_
     if ((threadIdx.x & 63) == 0 && mx == mx) atomicMax(out, __float_as_uint(fminf(mx, 3.0e38f)));
 }
 
-// workgroup = one 32-token tile of one (batch, head): thread (t = tid >> 3, s = tid & 7) walks float2 pieces s, s + 8, ... of row t
+// workgroup = one 32-token tile of one (batch, head): thread (t = tid >> 3, s = tid & 7) walks float2 pieces s, s + 8, ... of row t.
+// Round 5: the Q rows and the K image are assembled in LDS and leave as 16-byte stores of whole rows / one linear 22 KiB block.  (Rounds 1 - 4
+// stored every converted pair straight from the registers: 40 four-byte stores per thread, 32-byte segments of eight different rows per
+// wave instruction - the kernel moved its 5.3 GB per L14 layer at 0.85 TB/s, 81 % of its wave cycles issue-stalled, profiles/r4i_octattn_L14_*.)
+// Same arithmetic, same bits.
 __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ q_u, const float *__restrict__ k, const float *__restrict__ k_u,
                                                      const float *__restrict__ v, int64_t ldkv, int c, int H, int nt, const unsigned *__restrict__ vmax_bits,
                                                      _Float16 *__restrict__ qp, float *__restrict__ isq, float2 *__restrict__ diag,
                                                      char *__restrict__ kimg, char *__restrict__ vimg) {
     __shared__ float vt[32][FHD + 1];
+    __shared__ __attribute__((aligned(16))) char kst[FK_IMG];              // the K image of this (tile, head), as it will lie in memory
+    __shared__ __attribute__((aligned(16))) _Float16 qst[32][2 * FHP];     // the 32 Q rows (hi plane | lo plane)
     const int tid = threadIdx.x, t = tid >> 3, s = tid & 7;
     const int tile = blockIdx.x % nt, b = blockIdx.x / nt, head = blockIdx.y;
     const int D = H * FHD, cpad = nt * 32;
@@ -80,13 +86,22 @@ __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ 
 
     float2 qv[10], kv[10];
     float qm = 0.f, km = 0.f, sii = 0.f, dz = 0.f;                   // the two diagonal terms q_i.k_i, q_i.ku_i: plain fp32
+    // all 40 loads of the thread first (80 registers): written as one loop with their use, the compiler keeps only one iteration's four
+    // loads in flight (it waits for an iteration's data before it issues the next-but-one's) and the kernel is latency-bound
+    float2 ld_q[10], ld_k[10], ld_v[10], ld_u[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int p = s + 8 * i;
+        const int pc = p < 75 ? p : 74;
+        ld_q[i] = *(const float2 *)(q_u + row + 2 * pc); ld_k[i] = *(const float2 *)(k + rowk + 2 * pc);
+        ld_v[i] = *(const float2 *)(v + rowk + 2 * pc); ld_u[i] = *(const float2 *)(k_u + rowk + 2 * pc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         const int p = s + 8 * i;
         const bool ok = real && p < 75;
-        const int pc = p < 75 ? p : 74;
-        const float2 a = *(const float2 *)(q_u + row + 2 * pc), bb = *(const float2 *)(k + rowk + 2 * pc), cc = *(const float2 *)(v + rowk + 2 * pc),
-                     uu = *(const float2 *)(k_u + rowk + 2 * pc);
+        const float2 a = ld_q[i], bb = ld_k[i], cc = ld_v[i], uu = ld_u[i];
         qv[i] = ok ? a : make_float2(0.f, 0.f);
         kv[i] = ok ? bb : make_float2(0.f, 0.f);
         qm = fmaxf(qm, fmaxf(fabsf(qv[i].x), fabsf(qv[i].y)));
@@ -105,10 +120,9 @@ __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ 
     oa_pow2_scale(km, ks, iks);
 
     const size_t th = ((size_t)b * cpad + tok) * H + head;
-    _Float16 *qrow = qp + th * (2 * FHP);
-    char *kbase = kimg + (((size_t)b * nt + tile) * H + head) * FK_IMG;
-    _Float16 *krow = (_Float16 *)kbase + t * FKLD;
-    if (s == 0) { isq[th] = iqs; diag[th] = make_float2(sii, dz); ((float *)(kbase + FK_ISK))[t] = iks; }
+    _Float16 *qrow = qst[t];
+    _Float16 *krow = (_Float16 *)kst + t * FKLD;
+    if (s == 0) { isq[th] = iqs; diag[th] = make_float2(sii, dz); ((float *)(kst + FK_ISK))[t] = iks; }
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         const int p = s + 8 * i;                      // float2 piece; pieces 75..79 are the zero padding (dims 150..159)
@@ -123,7 +137,24 @@ __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ 
         *(h16x2 *)(krow + 2 * p) = kh;
         *(h16x2 *)(krow + FK_PLANE + 2 * p) = kl;
     }
+    // the bytes of the K image no row writes (dims 160 .. 167 of every row, the tail behind the scales) go out as zeros: the attention kernel
+    // copies the image as a whole and never reads them, but the workspace stays deterministic
+    if (s == 0) {
+        *(uint4 *)(krow + FHP) = make_uint4(0, 0, 0, 0);
+        *(uint4 *)(krow + FK_PLANE + FHP) = make_uint4(0, 0, 0, 0);
+    }
+    for (int e = FK_ISK + 128 + 16 * tid; e < FK_IMG; e += 16 * 256) *(uint4 *)(kst + e) = make_uint4(0, 0, 0, 0);
     __syncthreads();
+    {   // K image: one linear block; Q rows: 640 contiguous bytes per token, H x 640 bytes apart
+        char *kbase = kimg + (((size_t)b * nt + tile) * H + head) * FK_IMG;
+        for (int e = tid; e < FK_IMG / 16; e += 256) *(uint4 *)(kbase + 16 * e) = *(const uint4 *)(kst + 16 * e);
+        constexpr int QV = 2 * FHP * 2 / 16;          // 16-byte pieces per Q row (40)
+        for (int e = tid; e < 32 * QV; e += 256) {
+            const int r = e / QV, pce = e - r * QV;
+            const size_t thr = ((size_t)b * cpad + tile * 32 + r) * H + head;
+            *(uint4 *)((char *)(qp + thr * (2 * FHP)) + 16 * pce) = *(const uint4 *)((const char *)qst[r] + 16 * pce);
+        }
+    }
     // V^T: thread = (dim d, group g of 8 permuted key positions): position 8 g + j holds key 16 (g >> 1) + 4 (g & 1) + (j & 3) + 8 (j >> 2)
     _Float16 *vbase = (_Float16 *)(vimg + (((size_t)b * nt + tile) * H + head) * FV_IMG);
     for (int e = tid; e < FHP * 4; e += 256) {

@@ -198,6 +198,10 @@ struct RcLnLinArgs {
     // the next four are the key heads, the last four the value heads, written as bf16 hi / lo planes in the layout of the plane-fed
     // attention (csrc/attn.hip: swin_attn_planes_kernel): planes = [4][Tp][256] bf16 = K hi, K lo, V^T hi, V^T lo; plane_bytes = Tp * 512
     __bf16 *planes; int64_t plane_bytes; int nq;
+    // Round 5, short launches (the decoder's one-window forwards: 4 - 64 tiles on 256 CUs, every launch as long as ONE tile's serial chain of
+    // steps): `ngroups` workgroups share a tile, each runs LayerNorm on the tile's rows and then its own run of nsteps / ngroups steps (an even
+    // number, never straddling query / key / value).  Every output channel is still one accumulation chain of one wave: identical bits.
+    int ngroups;
 };
 
 #define RC_DS_WRITE(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(val), "n"(off) : "memory")
@@ -388,7 +392,10 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
         sb[i] = b; sbw[i] = b + (a.wbeta ? a.wbeta[i] : 0.f);
     }
     __syncthreads();
-    int tile = blockIdx.x;
+    const int ngr = a.ngroups > 1 ? a.ngroups : 1;
+    int tile = blockIdx.x / ngr;
+    const int tstride = (int)gridDim.x / ngr;                        // (the grid is a multiple of ngroups)
+    const int j0 = (int)(blockIdx.x % ngr) * (nsteps / ngr), j1 = j0 + nsteps / ngr;     // this workgroup's steps
     if (tile >= ntiles) return;
     char *bounce = smem + RC_OFF_BOUNCE + L.w * RC_BOUNCE;
     unsigned bw[4];
@@ -412,8 +419,8 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
 
     // the first step's slots and the first tile's rows (k = 16 s + 8 h + i of row `col`: natural k order); every later tile's rows are
     // requested during the second-to-last step of the tile before it
-    rc_issue_rowchunk(L, a.Whi, a.Wlo, 0, smem);
-    rc_issue_rowchunk(L, a.Whi, a.Wlo, 1, smem + RC_SLOT);
+    rc_issue_rowchunk(L, a.Whi, a.Wlo, 2 * j0, smem);
+    rc_issue_rowchunk(L, a.Whi, a.Wlo, 2 * j0 + 1, smem + RC_SLOT);
     float v[128];
     auto xrow = [&](int t) {
         const int r = t * RC_ROWS + 32 * L.w + L.col;
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
         RC_DS_READ4_WAIT(A[0][1], ad0, 16384, A[0][3], ad0, RC_SLOT + 16384, A[0][0], ad0, 0, A[0][2], ad0, RC_SLOT);
     }
     int gstep = 0;
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; tile < ntiles; tile += tstride) {
         const int m0 = tile * RC_ROWS;
         const int row = m0 + 32 * L.w + L.col;
         const int rowc = row < a.M ? row : a.M - 1;
@@ -458,28 +465,28 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
         const int64_t rows_left = (int64_t)a.M - m0;
         const int64_t span = (rows_left < RC_ROWS ? rows_left : RC_ROWS) * a.ldo * 4;
         const __amdgpu_buffer_rsrc_t rs = (a.probe & 1) ? rs_none : __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)m0 * a.ldo, 0, (int)span, 0x00020000);
-        const bool more = tile + (int)gridDim.x < ntiles;
-        const float *xnext = xrow(more ? tile + (int)gridDim.x : tile);
+        const bool more = tile + tstride < ntiles;
+        const float *xnext = xrow(more ? tile + tstride : tile);
 
         rf32x16 acc[2][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                               // the first step's accumulators start from its bias (the later ones' are
-            const rf32x4 b0 = *(const rf32x4 *)(tb + 8 * q), b1 = *(const rf32x4 *)(tb + 32 + 8 * q);   // set inside the step before)
+            const rf32x4 b0 = *(const rf32x4 *)(tb + 64 * j0 + 8 * q), b1 = *(const rf32x4 *)(tb + 64 * j0 + 32 + 8 * q);   // set inside the step before)
 #pragma unroll
             for (int u = 0; u < 4; ++u) { acc[0][0][4 * q + u] = b0[u]; acc[0][1][4 * q + u] = b1[u]; }
         }
         if (!KV) {
-        for (int j = 0; j < nsteps; j += 2) {
+        for (int j = j0; j < j1; j += 2) {
             // step j -> acc[0], stores acc[1] (step j - 1); step j + 1 -> acc[1], stores acc[0]
-            if (j + 2 == nsteps)
-                rc_ll_step<true, PROBE>(L, a, smem, gstep & 1, acc[0][0], acc[0][1], acc[1][0], acc[1][1], Xh, Xl, 2 * (j + 1), j ? rs : rs_none, voff,
+            if (j + 2 == j1)
+                rc_ll_step<true, PROBE>(L, a, smem, gstep & 1, acc[0][0], acc[0][1], acc[1][0], acc[1][1], Xh, Xl, 2 * (j + 1), j > j0 ? rs : rs_none, voff,
                                  ldo_bytes, 64 * (j - 1), bw, br0, xnext, v, A, tb + 64 * (j + 1), DBG ? tsl : nullptr, wr_hi, wr_lo);
             else
-                rc_ll_step<false, PROBE>(L, a, smem, gstep & 1, acc[0][0], acc[0][1], acc[1][0], acc[1][1], Xh, Xl, 2 * (j + 1), j ? rs : rs_none, voff,
+                rc_ll_step<false, PROBE>(L, a, smem, gstep & 1, acc[0][0], acc[0][1], acc[1][0], acc[1][1], Xh, Xl, 2 * (j + 1), j > j0 ? rs : rs_none, voff,
                                   ldo_bytes, 64 * (j - 1), bw, br0, xnext, v, A, tb + 64 * (j + 1), DBG ? tsl : nullptr, wr_hi, wr_lo);
             ++gstep;
-            rc_ll_step<false, PROBE>(L, a, smem, gstep & 1, acc[1][0], acc[1][1], acc[0][0], acc[0][1], Xh, Xl, (j + 2 < nsteps) ? 2 * (j + 2) : 0, rs, voff,
-                              ldo_bytes, 64 * j, bw, br0, xnext, v, A, tb + 64 * ((j + 2 < nsteps) ? j + 2 : 0), DBG ? tsl : nullptr, wr_hi, wr_lo);
+            rc_ll_step<false, PROBE>(L, a, smem, gstep & 1, acc[1][0], acc[1][1], acc[0][0], acc[0][1], Xh, Xl, (j + 2 < j1) ? 2 * (j + 2) : 2 * j0, rs, voff,
+                              ldo_bytes, 64 * j, bw, br0, xnext, v, A, tb + 64 * ((j + 2 < j1) ? j + 2 : j0), DBG ? tsl : nullptr, wr_hi, wr_lo);
             ++gstep;
         }
         stamp(t_step);
@@ -492,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) o[q][u] = acc[1][blk][4 * q + u];
-            rc_store_block(L, bounce, o, rs, ldo_bytes, voff, 64 * (nsteps - 1) + 32 * blk);
+            rc_store_block(L, bounce, o, rs, ldo_bytes, voff, 64 * (j1 - 1) + 32 * blk);
         }
         } else {
         // ---- query | key | value (or key | value) with the keys and values leaving as attention planes --------------------------------------
@@ -560,23 +567,32 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         auto role = [&](int j) { return j < nq ? 0 : (j < nq + 4 ? 1 : 2); };                     // 0 query, 1 key, 2 value
+        if (role(j0) == 2) {                                         // a workgroup whose run starts at a value step (ngroups > 1): its first accumulators
+#pragma unroll                                                       // in the swapped layout (lane = channel, register = row), as rc_ll_step<.., NSWAP> sets them
+            for (int blk = 0; blk < 2; ++blk) {
+                const float bb = sbl[64 * j0 + 32 * blk], bwv = sbl[64 * j0 + 32 * blk + 1024];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][blk][r] = ((maskh >> (8 * (r >> 2) + (r & 3))) & 1u) ? bwv : bb;
+            }
+        }
         auto post = [&](int j, const rf32x16 &c0, const rf32x16 &c1) {
             const int r = role(j);
             if (r == 1) store_k(c0, c1, j - nq);
             else if (r == 2) store_v(c0, c1, j - nq - 4);
         };
-        for (int j = 0; j < nsteps; j += 2) {
+        for (int j = j0; j < j1; j += 2) {
             // step j -> acc[0], step j + 1 -> acc[1]; a query step's results are stored by the step behind it
-            const bool val = role(j) == 2, nval = role(j + 2 < nsteps ? j + 2 : 0) == 2;
-            const __amdgpu_buffer_rsrc_t rsa = (j && role(j - 1) == 0) ? rs : rs_none, rsb = role(j) == 0 ? rs : rs_none;
-            const int gn = (j + 2 < nsteps) ? 2 * (j + 2) : 0;
-            const float *tbn = tb + 64 * ((j + 2 < nsteps) ? j + 2 : 0), *sbn1 = sbl + 64 * (j + 1), *sbn2 = sbl + 64 * ((j + 2 < nsteps) ? j + 2 : 0);
+            const int jn = j + 2 < j1 ? j + 2 : j0;                  // the step behind this pair (the next tile's first one at the end of the run)
+            const bool val = role(j) == 2, nval = role(jn) == 2;
+            const __amdgpu_buffer_rsrc_t rsa = (j > j0 && role(j - 1) == 0) ? rs : rs_none, rsb = role(j) == 0 ? rs : rs_none;
+            const int gn = 2 * jn;
+            const float *tbn = tb + 64 * jn, *sbn1 = sbl + 64 * (j + 1), *sbn2 = sbl + 64 * jn;
 #define RC_STEP_A(LX, SW) rc_ll_step<LX, PROBE, SW, SW>(L, a, smem, gstep & 1, acc[0][0], acc[0][1], acc[1][0], acc[1][1], Xh, Xl, 2 * (j + 1), rsa, voff, ldo_bytes, \
                                                 64 * (j - 1), bw, br0, xnext, v, A, tb + 64 * (j + 1), DBG ? tsl : nullptr, wr_hi, wr_lo, sbn1, maskh)
 #define RC_STEP_B(SW, NSW) rc_ll_step<false, PROBE, SW, NSW>(L, a, smem, gstep & 1, acc[1][0], acc[1][1], acc[0][0], acc[0][1], Xh, Xl, gn, rsb, voff, ldo_bytes, 64 * j, bw, \
                                                      br0, xnext, v, A, tbn, DBG ? tsl : nullptr, wr_hi, wr_lo, sbn2, maskh)
             if (!val) RC_STEP_A(false, false);
-            else if (j + 2 == nsteps) RC_STEP_A(true, true);
+            else if (j + 2 == j1) RC_STEP_A(true, true);
             else RC_STEP_A(false, true);
             ++gstep;
             post(j, acc[0][0], acc[0][1]);
@@ -588,6 +604,18 @@ __global__ __launch_bounds__(256, 1) void rc_ln_linear_kernel(const RcLnLinArgs 
 #undef RC_STEP_B
         }
         stamp(t_step);
+        if (role(j1 - 1) == 0) {                                     // a run that ENDS on a query step (ngroups > 1): nobody behind it stores its results
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                rf32x4 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) o[q][u] = acc[1][blk][4 * q + u];
+                rc_store_block(L, bounce, o, rs, ldo_bytes, voff, 64 * (j1 - 1) + 32 * blk);
+            }
+        }
         }
         stamp(t_drain);
         ++n_tiles;
@@ -1342,6 +1370,18 @@ __global__ __launch_bounds__(256, 1) void rc_edge_mlp_kernel(const RcEdgeArgs a)
 
 extern "C" SCP_API double scp_gelu_prescale(void) { return (double)SCP_GELU_S; }
 
+// workgroups per tile of a short rc_ln_linear launch (RcLnLinArgs.ngroups): the largest divisor g of nsteps / 2 with ntiles * g <= the CU count
+// (every workgroup then owns exactly one (tile, run of steps) and the launch lasts LayerNorm + nsteps / g steps instead of LayerNorm + nsteps)
+static int rc_ll_groups(int ntiles, int nsteps, int ncu) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("SCP_RC_GROUPS"); on = (e && e[0] == '0') ? 0 : 1; }      // SCP_RC_GROUPS=0: A/B bracket (identical bits)
+    int best = 1;
+    if (on)
+        for (int g = 2; g <= nsteps / 2; ++g)
+            if ((nsteps / 2) % g == 0 && (int64_t)ntiles * g <= ncu) best = g;
+    return best;
+}
+
 static unsigned long long *g_rc_dbg = nullptr;   // diagnostic only (tools/mb_rowchain_probe.py): [workgroup][wave][8] cycle sums
 extern "C" SCP_API int scp_rc_debug_buffer(unsigned long long *dev_buf) { g_rc_dbg = dev_buf; return SCP_OK; }
 
@@ -1382,7 +1422,8 @@ extern "C" SCP_API int scp_swin_ln_linear(const float *x, int64_t ldx, const flo
     const int ntiles = (M + RC_ROWS - 1) / RC_ROWS;
     const int ncu = rc_num_cu();
     SCP_PROF(SCP_PROF_LN_LINEAR, stream, 2.0 * M * 256.0 * N);
-    hipLaunchKernelGGL(rc_ln_linear_kernel<0>, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
+    a.ngroups = rc_ll_groups(ntiles, N / 64, ncu);
+    hipLaunchKernelGGL(rc_ln_linear_kernel<0>, dim3((unsigned)(a.ngroups > 1 ? ntiles * a.ngroups : (ntiles < ncu ? ntiles : ncu))), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;
 }
@@ -1408,7 +1449,8 @@ extern "C" SCP_API int scp_swin_ln_qkv(const float *x, int64_t ldx, const float 
     a.planes = (__bf16 *)planes; a.plane_bytes = Tp * 512; a.nq = N / 64 - 8;
     const int ntiles = M / RC_ROWS, ncu = rc_num_cu();
     SCP_PROF(SCP_PROF_LN_LINEAR, stream, 2.0 * M * 256.0 * N);
-    hipLaunchKernelGGL((rc_ln_linear_kernel<0, true>), dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
+    a.ngroups = rc_ll_groups(ntiles, N / 64, ncu);
+    hipLaunchKernelGGL((rc_ln_linear_kernel<0, true>), dim3((unsigned)(a.ngroups > 1 ? ntiles * a.ngroups : (ntiles < ncu ? ntiles : ncu))), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;
 }

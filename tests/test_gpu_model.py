@@ -233,6 +233,44 @@ def gpu_knn_for_oracle(dev):
     return f
 
 
+class _KnnLists:
+    """Records the neighbour lists of every kNN call of a GPU forward (both entry points) and replays them, in call order, to the CPU
+    oracle as its KNN_OVERRIDE: the oracle then computes with EXACTLY the neighbour sets the product used.  (gpu_knn_for_oracle above
+    runs the HIP search on the ORACLE's features instead - the same sets only as long as no two candidates lie within the float noise of
+    the two feature computations; the full-size Ford-like window has such pairs.)"""
+
+    def __init__(self, monkeypatch):
+        from scp_amd import native
+        self.lists = []
+        k1, k2 = native.knn_topk, native.knn_topk_packed
+
+        def topk(x, k):
+            idx = k1(x, k)
+            self.lists.append(("window", idx.cpu().long()))
+            return idx
+
+        def topk_packed(x, ctab, thr0=None):
+            idx = k2(x, ctab, thr0)
+            self.lists.append(("packed", idx.cpu().long()))
+            return idx
+
+        monkeypatch.setattr(native, "knn_topk", topk)
+        monkeypatch.setattr(native, "knn_topk_packed", topk_packed)
+
+    def replay(self, B, c):
+        """-> a KNN_OVERRIDE for models_ref.ehem_forward on B windows of c nodes (ce = c rounded up to even, ehem.py:92-99)."""
+        ce = c + (c & 1)
+        cp = -(-ce // 512) * 512
+        calls = iter(self.lists)
+
+        def f(x, k):
+            kind, idx = next(calls)
+            if kind == "window":
+                return idx[:, :ce, :k]
+            return torch.stack([idx[b * cp:b * cp + ce, :k] - b * cp for b in range(B)])      # (windows shorter than 20 nodes ask for k = n)
+        return f
+
+
 def test_edge_conv_matches_oracle_formulation(dev, ehem):
     """split-GEMM + gather/max == cat(f_j - f_i, f_i) conv + BN + LeakyReLU + max (dgcnn.py:48-71), same neighbours."""
     from oracle import models_ref
@@ -501,18 +539,19 @@ EVERY_ROW_VS_REFERENCE = {"logits_ehem_c1", "logits_ehem_c7", "logits_ehem_lvl1_
 
 
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_ehem_*.npz"))))
-def test_ehem_logits_vs_reference_packed_path(dev, ehem, name):
+def test_ehem_logits_vs_reference_packed_path(dev, ehem, monkeypatch, name):
     """The lattice-position goldens through forward_packed (the kernels the bench / CLI / decoder run: layernorm_rows,
     gemm_split, mlp_fused, hierarchical concat) with the same two assertions as the per-window test below."""
     z = golden(name)
     data, pos = _ehem_case(z)
+    rec = _KnnLists(monkeypatch)
     o1, o2 = _run_packed(ehem, data, pos, dev)
     st, w1, w2 = _want_rows(z)
     e = _row_err(o1, o2, st, w1, w2)
     rows_ok = (e.max(1) <= LOGIT_TOL).mean()
     from oracle import models_ref
     sd = {k: v.cpu() for k, v in ehem.state_dict().items()}
-    models_ref.KNN_OVERRIDE = gpu_knn_for_oracle(dev)
+    models_ref.KNN_OVERRIDE = rec.replay(data.shape[0], data.shape[1])      # the oracle with the neighbour lists this forward used
     try:
         with torch.no_grad():
             r1, r2 = models_ref.ehem_forward(sd, data, pos)
@@ -534,12 +573,13 @@ ROWS_OK_MIN = {"logits_ehem_b2_c256": 0.985,   # (no longer asserted: kept as th
                "logits_ehem_c8192": 1.0, "logits_ehem_lvl1_c6": 1.0}      # measured: 0.9902 / 0.9971 / 0.9933 / 1 / 1 / 1 / 1
 
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "logits_ehem_*.npz"))))
-def test_ehem_logits_vs_reference(dev, ehem, name):
+def test_ehem_logits_vs_reference(dev, ehem, monkeypatch, name):
     z = golden(name)
     data = torch.from_numpy(z["data"].astype(np.int64))
     pos = torch.from_numpy(z["pos"])
     if data.dim() == 3:
         data, pos = data[None], pos[None]
+    rec = _KnnLists(monkeypatch)
     o1, o2 = ehem(data.to(dev), pos.to(dev), enc=True)
     o1, o2 = o1.cpu().numpy(), o2.cpu().numpy()
     if "out1_sub" in z:
@@ -562,10 +602,10 @@ def test_ehem_logits_vs_reference(dev, ehem, name):
     # The reference's neighbour choice among EXACTLY tied distances is an artefact of its top-k implementation
     # (std::partial_sort on CPU, radix-select on CUDA); rows whose 20th/21st neighbours tie can differ: the fraction of rows that
     # agree is recorded (profiles/parity_r3.json), the proof that every other row is a tie is in the two tests at the end of this file.
-    # ALL rows agree to 1e-3 with the CPU oracle once it is given the same neighbour sets:
+    # ALL rows agree to 1e-3 with the CPU oracle once it is given the same neighbour sets (the lists this very forward used):
     from oracle import models_ref
     sd = {k: v.cpu() for k, v in ehem.state_dict().items()}
-    models_ref.KNN_OVERRIDE = gpu_knn_for_oracle(dev)
+    models_ref.KNN_OVERRIDE = rec.replay(data.shape[0], data.shape[1])
     try:
         with torch.no_grad():
             r1, r2 = models_ref.ehem_forward(sd, data, pos)
@@ -1148,6 +1188,34 @@ def test_swin_ln_qkv_planes_are_the_split_of_the_fp32_projection(dev, M, N):
         if q is not None:
             assert torch.equal(q, ref[:, :256].contiguous())
         assert torch.equal(kv.t.view(torch.int16), want.t.view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [768, 512, 256])
+def test_short_ln_linear_launches_split_a_tile_over_workgroups_with_identical_bits(dev, N):
+    """Round 5 (decoder latency): a launch with fewer tiles than CUs gives every tile to several workgroups, each running LayerNorm and its own
+    run of 64-channel steps (RcLnLinArgs.ngroups).  Every output channel is still one wave's accumulation chain: the rows of short launches
+    (128 ... 8192 rows: 6, 3, 2 or 1 workgroups per tile) equal the same rows inside a long launch (548 tiles, one workgroup each) bit for bit -
+    q, key planes, value planes, with and without a valid mask."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(N)
+    Mbig = 70144
+    x = (torch.randn((Mbig, 256), generator=g) * 1.5 + 0.3).to(dev)
+    gamma, beta = (1 + 0.1 * torch.randn(256, generator=g)).to(dev), (0.1 * torch.randn(256, generator=g)).to(dev)
+    valid = (torch.rand(Mbig, generator=g) > 0.1).float().to(dev)
+    W, b = (torch.randn((N, 256), generator=g) * 0.05).to(dev), (torch.randn(N, generator=g) * 0.1).to(dev)
+    fw = native.LnFoldedWeight(W, gamma, beta)
+    for vm in (valid, None):
+        big = native.swin_ln_linear(x, fw, b, 1e-5, vm)
+        bigq = native.swin_ln_qkv(x, fw, b, 1e-5, vm) if N != 256 else None
+        for M in (128, 512, 2048, 5504, 8192, 16384, 33024):
+            xs, vs = x[:M].contiguous(), None if vm is None else vm[:M].contiguous()
+            assert torch.equal(native.swin_ln_linear(xs, fw, b, 1e-5, vs), big[:M]), (N, M)
+            if bigq is not None:
+                q, kv = native.swin_ln_qkv(xs, fw, b, 1e-5, vs)
+                if q is not None:
+                    assert torch.equal(q, bigq[0][:M]), (N, M)
+                assert torch.equal(kv.t.view(torch.int16), bigq[1].t[:, :M].view(torch.int16)), (N, M)
 
 
 @pytest.mark.gpu

@@ -7,7 +7,7 @@ timeout 600 python tools/decode_cprofile.py > $O/decode_cprofile.txt 2>&1
 timeout 900 python -m pytest tests/test_gpu_dist.py tests/test_gpu_bench.py -x -q > $O/pytest_dist_bench.txt 2>&1; tail -3 $O/pytest_dist_bench.txt
 timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_e2e.py -x -q -k "f17m or L14cylin or c8192 or host_transform or batched" > $O/pytest_new.txt 2>&1; tail -3 $O/pytest_new.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_decode -o decode -- python3 $GRAFT_REPO_ROOT/bench.py --decode --steps 2 --warmup 1 > $O/prof_decode.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_decode -- python3 $GRAFT_REPO_ROOT/bench.py --decode --steps 2 --warmup 1 > $O/prof_decode.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$O/prof_decode/**/*kernel_stats.csv", recursive=True)
