@@ -35,6 +35,10 @@ SCP_API int scp_get_attention_variant(void);   /* 1 = default; anything else is 
 /* persistent workgroups of the row-chain launches (0 = one per CU of the device): for launches on a stream created with a CU mask
  * (tools/mb_cumask.py), whose CU set is smaller than the device's */
 SCP_API int scp_rc_set_grid(int32_t workgroups);
+/* which kernel scp_swin_post_attn launches: -1 (default) = by launch size (the wide kernel - 32 rows per workgroup, the waves split the output
+ * channels - while its tiles fit the chip twice, the chain kernel beyond), 0 = the chain kernel always, 1 = the wide kernel always.  The two give
+ * identical bits per row; the switch is the bracket of the test that asserts it and of timing runs (environment: SCP_RC_WIDE). */
+SCP_API int scp_rc_set_wide(int32_t mode);
 
 /* ---- launch brackets: HIP events recorded INSIDE the C ABI, directly around a kernel launch, on the stream it is launched on ----
  * While enabled, every bracketed entry point records one hipEvent immediately before and one immediately after its main kernel

@@ -1105,6 +1105,294 @@ __global__ __launch_bounds__(256, 1) void rc_post_attn_kernel(const RcPostArgs a
 }
 
 // =================================================================================================================================
+// rc_post_attn_wide_kernel: the SAME block as rc_post_attn_kernel for SHORT launches (round 5; the decoder's one-window forwards: a few dozen
+// 128-row tiles on 256 CUs, every launch as long as one wave's serial chain of 3 552 products - 93 us whatever M is).  Here a workgroup owns
+// 32 rows and its four waves split the OUTPUT CHANNELS of every product instead of the rows:
+//   proj   : wave w computes x1 blocks 2 w, 2 w + 1 (64 of the 256 channels) for all 32 rows              96 products
+//   (x1 blocks meet in LDS; every wave then holds the whole rows, runs LayerNorm on them and keeps the normalised rows as B fragments)
+//   fc1    : wave w computes hidden chunks w, w + 4, .., w + 28 (two chains at a time), GELU, hi / lo split -> H(c) into LDS     384 products
+//   fc2    : wave w accumulates output blocks 2 w, 2 w + 1 over all 32 hidden chunks in order                                     384 products
+// 864 products per wave instead of 3 552.  Every output element is still ONE wave's accumulation chain with the same operands in the same
+// order as in rc_post_attn_kernel (same start values, same three partial products per k-step, same GELU routine, same LayerNorm reduction
+// order), so a row's result has the same bits whichever kernel computed it - the decoder (short launches) and the encoder (one packed
+// launch) keep agreeing on every integer CDF (tests/test_gpu_model.py::test_wide_post_attn_kernel_has_the_chain_kernels_bits).
+// The weights do not go through LDS (every wave needs different ones; 128 KiB of the LDS hold H): a lane reads its 16-byte fragment of the
+// tiled planes straight from L2, a few slices ahead.
+// fragments in flight: k-steps (proj, fc1: 16 registers each) / hidden chunks (fc2: 32 registers each).  Measured 4 / 2, 8 / 4, 12 / 4, 8 / 8, 16 / 4:
+// 46.5 / 46.9 / 49.3 / 49.4 / 51.6 us per 512-row launch - the kernel is not waiting for these loads; a lone wave per SIMD pays for ISSUING them
+// (a vector load to registers holds the wave's issue for ~200 cycles, tools/src/mb_vmem_issue.cpp): 47 - 57 us against the chain kernel's 79 - 88
+#ifndef RCW_D1
+#define RCW_D1 4
+#endif
+#ifndef RCW_D2
+#define RCW_D2 2
+#endif
+#define RCW_H_BYTES (32 * 4096)                     // H(c): [32 chunks][64 lanes][4 x 16 B: hi t = 0, 1, lo t = 0, 1]
+__global__ __launch_bounds__(256, 1) void rc_post_attn_wide_kernel(const RcPostArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const RcLane L = rc_lane();
+    float *sbp = (float *)(smem + RC_OFF_BIAS), *sb2 = sbp + 256, *sb1 = sbp + 512;      // bp[256], b2[256], b1'[1024]
+    for (int i = threadIdx.x; i < 256; i += 256) { sbp[i] = a.bp[i]; sb2[i] = a.b2[i]; }
+    for (int i = threadIdx.x; i < 1024; i += 256) sb1[i] = a.b1[i];
+    __syncthreads();
+    // item = a 32-row tile: sub-tile (item & 3) of 128-row tile tile_list[item >> 2] (all tiles without a list)
+    const int n128 = a.tile_list ? a.n_list : (a.M + RC_ROWS - 1) / RC_ROWS;
+    char *bounce = smem + RC_OFF_BOUNCE + L.w * RC_BOUNCE;
+    char *hbuf = smem;                                                                    // H(c); the x1 blocks meet here first
+    const int ldc_bytes = (int)(a.ldc * 4);
+    const int voff = (L.lane >> 3) * ldc_bytes + (L.lane & 7) * 16;
+    // Weight fragments come by buffer loads: ONE resource for the whole weight buffer, the lane's offset inside a slot image in a VGPR (two of
+    // them: k-step parity), everything else - slot, k-slab, plane - in the scalar offset.  (With plain pointers the compiler precomputes a 64-bit
+    // address per fragment and spills them: 230 scratch accesses per step.)
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.W, 0, 2 * RC_W_PLANE, 0x00020000);
+    const int vrc0 = L.rg * 8192 + L.frag, vrc1 = L.rg * 8192 + (L.frag ^ 32);          // row-chunk slot image: + (s >> 1) * 1024, k-step parity s & 1
+    const int vkc0 = L.rg * 32768 + L.frag, vkc1 = L.rg * 32768 + (L.frag ^ 32);        // fc2 k-slab pieces: row group rg of a block, t = 0 / 1
+    auto wload = [&](int voff, int soff) { return __builtin_bit_cast(rbf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, voff, soff, 0)); };
+    for (int item = blockIdx.x; item < 4 * n128; item += gridDim.x) {
+        const int t128 = a.tile_list ? a.tile_list[item >> 2] : (item >> 2);
+        const int m0 = t128 * RC_ROWS + 32 * (item & 3);
+        if (m0 >= a.M) continue;                                                           // (uniform over the workgroup)
+        // ---- the tile's attention rows as B fragments (every wave all 32 rows): coalesced fetch + transposition as in the chain kernel ----
+        rbf16x8 Bh[16], Bl[16];
+        {
+            const int r0 = m0 + (L.lane >> 3);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = r0 + 8 * it;
+                const int64_t o = (int64_t)(r < a.M ? r : a.M - 1) * a.ldo_in + (L.lane & 7) * 8;
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) { Bh[4 * pp + it] = *(const rbf16x8 *)(a.Ohi + o + 64 * pp); Bl[4 * pp + it] = *(const rbf16x8 *)(a.Olo + o + 64 * pp); }
+            }
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int rho = 8 * it + (L.lane >> 3), kap = L.lane & 7;
+                        *(rbf16x8 *)(bounce + rho * 128 + ((kap ^ (rho & 7)) << 4)) = plane ? Bl[4 * pp + it] : Bh[4 * pp + it];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const rbf16x8 fr = *(const rbf16x8 *)(bounce + L.col * 128 + (((2 * q + L.h) ^ (L.col & 7)) << 4));
+                        if (plane) Bl[4 * pp + q] = fr; else Bh[4 * pp + q] = fr;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+        }
+        // ---- proj: blocks 2 w (chain c0) and 2 w + 1 (chain c1); weight rows [64 w, 64 w + 64) = row-chunk slots 2 w, 2 w + 1 ----------------
+        rf32x16 c0, c1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+        {
+            const int w0 = RC_W_PROJ + (2 * L.w) * 16384, w1 = w0 + 16384;
+            constexpr int D = RCW_D1;                                                     // slices of fragments in flight
+            rbf16x8 F[D][4];                                                              // [.][0] hi slot 0, [1] lo slot 0, [2] hi slot 1, [3] lo slot 1
+            auto fetch = [&](int s, rbf16x8 (&d)[4]) {
+                const int v = (s & 1) ? vrc1 : vrc0, o = (s >> 1) * 1024;
+                d[0] = wload(v, w0 + o); d[1] = wload(v, w0 + RC_W_PLANE + o);
+                d[2] = wload(v, w1 + o); d[3] = wload(v, w1 + RC_W_PLANE + o);
+            };
+#pragma unroll
+            for (int s = 0; s < D; ++s) fetch(s, F[s]);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                rbf16x8 (&A)[4] = F[s % D];
+                RC_MFMA_AVA(c0, A[1], Bh[s]); RC_MFMA_AVA(c1, A[3], Bh[s]);
+                RC_MFMA_AVA(c0, A[0], Bl[s]); RC_MFMA_AVA(c1, A[2], Bl[s]);
+                RC_MFMA_AVA(c0, A[0], Bh[s]); RC_MFMA_AVA(c1, A[2], Bh[s]);
+                if (s + D < 16) fetch(s + D, F[s % D]);
+                RC_SB;
+            }
+        }
+        // x1 = x + bp + proj: the lane's own row, channels 64 w + 32 b + 8 q + 4 h + u
+        {
+            const int r = m0 + L.col;
+            const float *xr = a.x + (int64_t)(r < a.M ? r : a.M - 1) * a.ldx + 64 * L.w + 4 * L.h;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const rf32x4 xq = *(const rf32x4 *)(xr + 32 * b + 8 * q);
+                    const rf32x4 bq = *(const rf32x4 *)(sbp + 64 * L.w + 32 * b + 8 * q + 4 * L.h);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (b == 0) c0[4 * q + u] += xq[u] + bq[u];
+                        else c1[4 * q + u] += xq[u] + bq[u];
+                    }
+                }
+        }
+        // ---- the eight x1 blocks meet in LDS ([block][lane][16 floats]); every wave takes all of them ------------------------------------------
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *(rf32x4 *)(hbuf + ((2 * L.w) * 64 + L.lane) * 64 + 16 * q) = (rf32x4){c0[4 * q], c0[4 * q + 1], c0[4 * q + 2], c0[4 * q + 3]};
+            *(rf32x4 *)(hbuf + ((2 * L.w + 1) * 64 + L.lane) * 64 + 16 * q) = (rf32x4){c1[4 * q], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
+        }
+        __syncthreads();
+        // ---- LayerNorm statistics and the normalised rows: the chain kernel's arithmetic, operation for operation.  The blocks are re-read from
+        // LDS in every pass (a wave has 256 registers the vector unit can read; eight blocks + the fragments would be all of them) --------------
+        auto yblock = [&](int b, rf32x16 &y) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const rf32x4 t = *(const rf32x4 *)(hbuf + (b * 64 + L.lane) * 64 + 16 * q);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) y[4 * q + u] = t[u];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        float sum = 0.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            rf32x16 y;
+            yblock(b, y);
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) sum += (y[r] + y[r + 1]) + (y[r + 2] + y[r + 3]);
+        }
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / 256.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            rf32x16 y;
+            yblock(b, y);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = y[r] - mean; sq += d * d; }
+        }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq * (1.0f / 256.0f) + a.eps);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            rf32x16 y;
+            yblock(b, y);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float fr[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fr[i] = (y[8 * t + i] - mean) * rstd;
+                rc_split8(fr, Bh[2 * b + t], Bl[2 * b + t]);
+            }
+        }
+        // this wave's two output blocks start from x1 + b2
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            rf32x16 y;
+            yblock(2 * L.w + b, y);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const rf32x4 bb = *(const rf32x4 *)(sb2 + 32 * (2 * L.w + b) + 8 * q + 4 * L.h);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (b == 0) c0[4 * q + u] = y[4 * q + u] + bb[u];
+                    else c1[4 * q + u] = y[4 * q + u] + bb[u];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                                                   // the exchange area becomes H
+        // ---- fc1 + GELU: hidden chunks w + 8 i (chain a1a) and w + 8 i + 4 (chain a1b), i = 0 .. 3 -------------------------------------------------
+        for (int i = 0; i < 4; ++i) {
+            const int ca = L.w + 8 * i, cb = ca + 4;
+            rf32x16 a1a, a1b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const rf32x4 ba = *(const rf32x4 *)(sb1 + 32 * ca + 8 * q + 4 * L.h), bb = *(const rf32x4 *)(sb1 + 32 * cb + 8 * q + 4 * L.h);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a1a[4 * q + u] = ba[u]; a1b[4 * q + u] = bb[u]; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int w0 = RC_W_FC1 + ca * 16384, w1 = RC_W_FC1 + cb * 16384;
+            constexpr int D = RCW_D1;
+            rbf16x8 F[D][4];
+            auto fetch = [&](int s, rbf16x8 (&d)[4]) {
+                const int v = (s & 1) ? vrc1 : vrc0, o = (s >> 1) * 1024;
+                d[0] = wload(v, w0 + o); d[1] = wload(v, w0 + RC_W_PLANE + o);
+                d[2] = wload(v, w1 + o); d[3] = wload(v, w1 + RC_W_PLANE + o);
+            };
+#pragma unroll
+            for (int s = 0; s < D; ++s) fetch(s, F[s]);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                rbf16x8 (&A)[4] = F[s % D];
+                RC_MFMA_AVA(a1a, A[1], Bh[s]); RC_MFMA_AVA(a1b, A[3], Bh[s]);
+                RC_MFMA_AVA(a1a, A[0], Bl[s]); RC_MFMA_AVA(a1b, A[2], Bl[s]);
+                RC_MFMA_AVA(a1a, A[0], Bh[s]); RC_MFMA_AVA(a1b, A[2], Bh[s]);
+                if (s + D < 16) fetch(s + D, F[s % D]);
+                RC_SB;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const rf32x16 &acc = half ? a1b : a1a;
+                ru32x4 Hh[2], Hl[2];
+                RcGelu g;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int st = 0; st < 12; ++st) {
+                        unsigned wh = 0, wl = 0;
+                        rc_gelu_stage(st, g, acc[2 * k], acc[2 * k + 1], wh, wl);
+                        if (st == 10) Hh[k >> 2][k & 3] = wh;
+                        if (st == 11) Hl[k >> 2][k & 3] = wl;
+                    }
+                char *hp = hbuf + ((half ? cb : ca) * 64 + L.lane) * 64;
+                *(ru32x4 *)(hp) = Hh[0]; *(ru32x4 *)(hp + 16) = Hh[1]; *(ru32x4 *)(hp + 32) = Hl[0]; *(ru32x4 *)(hp + 48) = Hl[1];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- fc2: blocks 2 w (c0), 2 w + 1 (c1) over the hidden chunks in order; W2 k-slab c, row groups 2 blk + rg --------------------------------
+        {
+            const int wf = RC_W_FC2 + (2 * (2 * L.w)) * 32768;                           // block 2 w (row groups 4 w, 4 w + 1); block 2 w + 1: + 65536
+            constexpr int D = RCW_D2;                                                     // chunks of fragments in flight
+            rbf16x8 F[D][8];                                                              // [t][plane][blk]: index 4 t + 2 plane + blk
+            auto fetch = [&](int c, rbf16x8 (&d)[8]) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+                        for (int blk = 0; blk < 2; ++blk)
+                            d[4 * t + 2 * plane + blk] = wload(t ? vkc1 : vkc0, wf + c * 1024 + plane * RC_W_PLANE + blk * 65536);
+            };
+#pragma unroll
+            for (int c = 0; c < D; ++c) fetch(c, F[c]);
+            auto chunk = [&](int c, rbf16x8 (&A)[8]) {
+                const char *hp = hbuf + (c * 64 + L.lane) * 64;
+                const ru32x4 Hh0 = *(const ru32x4 *)(hp), Hh1 = *(const ru32x4 *)(hp + 16), Hl0 = *(const ru32x4 *)(hp + 32), Hl1 = *(const ru32x4 *)(hp + 48);
+                // t = 0, then t = 1; per t: lo . hi, hi . lo, hi . hi (A index 4 t + 2 plane + blk)
+                RC_MFMA_AVV(c0, A[2], Hh0); RC_MFMA_AVV(c1, A[3], Hh0);
+                RC_MFMA_AVV(c0, A[0], Hl0); RC_MFMA_AVV(c1, A[1], Hl0);
+                RC_MFMA_AVV(c0, A[0], Hh0); RC_MFMA_AVV(c1, A[1], Hh0);
+                RC_MFMA_AVV(c0, A[6], Hh1); RC_MFMA_AVV(c1, A[7], Hh1);
+                RC_MFMA_AVV(c0, A[4], Hl1); RC_MFMA_AVV(c1, A[5], Hl1);
+                RC_MFMA_AVV(c0, A[4], Hh1); RC_MFMA_AVV(c1, A[5], Hh1);
+                if (c + D < 32) fetch(c + D, A);
+                RC_SB;
+            };
+            for (int c = 0; c < 32; c += D) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) chunk(c + k, F[k]);
+            }
+        }
+        // ---- x2 -> fp32 rows (the wave's 64 channels of the tile's 32 rows) ----------------------------------------------------------------------------
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t rows_left = (int64_t)a.M - m0;
+        const int64_t span = (rows_left < 32 ? rows_left : 32) * a.ldc * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out + (int64_t)m0 * a.ldc, 0, (int)span, 0x00020000);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            rf32x4 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[q][u] = b ? c1[4 * q + u] : c0[4 * q + u];
+            rc_store_block(L, bounce, o, rs, ldc_bytes, voff, 64 * L.w + 32 * b);
+        }
+        __syncthreads();                                                                   // H is free for the next item
+    }
+}
+
+// =================================================================================================================================
 // scp_swin_merge: SwinPatchMerging (swin_transformer.py:350-384) in one launch - gather the (even, odd) token of every pair, LayerNorm
 // over the 512 concatenated channels, 512 -> 256 reduction (no bias) - for M merged rows.  Replaces layernorm_rows(gather) + gemm_split.
 // A wave holds its 32 merged rows; the K = 512 product runs as two K = 256 halves over the SAME eight accumulator blocks Y: half 0
@@ -1386,6 +1674,13 @@ static unsigned long long *g_rc_dbg = nullptr;   // diagnostic only (tools/mb_ro
 extern "C" SCP_API int scp_rc_debug_buffer(unsigned long long *dev_buf) { g_rc_dbg = dev_buf; return SCP_OK; }
 
 static int g_rc_num_cu = 0, g_rc_grid = 0;
+// scp_debug.h: which kernel scp_swin_post_attn launches: -1 (default) by size, 0 the chain kernel always, 1 the wide kernel always (tests; SCP_RC_WIDE)
+static int g_rc_wide = -2;
+static int rc_wide_mode() {
+    if (g_rc_wide == -2) { const char *e = getenv("SCP_RC_WIDE"); g_rc_wide = e ? atoi(e) : -1; if (g_rc_wide < -1 || g_rc_wide > 1) g_rc_wide = -1; }
+    return g_rc_wide;
+}
+extern "C" SCP_API int scp_rc_set_wide(int32_t mode) { g_rc_wide = (mode < -1 || mode > 1) ? -1 : mode; return SCP_OK; }
 // measurement hook (scp_debug.h): number of persistent workgroups of the row-chain launches; 0 = one per CU of the device.  For streams
 // created with a CU mask (tools/mb_cumask.py) - a persistent grid larger than the stream's CU set would run in two rounds.
 extern "C" SCP_API int scp_rc_set_grid(int32_t workgroups) { g_rc_grid = workgroups > 0 ? workgroups : 0; return SCP_OK; }
@@ -1471,6 +1766,7 @@ extern "C" SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int6
     static bool configured = false;
     if (!configured) {
         HIP_TRY(hipFuncSetAttribute((const void *)rc_post_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)rc_post_attn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
         configured = true;
     }
     RcPostArgs a;
@@ -1483,6 +1779,15 @@ extern "C" SCP_API int scp_swin_post_attn(const void *Ohi, const void *Olo, int6
     const int ncu = rc_num_cu();
     // algorithmic work: the rows of the tiles processed (a tile list leaves out tiles of nothing but window padding)
     SCP_PROF(SCP_PROF_POST_ATTN, stream, 2.0 * (tile_list ? (double)n_tiles * RC_ROWS : (double)M) * (256.0 * 256.0 + 2.0 * 256.0 * 1024.0));
+    // short launches: the wide kernel (a workgroup per 32 rows, the waves split the output channels; same bits) while its 32-row tiles fit the
+    // chip (measured: 47 - 57 against 79 - 88 us up to 8 192 rows, 110 against 98 us at 16 384) - beyond that the chain kernel's 128-row tiles
+    // fill the CUs and stream every weight byte once per 128 rows instead of 32
+    if (rc_wide_mode() == 1 || (rc_wide_mode() < 0 && !g_rc_dbg && !a.dbg_mode && 4 * (int64_t)ntiles <= (int64_t)ncu)) {
+        const int items = 4 * ntiles;
+        hipLaunchKernelGGL(rc_post_attn_wide_kernel, dim3((unsigned)(items < 2 * ncu ? items : 2 * ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
+        LAUNCH_CHECK();
+        return SCP_OK;
+    }
     hipLaunchKernelGGL(rc_post_attn_kernel, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;

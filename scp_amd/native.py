@@ -93,6 +93,7 @@ def lib():
         "scp_ctx_get": (C.c_int, [_vp, i32]),
         "scp_ctx_make_current": (C.c_int, [_vp]),
         "scp_rc_debug_buffer": (C.c_int, [_vp]),
+        "scp_rc_set_wide": (C.c_int, [i32]),
         "scp_prof_enable": (C.c_int, [i32]),
         "scp_prof_count": (C.c_int, []),
         "scp_prof_read": (C.c_int, [i32, _vp, _vp, _vp]),

@@ -1345,6 +1345,56 @@ def test_swin_post_attn_vs_float64_and_the_launches_it_replaces(dev, M):
 
 
 @pytest.mark.gpu
+def test_wide_post_attn_kernel_has_the_chain_kernels_bits(dev):
+    """Round 5 (decoder latency): short launches of scp_swin_post_attn run rc_post_attn_wide_kernel - a workgroup per 32 rows, its four waves
+    splitting the output channels of every product instead of the rows (864 products per wave instead of 3 552: a quarter of the launch time
+    when the launch has fewer tiles than CUs).  Every output element is one wave's accumulation chain with the chain kernel's operands in the
+    chain kernel's order: the two kernels agree bit for bit - any M, ragged last tile, tile lists, in place - and so do the encoder (one packed
+    launch through the chain kernel) and the decoder (short launches)."""
+    from scp_amd import native
+    L = native.lib()
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *sh, s=1.0: (torch.randn(sh, generator=g) * s).to(dev)
+    wp, bp = rn(256, 256, s=0.05), rn(256, s=0.1)
+    gamma, beta = 1 + rn(256, s=0.1), rn(256, s=0.1)
+    w1, b1, w2, b2 = rn(1024, 256, s=0.05), rn(1024, s=0.1), rn(256, 1024, s=0.03), rn(256, s=0.1)
+    pw = native.PostAttnWeights(wp, bp, gamma, beta, w1, b1, w2, b2)
+    try:
+        for M in (1, 31, 32, 33, 128, 129, 1000, 4096, 8192, 20001):
+            x, o = rn(M, 256, s=2.0), rn(M, 256)
+            osp = native.split_rows(o)
+            L.scp_rc_set_wide(0)
+            want = native.swin_post_attn(osp, x, pw)
+            L.scp_rc_set_wide(1)
+            got = native.swin_post_attn(osp, x, pw)
+            assert torch.equal(got, want), M
+            xc = x.clone()
+            assert native.swin_post_attn(osp, xc, pw, out=xc) is xc and torch.equal(xc, want), M           # in place
+            if M >= 1000:                                                                                    # a tile list: the other tiles keep their rows
+                nt = (M + 127) // 128
+                tiles = torch.arange(nt, dtype=torch.int32, device=dev)[::3].contiguous()
+                L.scp_rc_set_wide(0)
+                a = native.swin_post_attn(osp, x.clone(), pw, out=None, tiles=None)
+                xa, xb = x.clone(), x.clone()
+                native.swin_post_attn(osp, xa, pw, out=xa, tiles=tiles)
+                L.scp_rc_set_wide(1)
+                native.swin_post_attn(osp, xb, pw, out=xb, tiles=tiles)
+                assert torch.equal(xa, xb), M
+                keep = torch.ones(nt, dtype=torch.bool)
+                keep[::3] = False
+                rows = torch.repeat_interleave(keep, 128)[:M].to(dev)
+                assert torch.equal(xb[rows], x[rows]) and torch.equal(xb[~rows], a[~rows]), M
+        # the automatic choice (by launch size) gives the same rows either way
+        L.scp_rc_set_wide(-1)
+        x, o = rn(70001, 256), rn(70001, 256)
+        big = native.swin_post_attn(native.split_rows(o), x, pw)                                            # 548 tiles: the chain kernel
+        for M in (512, 4096, 8192, 16384):
+            assert torch.equal(native.swin_post_attn(native.split_rows(o[:M].contiguous()), x[:M].contiguous(), pw), big[:M]), M
+    finally:
+        L.scp_rc_set_wide(-1)
+
+
+@pytest.mark.gpu
 def test_rowchain_weights_follow_parameter_updates(dev, ehem):
     """The folded / permuted weights of the row-chain kernels are caches keyed on their sources: an in-place parameter update after a
     forward takes effect (the same contract as every other derived weight)."""
