@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=4, help="frames in flight (encode_async handles not yet finished); 4 measured 1.2 % above 3, 5 no better")
     ap.add_argument("--batch", type=int, default=None, help="frames per stage-G / packed-forward / CDF launch (FrameEncoder.encode_batch_async); "
-                    "default: 4 for the level-12 EHEM configuration (a 115 k-node frame is 22 windows), 1 elsewhere")
+                    "default: 8 for the level-12 EHEM configuration (a 115 k-node frame is 22 windows), 1 elsewhere")
     ap.add_argument("--host-transform", action="store_true", help="(default for the EHEM configurations since round 5) strict-identity mode as the "
                     "HEADLINE: the reference's numpy float32 transform + quantiser on a prefetch thread one to two frames ahead")
     ap.add_argument("--device-transform", action="store_true", help="headline with the device transform (rounds 1 - 4); the strict leg becomes the extra key")
@@ -99,7 +99,7 @@ def run_all_configs(args, argv):
             del rest[i:i + 2]
     rc = 0
     for name in ("ehem-L16-m", "ehem-L12-s", "ehem-F17-m", "octattn-L12-spher", "octattn-L14-cylin"):
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name] + rest, stdout=subprocess.PIPE, text=True)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name, "--no-legs"] + rest, stdout=subprocess.PIPE, text=True)
         rc = rc or r.returncode
         line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
         if line is None:
@@ -571,7 +571,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    batch = args.batch if args.batch is not None else (4 if args.config == "ehem-L12-s" else 1)
+    batch = args.batch if args.batch is not None else (8 if args.config == "ehem-L12-s" else 1)     # (4 / 8 / 16 frames per launch sequence: 69.8 / 71.3 / 68.8 frames/s strict, round 5)
     if batch > 1 and not ehem:
         raise SystemExit("--batch is an EHEM option")
 
