@@ -47,7 +47,8 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md: aggregate L2 bandwidth
-PMC_PROFILES = ("r4_pmc_traffic.json", "r4_pmc_traffic_octattn_L14_cylin.json")   # profiles/: HBM bytes per launch / per frame from separate rocprofv3 --pmc passes (tools/r4_profiles.sh), one file per configuration
+PMC_PROFILES = ("r5_ehem_L16m_frame_pmc_traffic.json", "r5_octattn_L14_frame_pmc_traffic.json",     # profiles/: HBM bytes per launch / per frame from separate rocprofv3 --pmc passes
+                "r4_pmc_traffic.json", "r4_pmc_traffic_octattn_L14_cylin.json")                       # (tools/r5_profiles.sh), one file per configuration; the newest that exists is used
 
 
 def parse():
@@ -501,6 +502,11 @@ def side_legs(args, out):
     z = _child_line(["--decode", "--steps", "3", "--warmup", "1"])
     out["decode"] = z if "error" in z else dict(fps=z["value"], ms_per_step=z["ms_per_step"], steps=z["steps"], decoded_occupancy_equals_encoded=z["decoded_occupancy_equals_encoded"],
                                                stage_ms=z.get("stage_ms"), host_cpu_ms_per_frame=z.get("host_cpu_ms_per_frame"), workload=z["config"]["workload"])
+    z4 = _child_line(["--decode", "--decode-streams", "4", "--steps", "2", "--warmup", "1"])
+    out["decode_4_streams"] = z4 if "error" in z4 else dict(fps=z4["value"], frames_decoded_concurrently=z4["config"]["frames_decoded_concurrently"],
+                                                            decoded_occupancy_equals_encoded=z4["decoded_occupancy_equals_encoded"], host_cpu_ms_per_frame=z4.get("host_cpu_ms_per_frame"),
+                                                            note="four independent frames decoded side by side (one FrameDecoder, host thread and HIP stream each) in ONE process: the GPU has "
+                                                                 "room (a decode is a chain of short launches on a fraction of the CUs), the four launch threads share the interpreter lock")
     out["cli"] = cli_leg(args.leg_warmup, args.leg_steps)
     if "fps" in out["cli"]:
         out["cli_over_bench"] = out["cli"]["fps"] / out["value"]

@@ -80,7 +80,7 @@ def test_bench_device_transform_headline_and_strict_leg():
 def test_bench_side_legs_fill_configs_decode_and_cli():
     """The default run of the headline configuration adds the other four BASELINE.json workloads, the decoder and the drop-in CLI as child
     processes behind the headline: five `configs` entries, `decode`, `cli`, `cli_over_bench`."""
-    out = _run(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-strict-leg", "--leg-steps", "3", "--leg-warmup", "2"], timeout=2400)
+    out = _run(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-strict-leg", "--leg-steps", "2", "--leg-warmup", "1"], timeout=2400)
     assert out["strict_identity_verified"] is True and out["transform_parity"]["host_transform"] == [0, 0, 0]
     assert set(out["configs"]) == {"ehem-L16-m", "ehem-L12-s", "ehem-F17-m", "octattn-L12-spher", "octattn-L14-cylin"}, out.get("legs_error")
     for name, c in out["configs"].items():
@@ -91,7 +91,9 @@ def test_bench_side_legs_fill_configs_decode_and_cli():
     d = out["decode"]
     assert d["decoded_occupancy_equals_encoded"] is True and d["fps"] > 0
     c = out["cli"]
-    assert c["streams_written"] == c["files"] == 9 and c["files_timed"] == 3 and c["fps"] > 0 and abs(out["cli_over_bench"] - c["fps"] / out["value"]) < 1e-9
+    assert c["streams_written"] == c["files"] == 7 and c["files_timed"] == 2 and c["fps"] > 0 and abs(out["cli_over_bench"] - c["fps"] / out["value"]) < 1e-9
+    d4 = out["decode_4_streams"]
+    assert d4["decoded_occupancy_equals_encoded"] is True and d4["frames_decoded_concurrently"] == 4 and d4["fps"] > 0
 
 
 def test_bench_decode_mode_times_the_decoder_and_checks_the_round_trip():
