@@ -594,7 +594,9 @@ struct KnnWg { int32_t row0, n, q0, pad; };
 // tab: [nslots][8] entries for (slot, blockIdx % 8), then `nspill` overflow entries that take whatever an XCD's run holds beyond
 // nslots blocks (runs are cut by WORK, so a launch with many short windows can put more blocks into one run than any useful
 // nslots; the spill region has room for every block of the launch, so nothing is ever dropped).  Entries left zero are empty.
-__global__ __launch_bounds__(1024) void knn_sched_kernel(const int *__restrict__ ctab, int nchunks, KnnWg *__restrict__ tab, int nslots, int nspill) {
+// nsplit > 1 (short launches, round 5): every 256-query block becomes nsplit entries that sweep one nsplit-th of the candidate tiles each
+// (KnnWg.pad = which); their partial lists are merged by knn_merge_split_kernel.
+__global__ __launch_bounds__(1024) void knn_sched_kernel(const int *__restrict__ ctab, int nchunks, KnnWg *__restrict__ tab, int nslots, int nspill, int nsplit) {
     // sequences = chunks that start one (base == own first row); work of a 256-query block ~ n (its sweep length)
     __shared__ int seq_base[2048], seq_n[2048], seq_blk0[2049];
     __shared__ unsigned long long seq_w0[2049];
@@ -625,15 +627,15 @@ __global__ __launch_bounds__(1024) void knn_sched_kernel(const int *__restrict__
         unsigned long long wsum = 0;
         for (int q = 0; q < nseq; ++q) {
             seq_blk0[q] = b; seq_w0[q] = wsum;
-            const int nb = (seq_n[q] + 255) >> 8;
-            b += nb; wsum += (unsigned long long)nb * (unsigned)seq_n[q];
+            const int nb = ((seq_n[q] + 255) >> 8) * nsplit;
+            b += nb; wsum += (unsigned long long)nb * (unsigned)(seq_n[q] / nsplit + 1);
         }
         seq_blk0[nseq] = b; seq_w0[nseq] = wsum; wtot_s = wsum ? wsum : 1ull;
     }
     __syncthreads();
     const int nblk = seq_blk0[nseq];
     const unsigned long long wtot = wtot_s;
-    auto xcd_of = [&](int q, int j) { const unsigned long long cw = seq_w0[q] + (unsigned long long)j * (unsigned)seq_n[q]; const int x = (int)(cw * 8ull / wtot); return x > 7 ? 7 : x; };
+    auto xcd_of = [&](int q, int j) { const unsigned long long cw = seq_w0[q] + (unsigned long long)j * (unsigned)(seq_n[q] / nsplit + 1); const int x = (int)(cw * 8ull / wtot); return x > 7 ? 7 : x; };
     for (int q = tid; q < nseq; q += 1024) {
         const int nb = seq_blk0[q + 1] - seq_blk0[q];
         for (int j = 0; j < nb; ++j) atomicMin(&first_blk[xcd_of(q, j)], seq_blk0[q] + j);
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(1024) void knn_sched_kernel(const int *__restrict__
         const int nb = seq_blk0[q + 1] - seq_blk0[q];
         for (int j = 0; j < nb; ++j) {
             const int x = xcd_of(q, j), slot = seq_blk0[q] + j - first_blk[x];
-            KnnWg e; e.row0 = seq_base[q]; e.n = seq_n[q]; e.q0 = j * 256; e.pad = 0;
+            KnnWg e; e.row0 = seq_base[q]; e.n = seq_n[q]; e.q0 = (j / nsplit) * 256; e.pad = j % nsplit;
             if (slot < nslots) tab[slot * 8 + x] = e;
             else { const int k = atomicAdd(&spill_s, 1); if (k < nspill) tab[nslots * 8 + k] = e; }
         }
@@ -674,7 +676,9 @@ template <int K, int G, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void knn_f16x3_wg256_kernel(const _Float16 *__restrict__ planes, const float *__restrict__ xx,
                                                                 const float *__restrict__ inv_scale, const KnnWg *__restrict__ tab,
                                                                 int *__restrict__ idx, const float *__restrict__ thr0, int order,
-                                                                unsigned long long *__restrict__ dbg = nullptr) {
+                                                                unsigned long long *__restrict__ dbg = nullptr, int nsplit = 1,
+                                                                float *__restrict__ pval = nullptr, int *__restrict__ pidx = nullptr,
+                                                                int64_t prows = 0) {
     constexpr int RB = 4 * K;                       // bytes per row
     constexpr int R = RB / 16;                      // chunks per row (48 / 36)
     constexpr int NC = K / 16;                      // k-chunks of 16 features
@@ -700,7 +704,10 @@ __global__ __launch_bounds__(512, 2) void knn_f16x3_wg256_kernel(const _Float16 
     const char *pb = (const char *)planes + row0 * RB;
     const float *xxb = xx + row0, *isb = inv_scale + row0;
     const int qi = q0 + w * 32 + col;
-    const int nt = (n + 31) >> 5;
+    const int nt_all = (n + 31) >> 5;
+    // candidate tiles of this workgroup: all of them, or split wg.pad of nsplit (short launches: the sweep is what a launch lasts)
+    const int t_lo = nsplit > 1 ? (int)((int64_t)nt_all * wg.pad / nsplit) : 0;
+    const int nt = nsplit > 1 ? (int)((int64_t)nt_all * (wg.pad + 1) / nsplit) - t_lo : nt_all;
 
     f16x8 qa[NC], qb[NC];
     const int qc = qi < n ? qi : n - 1;
@@ -750,14 +757,15 @@ __global__ __launch_bounds__(512, 2) void knn_f16x3_wg256_kernel(const _Float16 
     // the same tile at about the same time; order 1: own tiles, then alternately outwards (the 128-query kernel's order)
     const int own0 = q0 >> 5;
     int own1 = own0 + 8;
-    own1 = own1 < nt ? own1 : nt;
+    own1 = own1 < nt_all ? own1 : nt_all;
     const int nown = own1 - own0;
     auto tile_of = [&](int s) {
+        if (nsplit > 1) return t_lo + s;                               // a split sweeps its run front to back
         if (s < nown) return own0 + s;
         const int r = s - nown;
         if (order == 0) return r < own0 ? r : r + nown;
         // outwards: alternately above own1 and below own0 while both sides last
-        const int below = own0, above = nt - own1, m = below < above ? below : above;
+        const int below = own0, above = nt_all - own1, m = below < above ? below : above;
         if (r < 2 * m) return (r & 1) ? own0 - 1 - (r >> 1) : own1 + (r >> 1);
         const int rr = r - 2 * m;
         return below > above ? own0 - 1 - m - rr : own1 + m + rr;
@@ -826,6 +834,23 @@ __global__ __launch_bounds__(512, 2) void knn_f16x3_wg256_kernel(const _Float16 
 #pragma unroll
         for (int t = 0; t < TK; ++t) { mval[(ql * 2 + h) * TK + t] = knn_key_val(key[t]); midx[(ql * 2 + h) * TK + t] = knn_key_idx(key[t]); }
         __syncthreads();
+        if (nsplit > 1) {                                // the query's 20 best of THIS split (value, local index; empty slots: -inf, INT_MAX), in list order
+            if (tid < 256 && q0 + tid < n) {
+                int h0 = 0, h1 = 0;
+                const size_t o0 = ((size_t)wg.pad * (size_t)prows + row0 + q0 + tid) * TK;
+                const float *va = mval + (tid * 2) * TK, *vb = va + TK;
+                const int *ia = midx + (tid * 2) * TK, *ib = ia + TK;
+                for (int o = 0; o < TK; ++o) {
+                    const float a = h0 < TK ? va[h0] : -INFINITY, b = h1 < TK ? vb[h1] : -INFINITY;
+                    const int ja = h0 < TK ? ia[h0] : INT_MAX, jb = h1 < TK ? ib[h1] : INT_MAX;
+                    const bool takea = (a > b) || (a == b && ja < jb);
+                    pval[o0 + o] = takea ? a : b;
+                    pidx[o0 + o] = takea ? ja : jb;
+                    if (takea) ++h0; else ++h1;
+                }
+            }
+            return;
+        }
         if (tid < 256 && q0 + tid < n) {
             int h0 = 0, h1 = 0;
             const int kk = n < TK ? n : TK;
@@ -845,6 +870,37 @@ __global__ __launch_bounds__(512, 2) void knn_f16x3_wg256_kernel(const _Float16 
                 } else out[o] = first;
             }
         }
+    }
+}
+
+// Merge of the partial lists of a split search: row r of sequence (base, n) takes the 20 best of its nsplit lists under the lists' own order
+// (value descending, index ascending) - a total order, so the result is the single-sweep list whatever the split.
+__global__ __launch_bounds__(256) void knn_merge_split_kernel(const int *__restrict__ ctab, const float *__restrict__ pval, const int *__restrict__ pidx,
+                                                             int64_t prows, int nsplit, int *__restrict__ idx) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= prows) return;
+    const int c = (int)(r >> 9), base = ctab[2 * c], n = ctab[2 * c + 1];
+    if (n <= 0 || r - base >= n) return;
+    int head[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) head[s] = 0;
+    const int kk = n < TK ? n : TK;
+    int first = 0;
+    int *out = idx + r * TK;
+    for (int o = 0; o < TK; ++o) {
+        if (o < kk) {
+            float bv = -INFINITY; int bj = INT_MAX, bs = 0;
+            for (int s = 0; s < nsplit; ++s) {
+                if (head[s] >= TK) continue;
+                const size_t p = ((size_t)s * (size_t)prows + r) * TK + head[s];
+                const float v = pval[p]; const int j = pidx[p];
+                if (v > bv || (v == bv && j < bj)) { bv = v; bj = j; bs = s; }
+            }
+            ++head[bs];
+            const int j = bj + base;
+            if (o == 0) first = j;
+            out[o] = j;
+        } else out[o] = first;
     }
 }
 
@@ -1030,6 +1086,11 @@ extern "C" SCP_API int scp_set_knn_mode(int32_t f16x3) { g_knn_mode = f16x3 ? 1 
 // workgroup shape of the packed f16x3 search: 256 = 256-query workgroups on the XCD schedule, a barrier per group of 3 / 4 tiles (default);
 // SCP_KNN_WG=257 / 258: groups of two tiles / one tile; +16: outward sweep order; 128: the 128-query kernel in launch order (all give
 // identical neighbour lists)
+static int knn_split_on() {   // SCP_KNN_SPLIT=0: A/B bracket of the split sweep of short launches (identical lists)
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("SCP_KNN_SPLIT"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on;
+}
 static int g_knn_wg = -1;
 static int knn_wg() { if (g_knn_wg < 0) { const char *e = getenv("SCP_KNN_WG"); g_knn_wg = e ? atoi(e) : 256; } return g_knn_wg; }
 extern "C" SCP_API int scp_set_knn_workgroup(int32_t v) { g_knn_wg = v; return SCP_OK; }
@@ -1042,7 +1103,16 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
     DevBuf *sp = knn_scratch(st);
     if (!sp) return SCP_EINVAL;
     DevBuf &sbuf = *sp;
-    int rc = sbuf.reserve(xx_bytes * (split ? 2 : 1) + (C <= 4 ? (size_t)npts * 16 + ((size_t)npts / 32 + grid.y + 1) * 32 : (split ? (size_t)npts * RB + 256 + ((size_t)(npts / 256) * 2 + 520) * sizeof(KnnWg) : 0)));
+    // short launches (round 5): when the launch has too few 256-query blocks for the chip, every block's candidate sweep is cut into nsplit runs
+    // (one workgroup each) and the partial lists are merged - the sweep is what a launch lasts (0.77 ms for one 8 192-point window on 32 CUs).
+    // nsplit from the padded row count (the host does not know the sequences): blocks x nsplit <= 256, at least ~4 tiles per run, <= 16.
+    int nsplit = 1;
+    if (split && ctab && knn_wg() == 256 && !g_knn_dbg && knn_split_on()) {
+        const int64_t nblk = npts / 256 > 0 ? npts / 256 : 1;
+        while (nsplit < 16 && nblk * (nsplit * 2) <= 256 && npts / 32 >= 8 * (int64_t)nsplit) nsplit *= 2;
+    }
+    const size_t part_bytes = nsplit > 1 ? (size_t)nsplit * (size_t)npts * TK * 8 + 256 : 0;
+    int rc = sbuf.reserve(xx_bytes * (split ? 2 : 1) + (C <= 4 ? (size_t)npts * 16 + ((size_t)npts / 32 + grid.y + 1) * 32 : (split ? (size_t)npts * RB + 256 + (((size_t)(npts / 256) * 2 + 8) * nsplit + 520) * sizeof(KnnWg) + part_bytes : 0)));
     if (rc) return rc;
     float *xx = sbuf.as<float>();
     void *aux = (char *)sbuf.p + xx_bytes;
@@ -1053,18 +1123,20 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
         if (ctab && knn_wg() >= 256 && npts / 512 <= 2048) {   // the schedule kernel lists at most 2048 sequences (one per 512-row chunk at worst)
             // XCD-affine schedule of 256-query workgroups (see knn_f16x3_wg256_kernel); the table lives behind the planes
             const int nchunks = (int)(npts / 512);
-            const int nspill = (int)(npts / 256);                   // every block of the launch fits
+            const int nspill = (int)(npts / 256) * nsplit;          // every block of the launch fits
             const int nslots = nspill / 8 + 64;                      // an XCD's run: its share of the blocks + slack for short windows
             const int nblocks = nslots * 8 + nspill;
             KnnWg *tab = (KnnWg *)((char *)pl + (((size_t)npts * RB + 255) & ~(size_t)255));
+            float *pval = (float *)((char *)tab + (((size_t)nblocks * sizeof(KnnWg) + 255) & ~(size_t)255));
+            int *pidx = (int *)(pval + (size_t)nsplit * (size_t)npts * TK);
             HIP_TRY(hipMemsetAsync(tab, 0, (size_t)nblocks * sizeof(KnnWg), st));
-            hipLaunchKernelGGL(knn_sched_kernel, dim3(1), dim3(1024), 0, st, ctab, nchunks, tab, nslots, nspill);
+            hipLaunchKernelGGL(knn_sched_kernel, dim3(1), dim3(1024), 0, st, ctab, nchunks, tab, nslots, nspill, nsplit);
             // knn_wg(): 256 = groups of 3 (K = 192) / 4 (K = 144) tiles, front-to-back order; 257: groups of 2; 258: one tile per barrier;
             // +16: outward order instead
             const int shape = knn_wg() & 15, order = (knn_wg() >> 4) & 7;
             SCP_PROF(SCP_PROF_KNN_FEAT, st, (double)C);
 #define KNN_LAUNCH(KK, GG) hipLaunchKernelGGL((knn_f16x3_wg256_kernel<KK, GG>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx, \
-                                              (const float *)isc, (const KnnWg *)tab, idx, thr0, order)
+                                              (const float *)isc, (const KnnWg *)tab, idx, thr0, order, (unsigned long long *)nullptr, nsplit, pval, pidx, (int64_t)npts)
             if (C == 144) { if (shape == 2) KNN_LAUNCH(144, 1); else if (shape == 1) KNN_LAUNCH(144, 2); else KNN_LAUNCH(144, 4); }
             else if (g_knn_dbg && shape == 0)
                 hipLaunchKernelGGL((knn_f16x3_wg256_kernel<192, 3, true>), dim3(nblocks), dim3(512), 0, st, (const _Float16 *)pl, (const float *)xx,
@@ -1072,6 +1144,10 @@ static int knn_launch(const float *x, int64_t npts, int C, dim3 grid, int n, int
             else { if (shape == 2) KNN_LAUNCH(192, 1); else if (shape == 1) KNN_LAUNCH(192, 2); else KNN_LAUNCH(192, 3); }
 #undef KNN_LAUNCH
             LAUNCH_CHECK();
+            if (nsplit > 1) {
+                hipLaunchKernelGGL(knn_merge_split_kernel, dim3((unsigned)cdiv64(npts, 256)), dim3(256), 0, st, ctab, (const float *)pval, (const int *)pidx, (int64_t)npts, nsplit, idx);
+                LAUNCH_CHECK();
+            }
             return SCP_OK;
         }
         SCP_PROF(SCP_PROF_KNN_FEAT, st, (double)C);

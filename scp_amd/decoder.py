@@ -283,7 +283,8 @@ class FrameDecoder:
         else:
             depths = [n_levels]
         out, off = [], 0
-        with native.use_profile(self.profile):
+        from . import ops
+        with native.use_profile(self.profile), ops.frozen_weights():            # (the weights do not change inside a frame: validated once per frame)
             for d in depths:
                 out.append(self._decode_tree(dec, d, pos_mm[off:off + d] if self.polar else None))
                 off += d

@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import native
-from ..ops import linear_s, leaky_mlp3_s, split_cat, linear, layer_norm, leaky_mlp3, _split, derived
+from ..ops import linear_s, leaky_mlp3_s, split_cat, linear, layer_norm, leaky_mlp3, _split, derived, frozen_epoch
 from .ehem import SHIFT, WINDOW, _edge_conv_packed, qkv_fused
 
 
@@ -161,22 +161,33 @@ def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None, tiles=None):
     """The same block on two row-chain launches around the attention kernel.  With `tiles` (the 128-row tiles that hold a real row) the
     block's second half runs IN PLACE on those tiles only and the attention skips the query tiles of pure window padding: their rows
     keep finite old values, which is all the next block needs (it multiplies their normalised rows by valid = 0)."""
-    att = layer.attention.self
     cross = query is not None
-    w = _rowchain_weights(layer, cross)
-    lnb = layer.layernorm_before
+    # inside ops.frozen_weights (one frame) a block's derived weights and the attributes the launches need are looked up once per frame: the
+    # decoder runs ~1 400 blocks per frame, and the nn.Module attribute walks + the validation of twelve source tensors were 45 us of each
+    ep = frozen_epoch()
+    fast = layer.__dict__.get("_scp_fast_x" if cross else "_scp_fast") if ep else None
+    if fast is not None and fast[0] == ep:
+        _, w, table, qbias, eps_b, eps_a = fast
+    else:
+        att = layer.attention.self
+        w = _rowchain_weights(layer, cross)
+        table, qbias = att.relative_position_bias_table, (att.query.bias if cross else None)
+        eps_b, eps_a = layer.layernorm_before.eps, layer.layernorm_after.eps
+        if ep:
+            layer.__dict__["_scp_fast_x" if cross else "_scp_fast"] = (ep, w, table, qbias, eps_b, eps_a)
     v1 = None if valid is None else valid.reshape(-1)
     if native.attention_bf16x3():
         # keys and values leave the projection as the bf16 planes the attention kernel stages by LDS-DMA (identical bits to the fp32 hand-over)
         if not cross:
-            q, kvp = native.swin_ln_qkv(x, w["kv"], w["b"], lnb.eps, v1)
+            q, kvp = native.swin_ln_qkv(x, w["kv"], w["b"], eps_b, v1)
         else:
-            q = native.swin_ln_linear(query, w["q"], att.query.bias, lnb.eps, v1)
-            _, kvp = native.swin_ln_qkv(x, w["kv"], w["b"], lnb.eps, v1)
-        o = native.swin_attention_packed_planes(q, kvp, att.relative_position_bias_table, wtab, shift, split=True, valid=v1 if tiles is not None else None)
+            q = native.swin_ln_linear(query, w["q"], qbias, eps_b, v1)
+            _, kvp = native.swin_ln_qkv(x, w["kv"], w["b"], eps_b, v1)
+        o = native.swin_attention_packed_planes(q, kvp, table, wtab, shift, split=True, valid=v1 if tiles is not None else None)
         if tiles is not None and tiles.shape[0] > 0:
-            return native.swin_post_attn(o, x, w["post"], layer.layernorm_after.eps, out=x, tiles=tiles)
-        return native.swin_post_attn(o, x, w["post"], layer.layernorm_after.eps)
+            return native.swin_post_attn(o, x, w["post"], eps_a, out=x, tiles=tiles)
+        return native.swin_post_attn(o, x, w["post"], eps_a)
+    att, lnb = layer.attention.self, layer.layernorm_before
     # numeric profile "attention = fp32 MFMA" (scp_ctx): the fp32-fed attention kernel takes q, k, v as rows
     if not cross:
         qkv = native.swin_ln_linear(x, w["kv"], w["b"], lnb.eps, v1)

@@ -21,11 +21,16 @@ def _split(w):
     """bf16 hi/lo planes of a weight, cached per tensor OBJECT (evicted when the tensor dies or is modified in place)."""
     key = id(w)
     ent = _cache.get(key)
+    ep = getattr(_TLS, "epoch", 0)
+    if ep and ent is not None and ent[3] == ep and ent[2]() is w:
+        return ent[0]
     ver = (w._version, w.data_ptr(), w.device)
     if ent is None or ent[1] != ver or ent[2]() is not w:
         sw = native.SplitWeight(w)
-        _cache[key] = (sw, ver, weakref.ref(w, lambda _r, k=key: _cache.pop(k, None)))
+        _cache[key] = (sw, ver, weakref.ref(w, lambda _r, k=key: _cache.pop(k, None)), ep)
         return sw
+    if ep:
+        _cache[key] = (ent[0], ent[1], ent[2], ep)
     return ent[0]
 
 
@@ -44,17 +49,50 @@ def _split16(w):
     return ent[0]
 
 
+_TLS = __import__("threading").local()
+_EPOCHS = __import__("itertools").count(1)
+
+
+def frozen_epoch():
+    """The calling thread's frozen-weights epoch (0 = none): see `frozen_weights`."""
+    return getattr(_TLS, "epoch", 0)
+
+
+class frozen_weights:
+    """`with ops.frozen_weights():` - inside the block (one frame of a FrameEncoder / FrameDecoder) the parameters do not change, so a derived
+    weight is validated against its sources ONCE, at its first use, instead of at every launch: the decoder runs ~1 400 Swin blocks per frame and
+    the validation (twelve (data_ptr, _version, device) triples per block, plus the nn.Module attribute walks to reach them) was a sixth of its
+    host time.  Outside the block every use validates, as before (`test_weights_replaced_after_a_forward_take_effect`).  Per thread; re-entrant."""
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "epoch", 0)
+        if not self.prev:
+            _TLS.epoch = next(_EPOCHS)
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.epoch = self.prev
+        return False
+
+
 def derived(owner, name, sources, build):
     """A tensor (tuple) derived from parameters - fused qkv weights, conv / BN folds, weight slabs - cached on the owning module
     and rebuilt whenever a source changed: its storage, device or in-place version (`load_state_dict`, `fill_weights` and
-    optimiser steps all bump `_version`).  The bf16 splits further down are keyed on the derived tensors, so they follow."""
-    key = tuple((t.data_ptr(), t._version, t.device) for t in sources)
+    optimiser steps all bump `_version`).  The bf16 splits further down are keyed on the derived tensors, so they follow.
+    Inside `frozen_weights` an entry validated in this epoch is returned as it is."""
     store = owner.__dict__.setdefault("_scp_derived", {})
     ent = store.get(name)
+    ep = getattr(_TLS, "epoch", 0)
+    if ep and ent is not None and ent[2] == ep:
+        return ent[1]
+    key = tuple((t.data_ptr(), t._version, t.device) for t in sources)
     if ent is None or ent[0] != key:
-        ent = (key, build())
+        ent = (key, build(), ep)
         store[name] = ent
         native.note_cache_fill()
+    elif ep:
+        ent = (ent[0], ent[1], ep)
+        store[name] = ent
     return ent[1]
 
 

@@ -129,6 +129,38 @@ def test_knn_packed_workgroup_shapes_agree_on_ragged_windows(dev):
             base += -(-n // 512) * 512
 
 
+@pytest.mark.parametrize("lengths", [[8192], [2049], [300], [33], [8192, 4000], [700, 700, 700, 20], [5000] * 6])
+def test_knn_short_launches_split_the_candidate_sweep_with_identical_lists(dev, lengths):
+    """Round 5 (decoder latency): a packed search with too few 256-query blocks for the chip cuts every block's candidate sweep into 2 - 16 runs
+    (one workgroup each) and merges the partial lists under the lists' own total order (value descending, index ascending) - the lists equal
+    the single-sweep kernel's (workgroup shape 257 never splits) and the dense per-window entry point's, heavily tied features included."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(len(lengths) * 1000 + lengths[0])
+    for C, ties in ((144, True), (192, False), (192, True)):
+        rows = sum(-(-n // 512) * 512 for n in lengths)
+        x = torch.zeros((rows, C))
+        tab, base = [], 0
+        for n in lengths:
+            x[base:base + n] = torch.randint(0, 3, (n, C), generator=g).float() if ties else torch.randn((n, C), generator=g)
+            tab += [[base, n]] * (-(-n // 512))
+            base += -(-n // 512) * 512
+        xd, td = x.to(dev), torch.tensor(tab, dtype=torch.int32, device=dev)
+        try:
+            native.set_knn_workgroup(256)
+            split = native.knn_topk_packed(xd, td).cpu()
+            native.set_knn_workgroup(257)
+            single = native.knn_topk_packed(xd, td).cpu()
+        finally:
+            native.set_knn_workgroup(256)
+        base = 0
+        for n in lengths:
+            assert torch.equal(split[base:base + n], single[base:base + n]), (C, ties, n)
+            k = min(20, n)
+            want = native.knn_topk(xd[base:base + n][None].contiguous(), k).cpu()[0].long() + base
+            assert torch.equal(split[base:base + n, :k].long(), want), (C, ties, n)
+            base += -(-n // 512) * 512
+
+
 def test_knn_packed_many_short_windows(dev):
     """More sequences than the XCD schedule lists (2048): the launch falls back to the 128-query kernel; and a launch of 1500 one-chunk
     windows on the schedule (every run holds far more blocks than its even share of slots: the spill region takes them)."""
