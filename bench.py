@@ -507,7 +507,7 @@ def side_legs(args, out):
                                                             decoded_occupancy_equals_encoded=z4["decoded_occupancy_equals_encoded"], host_cpu_ms_per_frame=z4.get("host_cpu_ms_per_frame"),
                                                             note="four independent frames decoded side by side (one FrameDecoder, host thread and HIP stream each) in ONE process: the GPU has "
                                                                  "room (a decode is a chain of short launches on a fraction of the CUs), the four launch threads share the interpreter lock")
-    out["cli"] = cli_leg(args.leg_warmup, args.leg_steps)
+    out["cli"] = cli_leg(args.leg_warmup, 2 * args.leg_steps)            # (files are cheap: a longer steady-state window than the bench legs')
     if "fps" in out["cli"]:
         out["cli_over_bench"] = out["cli"]["fps"] / out["value"]
     out["legs_note"] = ("`configs` / `decode` / `cli`: child processes of this run, started after the headline's timed region; each is this file's own "

@@ -91,7 +91,7 @@ def test_bench_side_legs_fill_configs_decode_and_cli():
     d = out["decode"]
     assert d["decoded_occupancy_equals_encoded"] is True and d["fps"] > 0
     c = out["cli"]
-    assert c["streams_written"] == c["files"] == 7 and c["files_timed"] == 2 and c["fps"] > 0 and abs(out["cli_over_bench"] - c["fps"] / out["value"]) < 1e-9
+    assert c["streams_written"] == c["files"] == 9 and c["files_timed"] == 4 and c["fps"] > 0 and abs(out["cli_over_bench"] - c["fps"] / out["value"]) < 1e-9
     d4 = out["decode_4_streams"]
     assert d4["decoded_occupancy_equals_encoded"] is True and d4["frames_decoded_concurrently"] == 4 and d4["fps"] > 0
 
