@@ -13,7 +13,8 @@ The headline `value` is measured in STRICT-IDENTITY mode (round 5): the float ->
 from the reference's integers (`transform_parity`); the device-transform rate is the extra key `device_transform`.
 After the headline (outside its timed region, N = 1 only) the default run adds short legs, each a child process running this file
 (5 warm-up + 10 timed frames): the other four BASELINE.json workloads and the decoder under `configs`, and a `cli` leg - `.bin` files on disk
-through the drop-in `encode_mullevel.py` (file read, parse, host -> device copy and the written `.bin` / `.dat` inside) - with `cli_over_bench`.
+through the drop-in `encode_mullevel.py` (file read, parse, host -> device copy and the written `.bin` / `.dat` inside) - with `cli_over_bench`;
+`decode_2_procs` / `decode_4_procs`: independent decoder processes sharing the GPU (a decode is a serial chain of short launches: streams scale by process).
 
 One step = one synthetic 120 000-point frame through the whole hot path on one GPU: quantiser (3 shells) -> octree
 serialisation -> context tables -> EHEM over every <= 8192-node window -> softmax/integer CDF -> range coder.  The frame
@@ -72,6 +73,8 @@ def parse():
     ap.add_argument("--leg-warmup", type=int, default=5)
     ap.add_argument("--oa-batch", type=int, default=None, help="OctAttention: windows per forward (OctAttnFrameEncoder.max_batch)")
     ap.add_argument("--decode", action="store_true", help="time the decoder (FrameDecoder) on the configuration's frame instead of the encoder")
+    ap.add_argument("--proc-barrier", default=None, metavar="DIR:N", help="with --decode: this process is one of N decoder processes sharing the GPU; after its warm-up it "
+                    "drops a file into DIR and starts its timed loop when N files are there (the parent computes the aggregate rate from the t_begin / t_end each line carries)")
     ap.add_argument("--decode-streams", type=int, default=1, help="with --decode: frames decoded CONCURRENTLY, each by its own FrameDecoder on its own host thread and "
                     "HIP stream (a frame's decode is a chain of dependent launch sequences that uses a fraction of the GPU: independent frames overlap)")
     ap.add_argument("--all-configs", action="store_true", help="run every configuration of CONFIGS in turn (child processes), one JSON line each")
@@ -409,11 +412,21 @@ def run_decode(args, cfg, enc, model, dev, frame_host):
         cpu_ms = 1e3 * (time.process_time() - cpu0) / (args.steps * nstreams)
         shells = outs[-1]
     else:
+        if args.proc_barrier:
+            bdir, nproc = args.proc_barrier.rsplit(":", 1)
+            open(os.path.join(bdir, f"ready_{os.getpid()}"), "w").close()
+            t_wait = time.perf_counter()
+            while len([f for f in os.listdir(bdir) if f.startswith("ready_")]) < int(nproc):
+                if time.perf_counter() - t_wait > 600:
+                    raise SystemExit("--proc-barrier: the other decoder processes never arrived")
+                time.sleep(0.002)
+        t_begin = time.time()
         cpu0, t0 = time.process_time(), time.perf_counter()
         for i in range(args.steps):
             shells = dec.decode(res["bytes"], res["n_levels"], res["pos_mm"])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        t_end = time.time()
         cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps
     for (codes, _), w in zip(shells, want):
         got = torch.cat(codes).cpu().numpy()
@@ -429,6 +442,8 @@ def run_decode(args, cfg, enc, model, dev, frame_host):
                       "levels": len(res["level_sizes"]), "phase1_launch_sequences_per_frame": len(res["level_sizes"]),
                       "phase2_launch_sequences_per_frame": with_phase2, "frames_decoded_concurrently": nstreams},
            "decoded_occupancy_equals_encoded": bool(ok), "host_cpu_ms_per_frame": cpu_ms, "stream_bytes": len(res["bytes"])}
+    if nstreams == 1:
+        out["t_begin"], out["t_end"] = t_begin, t_end
     out["stage_ms"] = stage
     out["stage_ms_note"] = "one extra decode of the same stream with a device synchronisation after every stage (slower than the timed decodes)"
     print(json.dumps(out), flush=True)
@@ -442,6 +457,35 @@ def _child_line(argv, timeout=900):
     if line is None:
         return {"error": f"exit code {r.returncode}: {r.stderr[-300:]}"}
     return json.loads(line)
+
+
+def decode_procs_leg(nproc, steps):
+    """`nproc` decoder PROCESSES side by side on this GPU (a decoding server's shape: a decode is a serial chain of short launches that keeps one host
+    thread busy and fills a fraction of the GPU, so independent streams are decoded by independent processes - threads of one process share the interpreter
+    lock).  Every child is `bench.py --decode`; their timed loops start together (file barrier); aggregate = all frames / (last end - first begin)."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [sys.executable, os.path.abspath(__file__), "--decode", "--steps", str(steps), "--warmup", "1", "--proc-barrier", f"{tmp}:{nproc}"]
+        ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(nproc)]
+        zs = []
+        for q in ps:
+            try:
+                so, se = q.communicate(timeout=900)
+            except subprocess.TimeoutExpired:
+                q.kill()
+                so, se = q.communicate()
+            line = next((l for l in reversed(so.splitlines()) if l.startswith("{")), None)
+            if line is None:
+                return {"error": f"exit code {q.returncode}: {se[-300:]}"}
+            zs.append(json.loads(line))
+    span = max(z["t_end"] for z in zs) - min(z["t_begin"] for z in zs)
+    return dict(fps=nproc * steps / span, processes=nproc, frames=nproc * steps, per_process_fps=[z["value"] for z in zs],
+                start_skew_ms=1e3 * (max(z["t_begin"] for z in zs) - min(z["t_begin"] for z in zs)),
+                decoded_occupancy_equals_encoded=all(z["decoded_occupancy_equals_encoded"] for z in zs),
+                host_cpu_ms_per_frame=max(z["host_cpu_ms_per_frame"] for z in zs),
+                note="independent decoder processes sharing ONE GPU (each: its own host thread, HIP queues, model replica), timed loops started together; "
+                     "fps = all frames / (last end - first begin)")
 
 
 def cli_leg(n_warm, n_timed):
@@ -502,11 +546,8 @@ def side_legs(args, out):
     z = _child_line(["--decode", "--steps", "3", "--warmup", "1"])
     out["decode"] = z if "error" in z else dict(fps=z["value"], ms_per_step=z["ms_per_step"], steps=z["steps"], decoded_occupancy_equals_encoded=z["decoded_occupancy_equals_encoded"],
                                                stage_ms=z.get("stage_ms"), host_cpu_ms_per_frame=z.get("host_cpu_ms_per_frame"), workload=z["config"]["workload"])
-    z4 = _child_line(["--decode", "--decode-streams", "4", "--steps", "2", "--warmup", "1"])
-    out["decode_4_streams"] = z4 if "error" in z4 else dict(fps=z4["value"], frames_decoded_concurrently=z4["config"]["frames_decoded_concurrently"],
-                                                            decoded_occupancy_equals_encoded=z4["decoded_occupancy_equals_encoded"], host_cpu_ms_per_frame=z4.get("host_cpu_ms_per_frame"),
-                                                            note="four independent frames decoded side by side (one FrameDecoder, host thread and HIP stream each) in ONE process: the GPU has "
-                                                                 "room (a decode is a chain of short launches on a fraction of the CUs), the four launch threads share the interpreter lock")
+    out["decode_2_procs"] = decode_procs_leg(2, 4)
+    out["decode_4_procs"] = decode_procs_leg(4, 4)
     out["cli"] = cli_leg(args.leg_warmup, 2 * args.leg_steps)            # (files are cheap: a longer steady-state window than the bench legs')
     if "fps" in out["cli"]:
         out["cli_over_bench"] = out["cli"]["fps"] / out["value"]
