@@ -690,8 +690,22 @@ __device__ __forceinline__ RcFragAddr rc_frag_addr(const RcLane &L, char *half_b
 // v_accvgpr moves (about 2.7 per MFMA gap).  With asm MFMAs it no longer inserts the wait states between a VALU write of a register
 // (its own v_accvgpr copies for the "a" constraints, the zeroing of an accumulator) and the MFMA that reads it: wrong results that
 // come and go with timing, and the build that added the nops by hand was slower (186 k against 171 k cycles per tile for the MLP).
+#ifdef RC_PROBE_SHAPE16
+// Timing probe (WRONG results; tools/r5_shape_probe.sh): every 32x32x16 product as two v_mfma_f32_16x16x32_bf16 on the same operand registers and two quarters of
+// the same accumulator - the MACs, the operand reads and the dependency distances of the real step, the other MFMA shape (profiles/r5_mfma_shape.md)
+__device__ __forceinline__ void rc_mfma_shape16(rf32x16 &acc, const rbf16x8 &a, const rbf16x8 &b) {
+    rf32x4 q0 = {acc[0], acc[1], acc[2], acc[3]}, q1 = {acc[4], acc[5], acc[6], acc[7]};
+    q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q0, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q1, 0, 0, 0);
+    acc[0] = q0[0]; acc[1] = q0[1]; acc[2] = q0[2]; acc[3] = q0[3];
+    acc[4] = q1[0]; acc[5] = q1[1]; acc[6] = q1[2]; acc[7] = q1[3];
+}
+#define RC_MFMA_AVA(acc, a, b) rc_mfma_shape16(acc, a, b)
+#define RC_MFMA_AVV(acc, a, b) rc_mfma_shape16(acc, a, __builtin_bit_cast(rbf16x8, b))
+#else
 #define RC_MFMA_AVA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0)
 #define RC_MFMA_AVV(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(rbf16x8, b), acc, 0, 0, 0)
+#endif
 #define RC_MFMA_DRAIN() do { } while (0)
 
 // GEMM step: two row-chunk slots, two chains (c0: slot 0, c1: slot 1) over the 16 k-steps of the resident B fragments.  Used for
