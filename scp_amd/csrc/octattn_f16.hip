@@ -48,9 +48,14 @@ __device__ __forceinline__ void oa_pow2_scale(float mx, float &sc, float &isc) {
     isc = __uint_as_float((unsigned)(127 - e) << 23);
 }
 
-// max |v| over the launch (non-negative floats order like their bit patterns)
+// max |v| over the launch: one partial maximum per wave (finite, non-negative), reduced by every workgroup of oa_prep_kernel.  (Until round 5
+// the waves met in an atomicMax on a word that a 4-byte hipMemsetAsync had cleared: that memset is a runtime blit kernel whose system-scope
+// release writes the whole L2 back - 100 us on average and up to 1.25 ms behind the key | value GEMM, 1.2 ms per L14 frame,
+// profiles/r5_octattn_L14_frame_kernel_stats.csv: __amd_rocclr_fillBufferAligned.)
+#define OA_PART_MAX 4096            // 1024 workgroups x 4 waves
+#define OA_HDR (1024 + 4 * OA_PART_MAX)
 __global__ __launch_bounds__(256) void oa_absmax_kernel(const float *__restrict__ v, int64_t n4, int d4 /* float4 per row */, int64_t ld,
-                                                       unsigned *__restrict__ out) {
+                                                       float *__restrict__ part) {
     float mx = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / d4;
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(256) void oa_absmax_kernel(const float *__restrict_
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0 && mx == mx) atomicMax(out, __float_as_uint(fminf(mx, 3.0e38f)));
+    if ((threadIdx.x & 63) == 0) part[blockIdx.x * 4 + (threadIdx.x >> 6)] = mx == mx ? fminf(mx, 3.0e38f) : 0.f;
 }
 
 // workgroup = one 32-token tile of one (batch, head): thread (t = tid >> 3, s = tid & 7) walks float2 pieces s, s + 8, ... of row t.
@@ -68,10 +73,11 @@ __global__ __launch_bounds__(256) void oa_absmax_kernel(const float *__restrict_
 // wave instruction - the kernel moved its 5.3 GB per L14 layer at 0.85 TB/s, 81 % of its wave cycles issue-stalled, profiles/r4i_octattn_L14_*.)
 // Same arithmetic, same bits.
 __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ q_u, const float *__restrict__ k, const float *__restrict__ k_u,
-                                                     const float *__restrict__ v, int64_t ldkv, int c, int H, int nt, const unsigned *__restrict__ vmax_bits,
-                                                     _Float16 *__restrict__ qp, float *__restrict__ isq, float2 *__restrict__ diag,
+                                                     const float *__restrict__ v, int64_t ldkv, int c, int H, int nt, const float *__restrict__ vpart, int npart,
+                                                     unsigned *__restrict__ vmax_out, _Float16 *__restrict__ qp, float *__restrict__ isq, float2 *__restrict__ diag,
                                                      char *__restrict__ kimg, char *__restrict__ vimg) {
     __shared__ float vt[32][FHD + 1];
+    __shared__ float vred[4];
     __shared__ __attribute__((aligned(16))) char kst[FK_IMG];              // the K image of this (tile, head), as it will lie in memory
     __shared__ __attribute__((aligned(16))) _Float16 qst[32][2 * FHP];     // the 32 Q rows (hi plane | lo plane)
     const int tid = threadIdx.x, t = tid >> 3, s = tid & 7;
@@ -81,8 +87,8 @@ __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ 
     const bool real = tok < c;
     const size_t row = ((size_t)b * c + (real ? tok : c - 1)) * D + (size_t)head * FHD;            // q_u: dense rows
     const size_t rowk = ((size_t)b * c + (real ? tok : c - 1)) * (size_t)ldkv + (size_t)head * FHD;   // k, k_u, v: rows ldkv floats apart
-    float vs, ivs;
-    oa_pow2_scale(__uint_as_float(*vmax_bits), vs, ivs);
+    float pm = 0.f;
+    for (int i = tid; i < npart; i += 256) pm = fmaxf(pm, vpart[i]);
 
     float2 qv[10], kv[10];
     float qm = 0.f, km = 0.f, sii = 0.f, dz = 0.f;                   // the two diagonal terms q_i.k_i, q_i.ku_i: plain fp32
@@ -97,6 +103,15 @@ __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ 
         ld_v[i] = *(const float2 *)(v + rowk + 2 * pc); ld_u[i] = *(const float2 *)(k_u + rowk + 2 * pc);
     }
     __builtin_amdgcn_sched_barrier(0);
+    // max |v| of the launch (every workgroup reduces the partial maxima itself; workgroup (0, 0) leaves the value for the attention kernel)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pm = fmaxf(pm, __shfl_xor(pm, o));
+    if ((tid & 63) == 0) vred[tid >> 6] = pm;
+    __syncthreads();
+    const float vmaxv = fmaxf(fmaxf(vred[0], vred[1]), fmaxf(vred[2], vred[3]));
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *vmax_out = __float_as_uint(vmaxv);
+    float vs, ivs;
+    oa_pow2_scale(vmaxv, vs, ivs);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         const int p = s + 8 * i;
@@ -361,7 +376,7 @@ static inline size_t oa_align(size_t x) { return (x + 1023) & ~(size_t)1023; }
 extern "C" SCP_API int64_t scp_octattn_f16x3_ws_bytes(int32_t B, int32_t c, int32_t H) {
     if (B <= 0 || c <= 0 || H <= 0) return SCP_EINVAL;
     const size_t nt = (size_t)(c + 31) / 32, rows = (size_t)B * nt * 32 * H;
-    return (int64_t)(1024 + oa_align(rows * 4) + oa_align(rows * 8) + oa_align(rows * 2 * FHP * 2) + (size_t)B * nt * H * (FK_IMG + FV_IMG));
+    return (int64_t)(OA_HDR + oa_align(rows * 4) + oa_align(rows * 8) + oa_align(rows * 2 * FHP * 2) + (size_t)B * nt * H * (FK_IMG + FV_IMG));
 }
 
 extern "C" SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
@@ -376,18 +391,19 @@ extern "C" SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float
     const size_t rows = (size_t)B * nt * 32 * H;
     char *ws = (char *)workspace;
     unsigned *vmax = (unsigned *)ws;
-    float *isq = (float *)(ws + 1024);
-    float2 *diag = (float2 *)(ws + 1024 + oa_align(rows * 4));
+    float *vpart = (float *)(ws + 1024);
+    float *isq = (float *)(ws + OA_HDR);
+    float2 *diag = (float2 *)(ws + OA_HDR + oa_align(rows * 4));
     _Float16 *qp = (_Float16 *)((char *)diag + oa_align(rows * 8));
     char *kimg = (char *)qp + oa_align(rows * 2 * FHP * 2);
     char *vimg = kimg + (size_t)B * nt * H * FK_IMG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(vmax, 0, 4, st) != hipSuccess) return SCP_EHIP;
     const int64_t n4 = (int64_t)B * c * H * FHD / 4;                 // 600 floats per token: a multiple of 4
     {
         SCP_PROF(SCP_PROF_OTHER, st, 0.0);             // operand preparation (planes, scales, diagonal terms)
-        hipLaunchKernelGGL(oa_absmax_kernel, dim3((unsigned)(n4 < 256 * 1024 ? (n4 + 255) / 256 : 1024)), dim3(256), 0, st, v, n4, H * FHD / 4, ldkv, vmax);
-        hipLaunchKernelGGL(oa_prep_kernel, dim3(B * nt, H), dim3(256), 0, st, q_u, k, k_u, v, ldkv, c, H, nt, vmax, qp, isq, diag, kimg, vimg);
+        const unsigned nblk = (unsigned)(n4 < 256 * 1024 ? (n4 + 255) / 256 : 1024);
+        hipLaunchKernelGGL(oa_absmax_kernel, dim3(nblk), dim3(256), 0, st, v, n4, H * FHD / 4, ldkv, vpart);
+        hipLaunchKernelGGL(oa_prep_kernel, dim3(B * nt, H), dim3(256), 0, st, q_u, k, k_u, v, ldkv, c, H, nt, vpart, (int)(4 * nblk), vmax, qp, isq, diag, kimg, vimg);
     }
     SCP_PROF(SCP_PROF_OA_ATTENTION, st, (double)B * 3.0 * 2.0 * c * (double)c * H * FHD);
     hipLaunchKernelGGL(oa_attn_f16x3_kernel, dim3(B * H * ((c + 127) / 128)), dim3(256), 0, st, v, v_u, ldkv, c, H, nt, vmax, qp, isq, diag,
