@@ -130,6 +130,9 @@ class FrameDecoder:
         self.context_size = model.cfg.model.context_size
         self.stats = None             # set to {} to collect wall seconds per stage (adds a device synchronisation per stamp: bench.py --decode)
         self._plans = {}              # one-window plans by window length (index maps depend on the length only): built once, reused
+        self._pin = [None, None]      # pinned staging of the CDF rows (grown on demand)
+        self._side = None             # side stream of ehem_phase2_prepare (created on first use, on the decoding thread's device)
+        self.prepare_ahead = os.environ.get("SCP_DEC_PREP", "1") != "0"       # A/B switch: 0 = everything of phase 2 after the even symbols
 
     def _stamp(self, key, t0):
         if self.stats is None:
@@ -157,6 +160,37 @@ class FrameDecoder:
             p = self._plans[c] = PackedPlan([c], device=self.device)
         return p
 
+    def _cdf_to_host(self, cdf_dev, then=None, slot=0):
+        """int16 CDF rows -> numpy, through a pinned buffer with an asynchronous copy: `then()` (launches for the side stream) runs on the host while
+        the GPU finishes phase 1 and the copy; returns (rows, then's result).  The rows are a view of pinned buffer `slot` (0: a level's phase-1 rows,
+        1: a window's phase-2 rows): consumed before the slot's next use."""
+        n = cdf_dev.numel()
+        if self._pin[slot] is None or self._pin[slot].numel() < n:
+            self._pin[slot] = torch.empty(max(n, 1 << 20), dtype=torch.int16, pin_memory=True)
+        host = self._pin[slot][:n].view(cdf_dev.shape)
+        host.copy_(cdf_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        r = then() if then is not None else None
+        ev.synchronize()
+        return host.numpy(), r
+
+    def _prepare(self, st, plan):
+        """Start the symbol-independent part of phase 2 (models/packed.py: ehem_phase2_prepare) on the side stream, behind everything the current
+        stream holds so far (phase 1); returns (prep, event).  The host decodes the even symbols meanwhile; phase 2 waits for the event."""
+        from .models.packed import ehem_phase2_prepare
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            prep = ehem_phase2_prepare(self.model, st, plan)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        return prep, done
+
     def _decode_window(self, dec, ctx, pos):
         """ctx uint8 [c,12] (own occupancy = 255 placeholder), pos f32 [c,3] -> int64 symbols [c] (device).
         Runs the SAME packed kernels as the encoder (a one-window plan): encoder and decoder must produce bit-identical
@@ -167,7 +201,8 @@ class FrameDecoder:
         plan = self._plan1(c)
         prob1, st = ehem_phase1_packed(self.model, ctx, pos, plan)
         t = self._stamp("phase1_model", t)
-        cdf = native.softmax_cdf(prob1.contiguous(), want_lohi=False, want_cdf=True)["cdf"].cpu().numpy()
+        cdf_dev = native.softmax_cdf(prob1.contiguous(), want_lohi=False, want_cdf=True)["cdf"]
+        cdf, prep = self._cdf_to_host(cdf_dev, (lambda: self._prepare(st, plan)) if (c > 1 and self.prepare_ahead) else None)
         t = self._stamp("cdf_d2h", t)
         even = torch.from_numpy(dec.run(cdf).astype(np.int64)).to(self.device)
         t = self._stamp("range_decoder", t)
@@ -178,9 +213,11 @@ class FrameDecoder:
             po = torch.zeros(Q0, dtype=torch.int64, device=self.device)
             po[:even.shape[0]] = even                       # one window: its real rows are the first rows of the cross layout
             t = self._stamp("index_ops", t)
-            prob2 = ehem_phase2_packed(self.model, st, plan, po)
+            if prep is not None:
+                torch.cuda.current_stream(self.device).wait_event(prep[1])
+            prob2 = ehem_phase2_packed(self.model, st, plan, po, prep=None if prep is None else prep[0])
             t = self._stamp("phase2_model", t)
-            cdf = native.softmax_cdf(prob2.contiguous(), want_lohi=False, want_cdf=True)["cdf"].cpu().numpy()
+            cdf, _ = self._cdf_to_host(native.softmax_cdf(prob2.contiguous(), want_lohi=False, want_cdf=True)["cdf"], slot=1)
             t = self._stamp("cdf_d2h", t)
             sym[1::2] = torch.from_numpy(dec.run(cdf).astype(np.int64)).to(self.device)
             t = self._stamp("range_decoder", t)
@@ -192,7 +229,7 @@ class FrameDecoder:
         deterministic: tests/test_gpu_e2e.py::test_full_frame_packed_forward_is_batch_invariant) and 10 - 50 x better at filling the
         GPU; phase 2 needs the window's decoded even symbols and the bitstream interleaves the windows (evens, odds, evens, ...),
         so it runs window by window on that window's slice of the phase-1 state (a one-window plan has exactly that layout)."""
-        from .models.packed import PackedPlan, ehem_phase1_packed, ehem_phase2_packed
+        from .models.packed import PackedPlan, ehem_phase1_packed, ehem_phase2_packed, phase2_prep_window
         cs = self.context_size
         n = ctx.shape[0]
         lengths = [min(cs, n - i) for i in range(0, n, cs)]
@@ -202,13 +239,21 @@ class FrameDecoder:
         plan = PackedPlan(lengths, device=self.device)
         prob1, st = ehem_phase1_packed(self.model, ctx, pos, plan)
         t = self._stamp("phase1_model", t)
-        cdf1 = native.softmax_cdf(prob1.contiguous(), want_lohi=False, want_cdf=True)["cdf"].cpu().numpy()
+        cdf1_dev = native.softmax_cdf(prob1.contiguous(), want_lohi=False, want_cdf=True)["cdf"]
+        # the level's query stream + pre_attn_mlp: one packed pass over all windows, launched while the CDF rows travel
+        cdf1, prep = self._cdf_to_host(cdf1_dev, (lambda: self._prepare(st, plan)) if self.prepare_ahead else None)
         t = self._stamp("cdf_d2h", t)
         sym = torch.empty(n, dtype=torch.int64, device=self.device)
         row0 = e0 = q0 = 0
+        nst = len(self.model.swin_cross_transformer.layers)
+        bases = [0] * nst                                                       # first row of the current window in every cross stage
         for c in lengths:
             ne = (c + 1) // 2
             qp = -(-((c + (c & 1)) // 2) // 512) * 512                     # cross-layout rows of this window (padded to 512)
+            rows, L = [], (c + (c & 1)) // 2                                    # (models/packed.py: StageLayout - every stage pads a window to x512 rows)
+            for _ in range(nst):
+                rows.append(-(-L // 512) * 512)
+                L = (L + 1) // 2
             even = torch.from_numpy(dec.run(cdf1[e0:e0 + ne]).astype(np.int64)).to(self.device)
             t = self._stamp("range_decoder", t)
             sym[row0:row0 + c:2] = even
@@ -219,15 +264,22 @@ class FrameDecoder:
                 po = torch.zeros(qp, dtype=torch.int64, device=self.device)
                 po[:ne] = even
                 t = self._stamp("index_ops", t)
-                prob2 = ehem_phase2_packed(self.model, stw, pw, po)
+                pwin = None
+                if prep is not None:
+                    if prep[1] is not None:
+                        torch.cuda.current_stream(self.device).wait_event(prep[1])
+                        prep = (prep[0], None)
+                    pwin = phase2_prep_window(prep[0], bases, rows)
+                prob2 = ehem_phase2_packed(self.model, stw, pw, po, prep=pwin)
                 t = self._stamp("phase2_model", t)
-                cdf = native.softmax_cdf(prob2.contiguous(), want_lohi=False, want_cdf=True)["cdf"].cpu().numpy()
+                cdf, _ = self._cdf_to_host(native.softmax_cdf(prob2.contiguous(), want_lohi=False, want_cdf=True)["cdf"], slot=1)
                 t = self._stamp("cdf_d2h", t)
                 sym[row0 + 1:row0 + c:2] = torch.from_numpy(dec.run(cdf).astype(np.int64)).to(self.device)
                 t = self._stamp("range_decoder", t)
             row0 += c
             e0 += ne
             q0 += qp
+            bases = [b + r for b, r in zip(bases, rows)]
         return sym
 
     def _decode_tree(self, dec, depth, pos_mm):

@@ -157,31 +157,36 @@ def _rowchain_weights(layer, cross):
     return derived(layer, "rowchain+" if cross else "rowchain", srcs, build)
 
 
-def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None, tiles=None):
+def _block_consts(layer, cross):
+    """(derived weights, bias table, query bias, eps before, eps after) of a block; inside ops.frozen_weights looked up once per frame."""
+    ep = frozen_epoch()
+    key = "_scp_fast_x" if cross else "_scp_fast"
+    fast = layer.__dict__.get(key) if ep else None
+    if fast is not None and fast[0] == ep:
+        return fast[1:]
+    att = layer.attention.self
+    out = (_rowchain_weights(layer, cross), att.relative_position_bias_table, (att.query.bias if cross else None), layer.layernorm_before.eps, layer.layernorm_after.eps)
+    if ep:
+        layer.__dict__[key] = (ep,) + out
+    return out
+
+
+def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None, tiles=None, q_pre=None):
     """The same block on two row-chain launches around the attention kernel.  With `tiles` (the 128-row tiles that hold a real row) the
     block's second half runs IN PLACE on those tiles only and the attention skips the query tiles of pure window padding: their rows
     keep finite old values, which is all the next block needs (it multiplies their normalised rows by valid = 0)."""
     cross = query is not None
     # inside ops.frozen_weights (one frame) a block's derived weights and the attributes the launches need are looked up once per frame: the
     # decoder runs ~1 400 blocks per frame, and the nn.Module attribute walks + the validation of twelve source tensors were 45 us of each
-    ep = frozen_epoch()
-    fast = layer.__dict__.get("_scp_fast_x" if cross else "_scp_fast") if ep else None
-    if fast is not None and fast[0] == ep:
-        _, w, table, qbias, eps_b, eps_a = fast
-    else:
-        att = layer.attention.self
-        w = _rowchain_weights(layer, cross)
-        table, qbias = att.relative_position_bias_table, (att.query.bias if cross else None)
-        eps_b, eps_a = layer.layernorm_before.eps, layer.layernorm_after.eps
-        if ep:
-            layer.__dict__["_scp_fast_x" if cross else "_scp_fast"] = (ep, w, table, qbias, eps_b, eps_a)
+    w, table, qbias, eps_b, eps_a = _block_consts(layer, cross)
     v1 = None if valid is None else valid.reshape(-1)
     if native.attention_bf16x3():
         # keys and values leave the projection as the bf16 planes the attention kernel stages by LDS-DMA (identical bits to the fp32 hand-over)
         if not cross:
             q, kvp = native.swin_ln_qkv(x, w["kv"], w["b"], eps_b, v1)
         else:
-            q = native.swin_ln_linear(query, w["q"], qbias, eps_b, v1)
+            # q_pre: the block's query projection, computed ahead by ehem_phase2_prepare (the decoder: it does not depend on the decoded symbols)
+            q = q_pre if q_pre is not None else native.swin_ln_linear(query, w["q"], qbias, eps_b, v1)
             _, kvp = native.swin_ln_qkv(x, w["kv"], w["b"], eps_b, v1)
         o = native.swin_attention_packed_planes(q, kvp, table, wtab, shift, split=True, valid=v1 if tiles is not None else None)
         if tiles is not None and tiles.shape[0] > 0:
@@ -193,20 +198,20 @@ def _swin_layer_rowchain(layer, x, valid, wtab, shift, query=None, tiles=None):
         qkv = native.swin_ln_linear(x, w["kv"], w["b"], lnb.eps, v1)
         q, k, v = qkv[:, :256], qkv[:, 256:512], qkv[:, 512:]
     else:
-        q = native.swin_ln_linear(query, w["q"], att.query.bias, lnb.eps, v1)
+        q = q_pre if q_pre is not None else native.swin_ln_linear(query, w["q"], att.query.bias, lnb.eps, v1)
         kv = native.swin_ln_linear(x, w["kv"], w["b"], lnb.eps, v1)
         k, v = kv[:, :256], kv[:, 256:]
     o = native.swin_attention_packed(q, k, v, att.relative_position_bias_table, wtab, shift, split=True)
     return native.swin_post_attn(o, x, w["post"], layer.layernorm_after.eps)
 
 
-def _swin_layer(layer, x, valid, wtab, shift, query=None, tiles=None):
+def _swin_layer(layer, x, valid, wtab, shift, query=None, tiles=None, q_pre=None):
     """swin_transformer.py:654-706 on a packed layout (rows beyond a window's length are don't-care, except that the
     LayerNorm output is zeroed there - the reference zero-pads AFTER LayerNorm): two row-chain launches around the attention kernel."""
     fc1, fc2 = layer.intermediate.dense, layer.output.dense
     if x.shape[1] != 256 or fc1.weight.shape != (1024, 256) or fc2.weight.shape != (256, 1024):
         raise native.ScpError("EHEM's Swin blocks are 256 wide with a 1024-wide MLP (configs/model/ehem.yaml); other widths are not built")
-    return _swin_layer_rowchain(layer, x, valid, wtab, shift, query, tiles)
+    return _swin_layer_rowchain(layer, x, valid, wtab, shift, query, tiles, q_pre)
 
 
 def _merge(m, x, maps):
@@ -219,15 +224,17 @@ def _merge(m, x, maps):
     return native.swin_merge(x, ev, od, mw, m.norm.eps)
 
 
-def _encoder(enc, x, valids, tabs, merges, query=None, tiles=None):
+def _encoder(enc, x, valids, tabs, merges, query=None, tiles=None, q_pre=None):
+    """q_pre[s][b]: the query projections of the cross blocks when they were computed ahead (then the query stream is not merged here)."""
     hs = [x]
     for s, stage in enumerate(enc.layers):
         for b, blk in enumerate(stage.blocks):
-            x = _swin_layer(blk, x, valids[s], tabs[s], SHIFT if b % 2 else 0, query, None if tiles is None else tiles[s])
+            x = _swin_layer(blk, x, valids[s], tabs[s], SHIFT if b % 2 else 0, query, None if tiles is None else tiles[s],
+                            None if q_pre is None else q_pre[s][b])
         hs.append(x)
         if s < len(enc.layers) - 1:
             x = _merge(stage.downsample, x, merges[s])
-            if query is not None:
+            if query is not None and q_pre is None:
                 query = _merge(stage.downsample, query, merges[s])
     return hs
 
@@ -342,19 +349,56 @@ def ehem_phase1_packed(model, ctx, pos, plan, table=None):
 
 
 @torch.no_grad()
-def ehem_phase2_packed(model, st, plan, pre_occ=None, table=None):
+def ehem_phase2_prepare(model, st, plan):
+    """The part of phase 2 that does NOT depend on the even nodes' occupancies (ehem.py:117-127): pre_attn_mlp(a1) and the query stream of the
+    cross transformer - LayerNorm + query projection of every block, patch merging of the queries between the stages.  The decoder runs it on
+    a side stream while the host range-decodes the even symbols (the GPU is idle then); same kernels on the same rows as inside
+    ehem_phase2_packed, so the bits are the same.  -> dict(pre = [Q0, 16 + 240] with the pre_attn columns filled, q[s][b] = query projections,
+    rows[s] = rows of cross stage s)."""
+    d = plan.d
+    a1, a2 = st["a1"], st["a2"]
+    no = model.pre_occ_mlp[4].weight.shape[0]
+    pre = torch.empty((a2.shape[0], no + model.pre_attn_mlp[4].weight.shape[0]), dtype=torch.float32, device=a2.device)
+    leaky_mlp3_s(model.pre_attn_mlp, a1, out=pre[:, no:])
+    enc = model.swin_cross_transformer
+    qs, query = [], a2
+    for s, stage in enumerate(enc.layers):
+        v1 = d["cross_valid"][s].reshape(-1)
+        row = []
+        for blk in stage.blocks:
+            w, _, qbias, eps_b, _ = _block_consts(blk, True)
+            row.append(native.swin_ln_linear(query, w["q"], qbias, eps_b, v1))
+        qs.append(row)
+        if s < len(enc.layers) - 1:
+            query = _merge(stage.downsample, query, d["cross_merge"][s])
+    return dict(pre=pre, q=qs)
+
+
+def phase2_prep_window(prep, bases, rows):
+    """The rows of ONE window inside a level-wide ehem_phase2_prepare result: bases[s] / rows[s] = first row / padded row count of the window in
+    cross stage s (a one-window plan has exactly these rows)."""
+    return dict(pre=prep["pre"][bases[0]:bases[0] + rows[0]], q=[[q[bases[s]:bases[s] + rows[s]] for q in qs] for s, qs in enumerate(prep["q"])])
+
+
+@torch.no_grad()
+def ehem_phase2_packed(model, st, plan, pre_occ=None, table=None, prep=None):
     """Odd-node logits given the occupancies of the even nodes (ehem.py:117-127).  pre_occ: int64 [Q0 rows] in the cross
-    layout (None = the true occupancies taken from ctx, as the encoder does)."""
+    layout (None = the true occupancies taken from ctx, as the encoder does).  prep: the result of ehem_phase2_prepare for these rows."""
     d = plan.d
     g = model.geo_feat_generator
     a1, a2 = st["a1"], st["a2"]
     po = st["pre_occ"] if pre_occ is None else pre_occ
     occ_feat = leaky_mlp3(model.pre_occ_mlp, F.embedding(po, g.occ_enc.weight))
     no = occ_feat.shape[1]
-    pre = torch.empty((a2.shape[0], no + model.pre_attn_mlp[4].weight.shape[0]), dtype=torch.float32, device=a2.device)
-    pre[:, :no] = occ_feat
-    leaky_mlp3_s(model.pre_attn_mlp, a1, out=pre[:, no:])
-    hc = _encoder(model.swin_cross_transformer, pre, d["cross_valid"], d["cross_tab"], d["cross_merge"], query=a2, tiles=d.get("cross_tiles"))
+    if prep is not None:
+        pre = prep["pre"]
+        pre[:, :no] = occ_feat
+    else:
+        pre = torch.empty((a2.shape[0], no + model.pre_attn_mlp[4].weight.shape[0]), dtype=torch.float32, device=a2.device)
+        pre[:, :no] = occ_feat
+        leaky_mlp3_s(model.pre_attn_mlp, a1, out=pre[:, no:])
+    hc = _encoder(model.swin_cross_transformer, pre, d["cross_valid"], d["cross_tab"], d["cross_merge"], query=a2, tiles=d.get("cross_tiles"),
+                  q_pre=None if prep is None else prep["q"])
     if table is not None:
         a = _concat_layer(model.prob_pred_mlp2[0], hc, d["cross_parent"], a2) if HIER else linear_s(_concat(hc, d["cross_concat"], extra=(a2, None)), model.prob_pred_mlp2[0].weight, model.prob_pred_mlp2[0].bias, act="leaky", want="split")
         from ..ops import _split
