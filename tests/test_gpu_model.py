@@ -1662,3 +1662,41 @@ def test_octattn_attention_takes_column_slices_of_one_projection(dev):
     a, au = native.octattn_attention(q_u, key[0], key[1], val[0], val[1], 4)
     b, bu = native.octattn_attention(q_u, key[0].contiguous(), key[1].contiguous(), val[0].contiguous(), val[1].contiguous(), 4)
     assert torch.equal(a, b) and torch.equal(au, bu)
+
+
+@pytest.mark.gpu
+def test_phase2_prepared_ahead_has_the_bits_of_the_plain_phase2(dev, ehem):
+    """Round 5 (decoder): pre_attn_mlp(a1) and the cross transformer's query stream do not depend on the decoded even symbols -
+    ehem_phase2_prepare computes them for a whole level in one packed pass (on a side stream in the decoder) and phase 2 takes a window's rows
+    of the result.  Same kernels on the same rows: the odd-node logits are bit-identical to the plain phase 2, level-wide and per window."""
+    from scp_amd.models.packed import PackedPlan, ehem_phase1_packed, ehem_phase2_packed, ehem_phase2_prepare, phase2_prep_window
+    from scp_amd import native
+    g = torch.Generator().manual_seed(3)
+    lengths = [2049, 700, 1, 1300]
+    T = sum(lengths)
+    ctx = torch.randint(0, 9, (T, 12), generator=g).to(torch.uint8)
+    ctx[:, 2::3] = torch.randint(0, 255, (T, 4), generator=g).to(torch.uint8)
+    ctx[:, 0::3] = 7
+    ctx, pos = ctx.to(dev), torch.rand((T, 3), generator=g).to(dev)
+    plan = PackedPlan(lengths, device=dev)
+    _, st = ehem_phase1_packed(ehem, ctx, pos, plan)
+    want = ehem_phase2_packed(ehem, st, plan)
+    prep = ehem_phase2_prepare(ehem, st, plan)
+    got = ehem_phase2_packed(ehem, st, plan, prep=prep)
+    assert torch.equal(got, want)
+    # one window at a time on its rows of the level-wide state and of the level-wide preparation (what FrameDecoder._decode_level does)
+    nst = len(ehem.swin_cross_transformer.layers)
+    bases, q0, o0 = [0] * nst, 0, 0
+    for c in lengths:
+        rows, L = [], (c + (c & 1)) // 2
+        for _ in range(nst):
+            rows.append(-(-L // 512) * 512)
+            L = (L + 1) // 2
+        if c > 1:
+            pw = PackedPlan([c], device=dev)
+            stw = dict(a1=native.SplitAct(st["a1"].t[:, q0:q0 + rows[0]], st["a1"].K), a2=st["a2"][q0:q0 + rows[0]], pre_occ=st["pre_occ"][q0:q0 + rows[0]])
+            one = ehem_phase2_packed(ehem, stw, pw, prep=phase2_prep_window(prep, bases, rows))
+            assert torch.equal(one, want[o0:o0 + c // 2])
+        q0 += rows[0]
+        o0 += c // 2
+        bases = [b + r for b, r in zip(bases, rows)]
