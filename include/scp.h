@@ -41,7 +41,8 @@ extern "C" {
  *        scp_linear_split calls give its bits); scp_geom_build takes float xyz through scp_geom_build_xyz as well (stage G in one
  *        launch sequence); scp_debug.h gained the launch brackets scp_prof_*.
  *   220  GELU (round 5, numeric profile ehem/5): max(y, 0) - |y| exp(-beta y^2) / P4(|y|) instead of the degree-12 erf polynomial, in every
- *        kernel that applies it; scp_swin_post_attn expects fc1 scaled by scp_gelu_prescale() and fc2 by its inverse. */
+ *        kernel that applies it; scp_swin_post_attn expects fc1 scaled by scp_gelu_prescale() and fc2 by its inverse.
+ *        (additive, no new version: scp_decode_expand.) */
 #define SCP_ABI_VERSION 220
 SCP_API int scp_version(void);
 SCP_API int scp_last_hip_error(void);
@@ -413,6 +414,18 @@ SCP_API int scp_embed_gather(const uint8_t *ctx, const float *pos, const int64_t
  * tables_dev: int64 scratch of 36 * W entries. */
 SCP_API int scp_packed_plan_sizes(const int64_t *lengths, int32_t W, int64_t *rows_out);
 SCP_API int scp_packed_plan(const int64_t *lengths, int32_t W, int64_t *tables_dev, void *const *outs, int32_t n_outs, void *stream);
+
+/* ---- decoder: the children of one decoded octree level + the model inputs of the level they form, one launch ------------------
+ * replaces: decode_ehem_mullevel.py:100-130 (decode_ehem.py likewise): child occupancy bits -> (parent, digit) pairs in breadth-first
+ * order, the ancestor window shifted by one, cal_pos_ary (:41-53), the next level's context rows and normalised positions.
+ *   sym i64[n]: decoded symbols of the parents (occupancy - 1; -1 = unknown: no children); cum i64[n]: INCLUSIVE scan of popcount(sym + 1);
+ *   pos i32[n][3] node origins; anc u8[n][9] = (level, octant, symbol) of (ggp, gp, p), 255 = pad; octant u8[n]; L = the parents' level;
+ *   shift = depth - L.  Outputs for the m = cum[n - 1] children: cpos i32[m][3], canc u8[m][9], coct u8[m], cctx u8[m][12] (ancestor
+ *   levels clamped to lv_clamp, own entry (lv_next, octant, 255)), cposn f32[m][3] = polar ? (pos - mn) / den : pos / den (double
+ *   arithmetic, rounded once), occ8 u8[n] = the parents' occupancy codes. */
+SCP_API int scp_decode_expand(const int64_t *sym, const int64_t *cum, const int32_t *pos, const uint8_t *anc, const uint8_t *octant, int64_t n,
+                              int32_t L, int32_t shift, int32_t lv_next, int32_t lv_clamp, int32_t polar, double mn, double den, int32_t *cpos,
+                              uint8_t *canc, uint8_t *coct, uint8_t *cctx, float *cposn, uint8_t *occ8, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Swin blocks on the row-chain kernels (csrc/rowchain.hip): a workgroup keeps 128 token rows in registers as the B operand of

@@ -191,3 +191,74 @@ extern "C" SCP_API int scp_packed_plan(const int64_t *lengths, int32_t W, int64_
     LAUNCH_CHECK();
     return SCP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Decoder: the children of one decoded octree level (decode_ehem_mullevel.py:100-130 / decode_ehem.py: the breadth-first
+// regeneration - children in (parent order, child digit) order, the ancestor window shifted by one, cal_pos_ary) AND the
+// model inputs of the level they form (context rows (level, octant, occupancy) x (ggp, gp, p, self) as uint8, positions
+// normalised with the level's (min, max) pair in double precision), in ONE launch.  Until round 5 this was ~25 torch index
+// launches per level behind the last window's symbols, with the GPU idle.
+//   sym[i]   decoded symbol of parent i (occupancy - 1; -1 = the multi-level shell's dropped last node: no children)
+//   cum[i]   inclusive scan of popcount(sym + 1)
+//   anc      uint8 [n][9]: (level, octant, symbol) of (ggp, gp, p) of every parent, 255 = unknown symbol / pad
+//   child c of parent i: pos = pos_i + digit bits << shift; anc = (anc_i[3:9], (L, octant_i, sym_i)); octant = digit + 1
+//   ctx row = (anc with levels clamped to lv_clamp, (lv_next, octant, 255)); posn = polar ? (pos - mn) / (mx - mn + eps) : pos / div
+struct ExpandArgs {
+    const int64_t *sym, *cum;
+    const int32_t *pos;
+    const uint8_t *anc, *octant;
+    int64_t n;
+    int32_t L, shift, lv_next, lv_clamp, polar;
+    double mn, den;
+    int32_t *cpos;
+    uint8_t *canc, *coct, *cctx, *occ8;
+    float *cposn;
+};
+
+__global__ __launch_bounds__(256) void decode_expand_kernel(const ExpandArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const int64_t s = a.sym[i];
+    const unsigned occ = (unsigned)((s + 1) & 0xff);
+    a.occ8[i] = (uint8_t)occ;
+    if (!occ) return;
+    int64_t c = a.cum[i] - __popc(occ);
+    const int px = a.pos[3 * i], py = a.pos[3 * i + 1], pz = a.pos[3 * i + 2];
+    uint8_t an[9];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) an[j] = a.anc[9 * i + 3 + j];
+    an[6] = (uint8_t)a.L; an[7] = a.octant[i]; an[8] = (uint8_t)s;
+    for (int d = 0; d < 8; ++d) {
+        if (!((occ >> d) & 1)) continue;
+        const int x = px + (((d >> 2) & 1) << a.shift), y = py + (((d >> 1) & 1) << a.shift), z = pz + ((d & 1) << a.shift);
+        a.cpos[3 * c] = x; a.cpos[3 * c + 1] = y; a.cpos[3 * c + 2] = z;
+        a.coct[c] = (uint8_t)(d + 1);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            a.canc[9 * c + j] = an[j];
+            a.cctx[12 * c + j] = (j % 3 == 0 && an[j] > a.lv_clamp) ? (uint8_t)a.lv_clamp : an[j];
+        }
+        a.cctx[12 * c + 9] = (uint8_t)a.lv_next; a.cctx[12 * c + 10] = (uint8_t)(d + 1); a.cctx[12 * c + 11] = 255;
+        if (a.polar) {
+            a.cposn[3 * c] = (float)(((double)x - a.mn) / a.den); a.cposn[3 * c + 1] = (float)(((double)y - a.mn) / a.den);
+            a.cposn[3 * c + 2] = (float)(((double)z - a.mn) / a.den);
+        } else {
+            a.cposn[3 * c] = (float)((double)x / a.den); a.cposn[3 * c + 1] = (float)((double)y / a.den); a.cposn[3 * c + 2] = (float)((double)z / a.den);
+        }
+        ++c;
+    }
+}
+
+extern "C" SCP_API int scp_decode_expand(const int64_t *sym, const int64_t *cum, const int32_t *pos, const uint8_t *anc, const uint8_t *octant, int64_t n,
+                                         int32_t L, int32_t shift, int32_t lv_next, int32_t lv_clamp, int32_t polar, double mn, double den, int32_t *cpos,
+                                         uint8_t *canc, uint8_t *coct, uint8_t *cctx, float *cposn, uint8_t *occ8, void *stream) {
+    if (!sym || !cum || !pos || !anc || !octant || !cpos || !canc || !coct || !cctx || !cposn || !occ8 || n <= 0 || L < 1 || L > 254 || shift < 0 ||
+        shift > 30 || lv_next < 0 || lv_next > 255 || lv_clamp < 0 || lv_clamp > 255 || !(den == den) || den == 0.0)
+        return SCP_EINVAL;
+    ExpandArgs a;
+    a.sym = sym; a.cum = cum; a.pos = pos; a.anc = anc; a.octant = octant; a.n = n; a.L = L; a.shift = shift; a.lv_next = lv_next;
+    a.lv_clamp = lv_clamp; a.polar = polar; a.mn = mn; a.den = den; a.cpos = cpos; a.canc = canc; a.coct = coct; a.cctx = cctx; a.cposn = cposn; a.occ8 = occ8;
+    hipLaunchKernelGGL(decode_expand_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}

@@ -283,47 +283,48 @@ class FrameDecoder:
         return sym
 
     def _decode_tree(self, dec, depth, pos_mm):
-        """One octree: returns (codes per level as device uint8 tensors, leaf integer coordinates [U,3])."""
+        """One octree: returns (codes per level as device uint8 tensors, leaf integer coordinates [U,3]).
+        Level state: pos int32 [n,3] node origins, anc uint8 [n,9] = (level, octant, symbol) of (ggp, gp, p) with pad = (0, 0, 255), octant uint8 [n];
+        the children of a decoded level and the model inputs of the level they form come from one launch (native.decode_expand)."""
         dev = self.device
-        # level 1: the root. columns of `anc`: (level, octant, occ) of (ggp, gp, p); pad = (0, 0, 255)
-        anc = torch.tensor([[0, 0, 255] * 3], dtype=torch.int64, device=dev)
-        octant = torch.ones(1, dtype=torch.int64, device=dev)
-        pos = torch.zeros((1, 3), dtype=torch.int64, device=dev)
-        codes = []
-        for L in range(1, depth + 1):
-            n = pos.shape[0]
+        anc = torch.tensor([[0, 0, 255] * 3], dtype=torch.uint8, device=dev)
+        octant = torch.ones(1, dtype=torch.uint8, device=dev)
+        pos = torch.zeros((1, 3), dtype=torch.int32, device=dev)
+
+        def level_params(L):
+            """(lv, ancestor level clamp, mn, den) of level L's inputs."""
             last = L == depth
             lv = min(L, self.lidar_level) if last else L                      # encode_dataset_ehem.py:86 clips the last chunk
-            a = anc.clone()
-            if last:
-                a[:, 0::3] = torch.clamp(a[:, 0::3], max=self.lidar_level)
-            own = torch.stack((torch.full((n,), lv, dtype=torch.int64, device=dev), octant,
-                               torch.full((n,), 255, dtype=torch.int64, device=dev)), 1)
-            ctx = torch.cat((a, own), 1).to(torch.uint8)
             if self.polar:
                 mn, mx = float(pos_mm[L - 1][0]), float(pos_mm[L - 1][1])
                 eps = 0.0 if (self.mullevel and last) else 1e-9
-                posn = ((pos.double() - mn) / (mx - mn + eps)).float()
-            else:
-                posn = (pos.double() / float(2 ** depth)).float()
+                return lv, (self.lidar_level if last else 255), mn, mx - mn + eps
+            return lv, (self.lidar_level if last else 255), 0.0, float(2 ** depth)
+
+        # level 1: the root
+        lv, clamp, mn, den = level_params(1)
+        ctx = torch.tensor([[0, 0, 255] * 3 + [lv, 1, 255]], dtype=torch.uint8, device=dev)
+        posn = ((pos.double() - mn) / den).float() if self.polar else (pos.double() / den).float()
+        codes = []
+        t = self._t0()
+        for L in range(1, depth + 1):
+            n = pos.shape[0]
+            last = L == depth
             rows = n - (1 if (self.mullevel and last) else 0)                  # the dropped last node is never coded
             sym = torch.full((n,), -1, dtype=torch.int64, device=dev)
-            t = self._stamp("tree_expansion", t) if L > 1 else self._t0()
+            t = self._stamp("tree_expansion", t)
             if rows > 0:
-                sym[:rows] = self._decode_level(dec, ctx[:rows].contiguous(), posn[:rows].contiguous())
+                sym[:rows] = self._decode_level(dec, ctx[:rows], posn[:rows])
             t = self._t0()
-            occ = sym + 1                                                       # 1..255; 0 = unknown (dropped node)
-            codes.append(occ.to(torch.uint8))
-            # children in (parent, digit) order
-            bits = ((occ[:, None] >> torch.arange(8, device=dev)[None]) & 1).bool()
-            par, dig = torch.nonzero(bits, as_tuple=True)
-            sh = depth - L
-            cpos = pos[par] + torch.stack((((dig >> 2) & 1) << sh, ((dig >> 1) & 1) << sh, (dig & 1) << sh), 1)
+            # children in (parent, digit) order; occupancy 1..255, 0 = unknown (dropped node)
             if last:
-                return codes, cpos
-            anc = torch.cat((anc[par][:, 3:], torch.stack((torch.full_like(par, L), octant[par], sym[par]), 1)), 1)
-            octant = dig + 1
-            pos = cpos
+                lvn, clamp, mn, den = 0, 255, 0.0, 1.0
+            else:
+                lvn, clamp, mn, den = level_params(L + 1)
+            occ8, pos, anc, octant, ctx, posn = native.decode_expand(sym, pos, anc, octant, L, depth - L, lvn, clamp, self.polar and not last, mn, den)
+            codes.append(occ8)
+            if last:
+                return codes, pos.long()
 
     def decode(self, stream, n_levels, pos_mm):
         """stream: bytes; n_levels: total level count from the file name; pos_mm: [n_levels,2] array from the .dat file.

@@ -353,8 +353,8 @@ def ehem_phase2_prepare(model, st, plan):
     """The part of phase 2 that does NOT depend on the even nodes' occupancies (ehem.py:117-127): pre_attn_mlp(a1) and the query stream of the
     cross transformer - LayerNorm + query projection of every block, patch merging of the queries between the stages.  The decoder runs it on
     a side stream while the host range-decodes the even symbols (the GPU is idle then); same kernels on the same rows as inside
-    ehem_phase2_packed, so the bits are the same.  -> dict(pre = [Q0, 16 + 240] with the pre_attn columns filled, q[s][b] = query projections,
-    rows[s] = rows of cross stage s)."""
+    ehem_phase2_packed, so the bits are the same.  -> dict(pre = [Q0, 16 + 240] with the pre_attn columns filled, q[s][b] = query projections).
+    A preparation (or a window's rows of it) is CONSUMED by the phase 2 that takes it: the cross blocks run in place on `pre`."""
     d = plan.d
     a1, a2 = st["a1"], st["a2"]
     no = model.pre_occ_mlp[4].weight.shape[0]

@@ -109,6 +109,7 @@ def lib():
         "scp_embed_gather": (C.c_int, [_vp, _vp, _vp, i64, _vp, _vp, _vp, _vp, _vp, _vp, i64, _vp]),
         "scp_packed_plan_sizes": (C.c_int, [_vp, i32, _vp]),
         "scp_packed_plan": (C.c_int, [_vp, i32, _vp, _vp, i32, _vp]),
+        "scp_decode_expand": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i64, i32, i32, i32, i32, i32, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
         "scp_edge_gather_max": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, i32, _vp]),
         "scp_swin_attention": (C.c_int, [_vp, _vp, _vp, _vp, i32, i32, i32, i32, i32, _vp, _vp]),
         "scp_octattn_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i32, i32, i32, i32, _vp, _vp, _vp]),
@@ -466,6 +467,31 @@ def embed_gather(ctx, pos, inmap, occ_enc, level_enc, octant_enc):
                                   _dev(level_enc), _dev(octant_enc), x.data_ptr(), p.data_ptr(), o.data_ptr(), rows, _stream()),
            "scp_embed_gather")
     return x, p, o
+
+
+_POPC = {}
+
+
+def decode_expand(sym, pos, anc, octant, L, shift, lv_next, lv_clamp, polar, mn, den):
+    """Decoder: children of one decoded level + the next level's model inputs, one launch (csrc/plan.hip: scp_decode_expand).
+    sym int64 [n] (-1 = unknown), pos int32 [n,3], anc uint8 [n,9], octant uint8 [n] ->
+    (occ8 uint8 [n], cpos int32 [m,3], canc uint8 [m,9], coct uint8 [m], cctx uint8 [m,12], cposn float32 [m,3]); one host sync (m)."""
+    dev, n = sym.device, sym.shape[0]
+    tab = _POPC.get(dev)
+    if tab is None:
+        tab = _POPC[dev] = torch.tensor([bin(v).count("1") for v in range(256)], dtype=torch.int64, device=dev)
+    cum = torch.cumsum(tab[sym + 1], 0)
+    m = int(cum[-1])
+    occ8 = torch.empty(n, dtype=torch.uint8, device=dev)
+    cpos = torch.empty((m, 3), dtype=torch.int32, device=dev)
+    canc = torch.empty((m, 9), dtype=torch.uint8, device=dev)
+    coct = torch.empty(m, dtype=torch.uint8, device=dev)
+    cctx = torch.empty((m, 12), dtype=torch.uint8, device=dev)
+    cposn = torch.empty((m, 3), dtype=torch.float32, device=dev)
+    _check(lib().scp_decode_expand(_dev(sym, torch.int64), cum.data_ptr(), _dev(pos, torch.int32), _dev(anc, torch.uint8), _dev(octant, torch.uint8), n,
+                                   int(L), int(shift), int(lv_next), int(lv_clamp), 1 if polar else 0, float(mn), float(den), cpos.data_ptr(), canc.data_ptr(),
+                                   coct.data_ptr(), cctx.data_ptr(), cposn.data_ptr(), occ8.data_ptr(), _stream()), "scp_decode_expand")
+    return occ8, cpos, canc, coct, cctx, cposn
 
 
 def packed_plan(lengths, device):

@@ -1684,7 +1684,9 @@ def test_phase2_prepared_ahead_has_the_bits_of_the_plain_phase2(dev, ehem):
     prep = ehem_phase2_prepare(ehem, st, plan)
     got = ehem_phase2_packed(ehem, st, plan, prep=prep)
     assert torch.equal(got, want)
-    # one window at a time on its rows of the level-wide state and of the level-wide preparation (what FrameDecoder._decode_level does)
+    # one window at a time on its rows of the level-wide state and of the level-wide preparation (what FrameDecoder._decode_level does);
+    # a preparation is consumed by the phase 2 that takes it (the blocks run in place on `pre`): a fresh one
+    prep = ehem_phase2_prepare(ehem, st, plan)
     nst = len(ehem.swin_cross_transformer.layers)
     bases, q0, o0 = [0] * nst, 0, 0
     for c in lengths:
@@ -1700,3 +1702,44 @@ def test_phase2_prepared_ahead_has_the_bits_of_the_plain_phase2(dev, ehem):
         q0 += rows[0]
         o0 += c // 2
         bases = [b + r for b, r in zip(bases, rows)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("polar,last", [(True, False), (True, True), (False, False)])
+def test_decode_expand_kernel_equals_the_torch_construction(dev, polar, last):
+    """scp_decode_expand (the decoder's breadth-first regeneration, decode_ehem_mullevel.py:100-130, in one launch) against the torch index
+    construction it replaced: children in (parent, digit) order, shifted ancestor windows, origins, and the next level's context rows and
+    double-precision normalised positions - bit for bit."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(5)
+    n, L, depth, lidar = 3000, 9, 13, 12
+    sym = torch.randint(0, 255, (n,), generator=g)
+    sym[-1] = -1                                                      # the dropped last node of a multi-level shell: no children
+    pos = torch.randint(0, 2 ** 12, (n, 3), generator=g) << (depth - L + 1)
+    anc = torch.randint(0, 255, (n, 9), generator=g)
+    anc[:, 0::3] = torch.tensor([L - 3, L - 2, L - 1])
+    octant = torch.randint(1, 9, (n,), generator=g)
+    mn, mx = -3.0, 8191.5
+    eps = 0.0 if last else 1e-9
+    lvn = min(L + 1, lidar) if last else L + 1
+    clamp = lidar if last else 255
+    den = (mx - mn + eps) if polar else float(2 ** depth)
+    # the torch construction (FrameDecoder._decode_tree until round 5)
+    occ = sym + 1
+    bits = ((occ[:, None] >> torch.arange(8)[None]) & 1).bool()
+    par, dig = torch.nonzero(bits, as_tuple=True)
+    sh = depth - L
+    cpos = pos[par] + torch.stack((((dig >> 2) & 1) << sh, ((dig >> 1) & 1) << sh, (dig & 1) << sh), 1)
+    canc = torch.cat((anc[par][:, 3:], torch.stack((torch.full_like(par, L), octant[par], sym[par]), 1)), 1)
+    coct = dig + 1
+    a = canc.clone()
+    a[:, 0::3] = torch.clamp(a[:, 0::3], max=clamp)
+    own = torch.stack((torch.full_like(par, lvn), coct, torch.full_like(par, 255)), 1)
+    cctx = torch.cat((a, own), 1).to(torch.uint8)
+    cposn = (((cpos.double() - mn) / den) if polar else (cpos.double() / den)).float()
+    got = native.decode_expand(sym.to(dev), pos.to(torch.int32).to(dev), anc.to(torch.uint8).to(dev), octant.to(torch.uint8).to(dev), L, sh, lvn, clamp,
+                               polar, mn if polar else 0.0, den)
+    occ8, gpos, ganc, goct, gctx, gposn = [x.cpu() for x in got]
+    assert torch.equal(occ8, occ.to(torch.uint8)) and torch.equal(gpos.long(), cpos) and torch.equal(ganc, canc.to(torch.uint8))
+    assert torch.equal(goct, coct.to(torch.uint8)) and torch.equal(gctx, cctx)
+    assert torch.equal(gposn.view(torch.int32), cposn.view(torch.int32))
