@@ -131,6 +131,7 @@ class FrameDecoder:
         self.stats = None             # set to {} to collect wall seconds per stage (adds a device synchronisation per stamp: bench.py --decode)
         self._plans = {}              # one-window plans by window length (index maps depend on the length only): built once, reused
         self._pin = [None, None]      # pinned staging of the CDF rows (grown on demand)
+        self._pin_po = None           # pinned staging of a window's even symbols on their way up
         self._side = None             # side stream of ehem_phase2_prepare (created on first use, on the decoding thread's device)
         self.prepare_ahead = os.environ.get("SCP_DEC_PREP", "1") != "0"       # A/B switch: 0 = everything of phase 2 after the even symbols
 
@@ -191,8 +192,21 @@ class FrameDecoder:
             done.record(self._side)
         return prep, done
 
-    def _decode_window(self, dec, ctx, pos):
-        """ctx uint8 [c,12] (own occupancy = 255 placeholder), pos f32 [c,3] -> int64 symbols [c] (device).
+    def _even_to_device(self, even, qp):
+        """The decoded even symbols of a window (int16 numpy [ne]) -> int64 device tensor [qp] in the cross layout (zeros behind the real rows):
+        one asynchronous copy out of a pinned buffer.  (The buffer's previous contents were consumed: a window's phase-2 rows are read back,
+        with a synchronisation, before the next window gets here.)"""
+        if self._pin_po is None or self._pin_po.numel() < qp:
+            self._pin_po = torch.empty(max(qp, 8192), dtype=torch.int64, pin_memory=True)
+        h = self._pin_po[:qp].numpy()
+        h[:even.shape[0]] = even
+        h[even.shape[0]:] = 0
+        po = torch.empty(qp, dtype=torch.int64, device=self.device)
+        po.copy_(self._pin_po[:qp], non_blocking=True)
+        return po
+
+    def _decode_window(self, dec, ctx, pos, sym):
+        """ctx uint8 [c,12] (own occupancy = 255 placeholder), pos f32 [c,3]; the symbols go to sym[:c] (host int64).
         Runs the SAME packed kernels as the encoder (a one-window plan): encoder and decoder must produce bit-identical
         integer CDFs, and every kernel on the path is deterministic per row / per window, independent of the batch."""
         from .models.packed import PackedPlan, ehem_phase1_packed, ehem_phase2_packed
@@ -204,14 +218,11 @@ class FrameDecoder:
         cdf_dev = native.softmax_cdf(prob1.contiguous(), want_lohi=False, want_cdf=True)["cdf"]
         cdf, prep = self._cdf_to_host(cdf_dev, (lambda: self._prepare(st, plan)) if (c > 1 and self.prepare_ahead) else None)
         t = self._stamp("cdf_d2h", t)
-        even = torch.from_numpy(dec.run(cdf).astype(np.int64)).to(self.device)
+        even = dec.run(cdf)
         t = self._stamp("range_decoder", t)
-        sym = torch.empty(c, dtype=torch.int64, device=self.device)
-        sym[0::2] = even
+        sym[0:c:2] = even
         if c > 1:
-            Q0 = plan.d["a1map"].shape[0]
-            po = torch.zeros(Q0, dtype=torch.int64, device=self.device)
-            po[:even.shape[0]] = even                       # one window: its real rows are the first rows of the cross layout
+            po = self._even_to_device(even, plan.d["a1map"].shape[0])   # one window: its real rows are the first rows of the cross layout
             t = self._stamp("index_ops", t)
             if prep is not None:
                 torch.cuda.current_stream(self.device).wait_event(prep[1])
@@ -219,22 +230,25 @@ class FrameDecoder:
             t = self._stamp("phase2_model", t)
             cdf, _ = self._cdf_to_host(native.softmax_cdf(prob2.contiguous(), want_lohi=False, want_cdf=True)["cdf"], slot=1)
             t = self._stamp("cdf_d2h", t)
-            sym[1::2] = torch.from_numpy(dec.run(cdf).astype(np.int64)).to(self.device)
+            sym[1:c:2] = dec.run(cdf)
             t = self._stamp("range_decoder", t)
-        return sym
 
-    def _decode_level(self, dec, ctx, pos):
-        """All windows of one level.  The even-node logits of a window depend on ancestors only (ehem.py:92-115), so phase 1 runs
+    def _decode_level(self, dec, ctx, pos, n_total):
+        """All windows of one level -> int64 device tensor [n_total]: the symbols of the ctx.shape[0] coded nodes, -1 behind them (the dropped last
+        node of a multi-level shell).  The even-node logits of a window depend on ancestors only (ehem.py:92-115), so phase 1 runs
         ONCE for the whole level as a packed forward - bit-identical to one-window launches (every kernel is per-row / per-window
         deterministic: tests/test_gpu_e2e.py::test_full_frame_packed_forward_is_batch_invariant) and 10 - 50 x better at filling the
         GPU; phase 2 needs the window's decoded even symbols and the bitstream interleaves the windows (evens, odds, evens, ...),
-        so it runs window by window on that window's slice of the phase-1 state (a one-window plan has exactly that layout)."""
+        so it runs window by window on that window's slice of the phase-1 state (a one-window plan has exactly that layout).
+        The decoded symbols stay on the host until the level is complete (one copy); a window sends only its even symbols up."""
         from .models.packed import PackedPlan, ehem_phase1_packed, ehem_phase2_packed, phase2_prep_window
         cs = self.context_size
         n = ctx.shape[0]
+        sym = np.full(n_total, -1, np.int64)
         lengths = [min(cs, n - i) for i in range(0, n, cs)]
         if len(lengths) == 1:
-            return self._decode_window(dec, ctx, pos)
+            self._decode_window(dec, ctx, pos, sym)
+            return torch.from_numpy(sym).to(self.device)
         t = self._t0()
         plan = PackedPlan(lengths, device=self.device)
         prob1, st = ehem_phase1_packed(self.model, ctx, pos, plan)
@@ -243,7 +257,6 @@ class FrameDecoder:
         # the level's query stream + pre_attn_mlp: one packed pass over all windows, launched while the CDF rows travel
         cdf1, prep = self._cdf_to_host(cdf1_dev, (lambda: self._prepare(st, plan)) if self.prepare_ahead else None)
         t = self._stamp("cdf_d2h", t)
-        sym = torch.empty(n, dtype=torch.int64, device=self.device)
         row0 = e0 = q0 = 0
         nst = len(self.model.swin_cross_transformer.layers)
         bases = [0] * nst                                                       # first row of the current window in every cross stage
@@ -254,15 +267,14 @@ class FrameDecoder:
             for _ in range(nst):
                 rows.append(-(-L // 512) * 512)
                 L = (L + 1) // 2
-            even = torch.from_numpy(dec.run(cdf1[e0:e0 + ne]).astype(np.int64)).to(self.device)
+            even = dec.run(cdf1[e0:e0 + ne])
             t = self._stamp("range_decoder", t)
             sym[row0:row0 + c:2] = even
             if c > 1:
                 pw = self._plan1(c)
                 stw = dict(a1=native.SplitAct(st["a1"].t[:, q0:q0 + qp], st["a1"].K), a2=st["a2"][q0:q0 + qp],
                            pre_occ=st["pre_occ"][q0:q0 + qp])
-                po = torch.zeros(qp, dtype=torch.int64, device=self.device)
-                po[:ne] = even
+                po = self._even_to_device(even, qp)
                 t = self._stamp("index_ops", t)
                 pwin = None
                 if prep is not None:
@@ -274,13 +286,13 @@ class FrameDecoder:
                 t = self._stamp("phase2_model", t)
                 cdf, _ = self._cdf_to_host(native.softmax_cdf(prob2.contiguous(), want_lohi=False, want_cdf=True)["cdf"], slot=1)
                 t = self._stamp("cdf_d2h", t)
-                sym[row0 + 1:row0 + c:2] = torch.from_numpy(dec.run(cdf).astype(np.int64)).to(self.device)
+                sym[row0 + 1:row0 + c:2] = dec.run(cdf)
                 t = self._stamp("range_decoder", t)
             row0 += c
             e0 += ne
             q0 += qp
             bases = [b + r for b, r in zip(bases, rows)]
-        return sym
+        return torch.from_numpy(sym).to(self.device)
 
     def _decode_tree(self, dec, depth, pos_mm):
         """One octree: returns (codes per level as device uint8 tensors, leaf integer coordinates [U,3]).
@@ -311,10 +323,8 @@ class FrameDecoder:
             n = pos.shape[0]
             last = L == depth
             rows = n - (1 if (self.mullevel and last) else 0)                  # the dropped last node is never coded
-            sym = torch.full((n,), -1, dtype=torch.int64, device=dev)
             t = self._stamp("tree_expansion", t)
-            if rows > 0:
-                sym[:rows] = self._decode_level(dec, ctx[:rows], posn[:rows])
+            sym = self._decode_level(dec, ctx[:rows], posn[:rows], n) if rows > 0 else torch.full((n,), -1, dtype=torch.int64, device=dev)
             t = self._t0()
             # children in (parent, digit) order; occupancy 1..255, 0 = unknown (dropped node)
             if last:
