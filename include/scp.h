@@ -42,7 +42,7 @@ extern "C" {
  *        launch sequence); scp_debug.h gained the launch brackets scp_prof_*.
  *   220  GELU (round 5, numeric profile ehem/5): max(y, 0) - |y| exp(-beta y^2) / P4(|y|) instead of the degree-12 erf polynomial, in every
  *        kernel that applies it; scp_swin_post_attn expects fc1 scaled by scp_gelu_prescale() and fc2 by its inverse.
- *        (additive, no new version: scp_decode_expand.) */
+ *        (additive, no new version: scp_decode_expand, scp_linear_split_f16_max, scp_row_scale_from_max, scp_octattn_attention_f16x3_vmax.) */
 #define SCP_ABI_VERSION 220
 SCP_API int scp_version(void);
 SCP_API int scp_last_hip_error(void);
@@ -264,6 +264,16 @@ SCP_API int scp_layernorm_add_split_f16(const float *a, const float *b, int64_t 
 SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, int64_t lda, const float *a_inv_scale, const void *Whi, const void *Wlo,
                                  const float *w_inv_scale, int32_t Npad, int32_t Kpad, const float *bias, const float *residual, int64_t ldr,
                                  float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream);
+/* scp_linear_split_f16 that also takes maxima of its OUTPUT in the epilogue (round 5; atomicMax on the bit patterns of |C|, the caller zeroes the
+ * words before the call): row_max[M] = max |C[m][:]| (may be NULL), col_max (one word, may be NULL) = max |C[m][n]| over m < col_rows,
+ * col_lo <= n < col_hi.  The power-of-two scales of the next f16x3 layer come from them without a pass over C: scp_row_scale_from_max gives what
+ * scp_row_scale_f16 gives on C (attention_model.py:97-125: linear1 -> ReLU -> linear2), scp_octattn_attention_f16x3_vmax takes col_max of the
+ * key | value projection for max |v|.  C is the same, bit for bit. */
+SCP_API int scp_linear_split_f16_max(const void *Ahi, const void *Alo, int64_t lda, const float *a_inv_scale, const void *Whi, const void *Wlo,
+                                     const float *w_inv_scale, int32_t Npad, int32_t Kpad, const float *bias, const float *residual, int64_t ldr,
+                                     float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, uint32_t *row_max,
+                                     uint32_t *col_max, int32_t col_lo, int32_t col_hi, int32_t col_rows, void *stream);
+SCP_API int scp_row_scale_from_max(const uint32_t *row_max, int32_t M, float *scale, float *inv_scale, void *stream);
 /* The same dense layer with the ACTIVATION pre-split too: A arrives as bf16 planes hi/lo [M][lda] (lda % 8 == 0, lda >= Kpad,
  * columns K..Kpad zero) written by the producing kernel (scp_split_rows, scp_layernorm_rows_split, the attention kernels, or this
  * function's own split output), so operand tiles go global -> LDS by LDS-DMA with no conversion.  Outputs: C fp32 [M][ldc]
@@ -333,6 +343,11 @@ SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float *k, const 
                                         int64_t ldkv, int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *workspace,
                                         int64_t ws_bytes, void *stream);   /* ldkv: row stride (floats) of k, k_u, v, v_u - H * hd for dense
                                         rows, 1280 when they are column slices of one key | value projection (round 4); q_u, out, out_u dense */
+/* the same with max |v| over the B * c rows of v GIVEN (device word: the bit pattern of a finite non-negative float, e.g. col_max of the
+ * scp_linear_split_f16_max call that wrote v): no pass over v */
+SCP_API int scp_octattn_attention_f16x3_vmax(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
+                                             int64_t ldkv, int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *workspace,
+                                             int64_t ws_bytes, const uint32_t *vmax_bits, void *stream);
 /* OctAttention's input stage in one launch (oct_attention.py:48-66): embeddings of the four ancestors + Linear(3 -> d_pos) of their
  * positions, concatenated to D = 4 (d_occ + d_lvl + d_oct + d_pos) <= 768 channels, scaled by sqrt(D), plus the position table pe [c][D];
  * both streams (1 = "unknown": occ_enc[255] for the node's own occupancy).  ctx uint8 [n][12] = (occ, level, octant) x 4, pos fp32

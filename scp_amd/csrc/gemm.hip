@@ -395,6 +395,22 @@ extern "C" SCP_API int scp_split_rows_f16(const float *A, int64_t lda, int32_t M
     return SCP_OK;
 }
 
+// row scales from row maxima that a producing kernel's epilogue took (scp_linear_split_f16_max): bit patterns of max |row| -> scale, 1 / scale
+__global__ __launch_bounds__(256) void row_scale_from_max_kernel(const unsigned *__restrict__ mxb, int M, float *__restrict__ sc, float *__restrict__ isc) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s, is;
+    pow2_scale(__uint_as_float(mxb[m]), s, is);
+    sc[m] = s; isc[m] = is;
+}
+
+extern "C" SCP_API int scp_row_scale_from_max(const uint32_t *row_max, int32_t M, float *scale, float *inv_scale, void *stream) {
+    if (!row_max || !scale || !inv_scale || M <= 0) return SCP_EINVAL;
+    hipLaunchKernelGGL(row_scale_from_max_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned *)row_max, M, scale, inv_scale);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
 // row scales of an activation on their own (scale [M], 1 / scale [M]): several layers reading the SAME rows (OctAttention's key / value /
 // query projections of one embedding tensor) share them through scp_linear_f16x3_scaled
 extern "C" SCP_API int scp_row_scale_f16(const float *A, int64_t lda, int32_t M, int32_t K, float *scale, float *inv_scale, void *stream) {

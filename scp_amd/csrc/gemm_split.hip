@@ -59,6 +59,12 @@ struct GemmSplitArgs {
     int ncols_out;                               // split output: columns written (N rounded up to 32, <= ldo): zero filled beyond N
     int wtiled;                                  // weight planes in the tiled layout (default) / row-major [Npad][Kpad] (SCP_WTILE=0)
     const float *a_isc, *w_isc;                  // F16 kernels: inverse power-of-two scale per activation row [M] / weight row [Npad]
+    // F16 kernels, optional maxima of the OUTPUT taken in the epilogue (atomicMax on the bit patterns of |y|; the caller zeroes them): what the next
+    // layer's power-of-two scales are made from, without a pass over the output (OctAttention: row scales of linear1's output for linear2, max |v|
+    // of the key | value projection for the attention kernel's V planes)
+    unsigned *row_max;                           // [M]: max |C[m][:]| or null
+    unsigned *col_max;                           // one word: max |C[m][n]| over m < cm_rows, cm_lo <= n < cm_hi, or null
+    int cm_lo, cm_hi, cm_rows;
 };
 
 // EXT: the epilogue extensions (gathered residual before the activation, scattered output rows) are compiled only into the
@@ -252,6 +258,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
         const int nb = cn0 + wn * 64 + c4;
         const bool full = (cn0 + wn * 64 + 64 <= a.N) && a.vec_ok;        // wave-uniform: the wave's 64 columns are all real
         const bool has_res = a.res != nullptr, has_c = a.C != nullptr, has_o = a.Ohi != nullptr;
+        const bool maxes = F16 && (a.row_max || a.col_max);     // (bf16 instantiations: compiled out)
+        float cmx = 0.f;
+        auto take_max = [&](const f32x4 &y, int m, bool okrow) {   // all 64 lanes call this; lanes of rows beyond M contribute 0
+            float mx = okrow ? fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))) : 0.f;
+            if (a.col_max && okrow && m < a.cm_rows) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (nb + u >= a.cm_lo && nb + u < a.cm_hi) cmx = fmaxf(cmx, fabsf(y[u]));
+            }
+            if (a.row_max) {   // the 16 lanes of a row (same lane >> 4) hold its 64 columns of this wave
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                if ((lane & 15) == 0 && okrow) atomicMax(a.row_max + m, __float_as_uint(fminf(mx, 3.0e38f)));
+            }
+        };
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = cm0 + wm * (TM * 32) + i * 32 + rsub;     // row of it = 0; it adds 4
@@ -291,6 +312,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
 #pragma unroll
                         for (int u = 0; u < 4; ++u) y[u] = apply_act_s<ACT>(y[u]);
                     }
+                    if (maxes) take_max(y, m, m < a.M);
                     if (has_c && m < a.M) {
                         const int64_t orow = (EXT && a.out_map) ? ((const int64_t *)(smem + MAPOFF))[BM + m - cm0] : (int64_t)m;
                         if (orow >= 0) *(f32x4 *)(a.C + orow * a.ldc + nb) = y;
@@ -313,7 +335,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                 for (int it = 0; it < 8; ++it) {
                     const int m = mb + 4 * it;
                     f32x4 y = *(const f32x4 *)(stg + (4 * it + rsub) * 64 + c4);
-                    if (m >= a.M) continue;
+                    if (m >= a.M) {
+                        if (maxes) take_max(y, m, false);
+                        continue;
+                    }
                     for (int u = 0; u < 4; ++u) {
                         if (nb + u < a.N) {
                             if (has_res) y[u] += a.res[((EXT && a.res_map) ? a.res_map[m] : (int64_t)m) * a.ldr + nb + u];
@@ -324,6 +349,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                             }
                         } else y[u] = 0.f;
                     }
+                    if (maxes) take_max(y, m, true);
                     if (has_o && nb < a.ncols_out) {
                         bf16x4 hi, lo;
                         for (int u = 0; u < 4; ++u) {
@@ -336,6 +362,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
                     }
                 }
             }
+        }
+        if (maxes && a.col_max) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cmx = fmaxf(cmx, __shfl_xor(cmx, o));
+            if (lane == 0 && cmx > 0.f) atomicMax(a.col_max, __float_as_uint(fminf(cmx, 3.0e38f)));
         }
         // the next tile's first barrier orders these LDS reads before the DMA that refills stage 1
     }
@@ -451,7 +482,7 @@ static int linear_split_impl(const void *Ahi, const void *Alo, int64_t lda, cons
         g_num_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     }
     GemmSplitArgs ga;
-    ga.a_isc = nullptr; ga.w_isc = nullptr;
+    ga.a_isc = nullptr; ga.w_isc = nullptr; ga.row_max = nullptr; ga.col_max = nullptr; ga.cm_lo = ga.cm_hi = ga.cm_rows = 0;
     ga.Ahi = (const __bf16 *)Ahi; ga.Alo = (const __bf16 *)Alo; ga.lda = lda;
     ga.Whi = (const __bf16 *)Whi; ga.Wlo = (const __bf16 *)Wlo; ga.Kpad = Kpad;
     ga.bias = bias; ga.res = residual; ga.ldr = ldr; ga.C = C; ga.ldc = ldc;
@@ -500,9 +531,12 @@ extern "C" SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_
 // f16x3 form (OctAttention's dense layers, oct_attention.py:48-83 / attention_model.py:97-125): A planes + inverse row scales from
 // scp_split_rows_f16, W planes (tiled) + inverse row scales from scp_split_weight_f16 with Npad % 256 == 0; act: 0 none, 3 ReLU.
 // Bit-identical to scp_linear_f16x3_scaled on the fp32 rows the planes were made from.
-extern "C" SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, int64_t lda, const float *a_inv_scale, const void *Whi, const void *Wlo,
-                                            const float *w_inv_scale, int32_t Npad, int32_t Kpad, const float *bias, const float *residual, int64_t ldr,
-                                            float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream) {
+static int linear_split_f16_impl(const void *Ahi, const void *Alo, int64_t lda, const float *a_inv_scale, const void *Whi, const void *Wlo,
+                                 const float *w_inv_scale, int32_t Npad, int32_t Kpad, const float *bias, const float *residual, int64_t ldr,
+                                 float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, uint32_t *row_max, uint32_t *col_max,
+                                 int32_t col_lo, int32_t col_hi, int32_t col_rows, void *stream) {
+    if (col_max && (col_lo < 0 || col_hi > N || col_lo >= col_hi || col_rows <= 0)) return SCP_EINVAL;
+    if ((((uintptr_t)row_max | (uintptr_t)col_max) & 3)) return SCP_EINVAL;
     if (!Ahi || !Alo || !a_inv_scale || !Whi || !Wlo || !w_inv_scale || !C || M <= 0 || N <= 0 || K <= 0 || (lda & 7) || Kpad < K || (Kpad & 31) || cfg < 0 || cfg > 3 ||
         lda < Kpad || (Npad & 255) || Npad < N || (act != ACT_NONE && act != ACT_RELU) || ldc < N || (residual && ldr < N) ||
         (((uintptr_t)Ahi | (uintptr_t)Alo | (uintptr_t)Whi | (uintptr_t)Wlo) & 15) || (((uintptr_t)C | (uintptr_t)residual) & 3))
@@ -519,6 +553,7 @@ extern "C" SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, in
     ga.Whi = (const __bf16 *)Whi; ga.Wlo = (const __bf16 *)Wlo; ga.Kpad = Kpad;
     ga.bias = bias; ga.res = residual; ga.ldr = ldr; ga.C = C; ga.ldc = ldc; ga.M = M; ga.N = N;
     ga.a_isc = a_inv_scale; ga.w_isc = w_inv_scale;
+    ga.row_max = row_max; ga.col_max = col_max; ga.cm_lo = col_lo; ga.cm_hi = col_hi; ga.cm_rows = col_rows;
     { static int wt = -1; if (wt < 0) { const char *e = getenv("SCP_WTILE"); wt = (e && e[0] == '0') ? 0 : 1; } ga.wtiled = wt; }
     ga.vec_ok = !((ldc & 3) || ((uintptr_t)C & 15) || (residual && ((ldr & 3) || ((uintptr_t)residual & 15))));
     // cfg 0 = automatic.  3: 128 x 128 tiles, 4 waves, two workgroups per CU: N = 600 / 300 waste 6 % / 22 % of a 128-wide column tiling
@@ -531,6 +566,25 @@ extern "C" SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, in
     if (cfg == 1) return launch_cfg<2, 4, 4, false, true>(ga, act, st, work);
     if (cfg == 2) return launch_cfg<4, 2, 2, false, true>(ga, act, st, work);
     return launch_cfg<2, 2, 2, false, true>(ga, act, st, work);
+}
+
+extern "C" SCP_API int scp_linear_split_f16(const void *Ahi, const void *Alo, int64_t lda, const float *a_inv_scale, const void *Whi, const void *Wlo,
+                                            const float *w_inv_scale, int32_t Npad, int32_t Kpad, const float *bias, const float *residual, int64_t ldr,
+                                            float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream) {
+    return linear_split_f16_impl(Ahi, Alo, lda, a_inv_scale, Whi, Wlo, w_inv_scale, Npad, Kpad, bias, residual, ldr, C, ldc, M, N, K, act, cfg, nullptr, nullptr, 0, 0,
+                                 0, stream);
+}
+
+// scp_linear_split_f16 that also takes maxima of its output in the epilogue (atomicMax on the bit patterns of |C|; the caller zeroes the words): row_max [M]
+// = max |C[m][:]|; col_max (one word) = max |C[m][n]| over m < col_rows, col_lo <= n < col_hi.  The power-of-two scales of the NEXT f16x3 layer come from
+// them (scp_row_scale_from_max; scp_octattn_attention_f16x3_vmax) without a pass over C.  Same C, bit for bit.
+extern "C" SCP_API int scp_linear_split_f16_max(const void *Ahi, const void *Alo, int64_t lda, const float *a_inv_scale, const void *Whi, const void *Wlo,
+                                                const float *w_inv_scale, int32_t Npad, int32_t Kpad, const float *bias, const float *residual, int64_t ldr,
+                                                float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, uint32_t *row_max,
+                                                uint32_t *col_max, int32_t col_lo, int32_t col_hi, int32_t col_rows, void *stream) {
+    if (!row_max && !col_max) return SCP_EINVAL;
+    return linear_split_f16_impl(Ahi, Alo, lda, a_inv_scale, Whi, Wlo, w_inv_scale, Npad, Kpad, bias, residual, ldr, C, ldc, M, N, K, act, cfg, row_max, col_max,
+                                 col_lo, col_hi, col_rows, stream);
 }
 
 // the same with a GATHERED residual added BEFORE the activation: out[m] = act(A[m] . W^T + bias + residual[res_map[m]]).

@@ -379,9 +379,8 @@ extern "C" SCP_API int64_t scp_octattn_f16x3_ws_bytes(int32_t B, int32_t c, int3
     return (int64_t)(OA_HDR + oa_align(rows * 4) + oa_align(rows * 8) + oa_align(rows * 2 * FHP * 2) + (size_t)B * nt * H * (FK_IMG + FV_IMG));
 }
 
-extern "C" SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
-                                                   int64_t ldkv, int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *workspace,
-                                                   int64_t ws_bytes, void *stream) {
+static int oa_attention_impl(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u, int64_t ldkv, int32_t B, int32_t c, int32_t H,
+                             int32_t hd, float *out, float *out_u, void *workspace, int64_t ws_bytes, const uint32_t *vmax_given, void *stream) {
     if (!q_u || !k || !k_u || !v || !v_u || !out || !out_u || !workspace || B <= 0 || c <= 0 || c > 1024 || H <= 0 || hd != FHD || ((H * FHD) & 3) ||
         ldkv < H * FHD || (ldkv & 3) || ((((uintptr_t)k_u | (uintptr_t)v_u) & 15) != 0) ||
         ((((uintptr_t)q_u | (uintptr_t)k | (uintptr_t)v) & 15) != 0) || ((uintptr_t)workspace & 1023) ||
@@ -402,12 +401,30 @@ extern "C" SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float
     {
         SCP_PROF(SCP_PROF_OTHER, st, 0.0);             // operand preparation (planes, scales, diagonal terms)
         const unsigned nblk = (unsigned)(n4 < 256 * 1024 ? (n4 + 255) / 256 : 1024);
-        hipLaunchKernelGGL(oa_absmax_kernel, dim3(nblk), dim3(256), 0, st, v, n4, H * FHD / 4, ldkv, vpart);
-        hipLaunchKernelGGL(oa_prep_kernel, dim3(B * nt, H), dim3(256), 0, st, q_u, k, k_u, v, ldkv, c, H, nt, vpart, (int)(4 * nblk), vmax, qp, isq, diag, kimg, vimg);
+        // max |v|: given by the caller (the epilogue of the projection that wrote v took it: one word, the bit pattern of a finite non-negative float),
+        // or one pass over v here
+        if (!vmax_given) hipLaunchKernelGGL(oa_absmax_kernel, dim3(nblk), dim3(256), 0, st, v, n4, H * FHD / 4, ldkv, vpart);
+        hipLaunchKernelGGL(oa_prep_kernel, dim3(B * nt, H), dim3(256), 0, st, q_u, k, k_u, v, ldkv, c, H, nt, vmax_given ? (const float *)vmax_given : (const float *)vpart,
+                           vmax_given ? 1 : (int)(4 * nblk), vmax, qp, isq, diag, kimg, vimg);
     }
     SCP_PROF(SCP_PROF_OA_ATTENTION, st, (double)B * 3.0 * 2.0 * c * (double)c * H * FHD);
     hipLaunchKernelGGL(oa_attn_f16x3_kernel, dim3(B * H * ((c + 127) / 128)), dim3(256), 0, st, v, v_u, ldkv, c, H, nt, vmax, qp, isq, diag,
                        kimg, vimg, out, out_u);
     LAUNCH_CHECK();
     return SCP_OK;
+}
+
+extern "C" SCP_API int scp_octattn_attention_f16x3(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
+                                                   int64_t ldkv, int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *workspace,
+                                                   int64_t ws_bytes, void *stream) {
+    return oa_attention_impl(q_u, k, k_u, v, v_u, ldkv, B, c, H, hd, out, out_u, workspace, ws_bytes, nullptr, stream);
+}
+
+// the same with max |v| (over the B * c rows of v) given as the bit pattern of a float in device memory - e.g. the col_max word of the scp_linear_split_f16_max
+// call that wrote v: no pass over v
+extern "C" SCP_API int scp_octattn_attention_f16x3_vmax(const float *q_u, const float *k, const float *k_u, const float *v, const float *v_u,
+                                                        int64_t ldkv, int32_t B, int32_t c, int32_t H, int32_t hd, float *out, float *out_u, void *workspace,
+                                                        int64_t ws_bytes, const uint32_t *vmax_bits, void *stream) {
+    if (!vmax_bits || ((uintptr_t)vmax_bits & 3)) return SCP_EINVAL;
+    return oa_attention_impl(q_u, k, k_u, v, v_u, ldkv, B, c, H, hd, out, out_u, workspace, ws_bytes, vmax_bits, stream);
 }

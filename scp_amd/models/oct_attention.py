@@ -150,9 +150,9 @@ class OctAttention(nn.Module):
         else:
             E = self._embed_torch(data, pos, cap)
 
-        def lin(a, x, w, b, act=None, residual=None, rows=None, scales=None):
+        def lin(a, x, w, b, act=None, residual=None, rows=None, scales=None, row_max=None):
             if planes:
-                return native.linear_split_f16(a if rows is None else a.rows(*rows), _ops._split16(w), b, _ops._ACT[act], residual)
+                return native.linear_split_f16(a if rows is None else a.rows(*rows), _ops._split16(w), b, _ops._ACT[act], residual, row_max=row_max)
             return linear(x, w, b, act=act, residual=residual, scales=scales)
 
         for lyr in self.transformer_encoder.layers:
@@ -172,19 +172,25 @@ class OctAttention(nn.Module):
                 # at M = 262 144 (tools/mb_oa_cfg.py); same products in the same k order: identical bits.  The attention kernels take the
                 # two column slices with their row stride.
                 wkv, bkv = _ops.derived(a, "kv_cat", [a.mlp_key.weight, a.mlp_key.bias, a.mlp_value.weight, a.mlp_value.bias], lambda: _kv_cat(a, D))
-                kv = native.linear_split_f16(pa, _ops._split16(wkv), bkv, cfg=1).reshape(2, B, c, wkv.shape[0])
+                # round 5: the maxima the next kernels scale by come out of the producing GEMM's epilogue (one zeroed buffer per layer): max |v| of the
+                # known stream for the attention kernel's V planes, the row maxima of linear1's output for linear2 - no pass over either tensor
+                mxw = torch.zeros(2 * n + 1, dtype=torch.int32, device=E.device)
+                vmax, h1max = mxw[2 * n:], mxw[:2 * n]
+                kv = native.linear_split_f16(pa, _ops._split16(wkv), bkv, cfg=1, col_max=(vmax, _KV_OFF, _KV_OFF + D, n)).reshape(2, B, c, wkv.shape[0])
                 key, val = kv[..., :D], kv[..., _KV_OFF:_KV_OFF + D]
             else:
+                vmax = h1max = None
                 key = lin(pa, E, a.mlp_key.weight, a.mlp_key.bias, scales=rs).reshape(2, B, c, D)
                 val = lin(pa, E, a.mlp_value.weight, a.mlp_value.bias, scales=rs).reshape(2, B, c, D)
             q_u = lin(pa, E[1], a.mlp_query.weight, a.mlp_query.bias, rows=(n, 2 * n), scales=rsq).reshape(B, c, D)
             att = torch.empty_like(E)
-            native.octattn_attention(q_u, key[0], key[1], val[0], val[1], self.heads, out=att[0], out_u=att[1])
+            native.octattn_attention(q_u, key[0], key[1], val[0], val[1], self.heads, out=att[0], out_u=att[1], vmax=vmax)
             # norm(x + residual) in one pass; with `planes` the same pass writes the f16x3 operand of the layer that reads the result
             E, p1 = native.layernorm_add(att, E, lyr.norm1.weight, lyr.norm1.bias, 1e-5, planes=True) if planes else \
                 (native.layernorm_add(att, E, lyr.norm1.weight, lyr.norm1.bias, 1e-5), None)
-            h1 = lin(p1, E, lyr.linear1.weight, lyr.linear1.bias, act="relu")
-            y2 = linear(h1, lyr.linear2.weight, lyr.linear2.bias, residual=E.reshape(h1.shape[:-1] + (D,))).reshape(E.shape)
+            h1 = lin(p1, E, lyr.linear1.weight, lyr.linear1.bias, act="relu", row_max=h1max)
+            y2 = linear(h1, lyr.linear2.weight, lyr.linear2.bias, residual=E.reshape(h1.shape[:-1] + (D,)),
+                        scales=None if h1max is None else native.RowScales.from_max(h1max)).reshape(E.shape)
             E, pa = native.layernorm_add(y2, None, lyr.norm2.weight, lyr.norm2.bias, 1e-5, planes=True) if planes else \
                 (native.layernorm_add(y2, None, lyr.norm2.weight, lyr.norm2.bias, 1e-5), None)
         emu = E[1]

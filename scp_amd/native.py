@@ -99,6 +99,9 @@ def lib():
         "scp_prof_read": (C.c_int, [i32, _vp, _vp, _vp]),
         "scp_set_knn_mode": (C.c_int, [i32]),
         "scp_row_scale_f16": (C.c_int, [_vp, i64, i32, i32, _vp, _vp, _vp]),
+        "scp_row_scale_from_max": (C.c_int, [_vp, i32, _vp, _vp, _vp]),
+        "scp_linear_split_f16_max": (C.c_int, [_vp, _vp, i64, _vp, _vp, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, i32, _vp, _vp, i32, i32, i32, _vp]),
+        "scp_octattn_attention_f16x3_vmax": (C.c_int, [_vp, _vp, _vp, _vp, _vp, i64, i32, i32, i32, i32, _vp, _vp, _vp, i64, _vp, _vp]),
         "scp_linear_f16x3_scaled": (C.c_int, [_vp, i64, _vp, _vp, _vp, i32, _vp, _vp, i64, _vp, i64, i32, i32, i32, i32, _vp, _vp, _vp]),
         "scp_layernorm_add": (C.c_int, [_vp, _vp, i64, i32, _vp, _vp, C.c_float, _vp, _vp]),
         "scp_layernorm_add_split_f16": (C.c_int, [_vp, _vp, i64, i32, _vp, _vp, C.c_float, _vp, _vp, _vp, i64, _vp, _vp, _vp]),
@@ -841,6 +844,14 @@ class RowScales:
     def rows(self, a, b):
         return RowScales(None, self.sc[a:b], self.isc[a:b])
 
+    @staticmethod
+    def from_max(row_max):
+        """The scales of rows whose maxima a producing kernel's epilogue took (linear_split_f16(..., row_max=...)): int32 [M] bit patterns of max |row|."""
+        M = row_max.shape[0]
+        ws = torch.empty((2, M), dtype=torch.float32, device=row_max.device)
+        _check(lib().scp_row_scale_from_max(_dev(row_max, torch.int32), M, ws[0].data_ptr(), ws[1].data_ptr(), _stream()), "scp_row_scale_from_max")
+        return RowScales(None, ws[0], ws[1])
+
 
 class SplitActF16:
     """An fp32 activation [M, K] as the f16x3 kernels' operand, made ONCE (scp_split_rows_f16): power-of-two row scales (sc, isc) and
@@ -868,9 +879,11 @@ class SplitActF16:
         return SplitActF16(parts=(self.hi[a:b], self.lo[a:b], self.sc[a:b], self.isc[a:b], self.K))
 
 
-def linear_split_f16(a, sw, bias=None, act=ACT_NONE, residual=None, cfg=0, out=None):
+def linear_split_f16(a, sw, bias=None, act=ACT_NONE, residual=None, cfg=0, out=None, row_max=None, col_max=None):
     """act(A W^T + bias) + residual on pre-split f16 planes (SplitActF16 x SplitWeightF16) -> fp32 [M, N]; bit-identical to linear_f16x3
-    on the fp32 rows the planes were made from (csrc/gemm_split.hip, F16 instantiation: operands by LDS-DMA, no conversion in the tile)."""
+    on the fp32 rows the planes were made from (csrc/gemm_split.hip, F16 instantiation: operands by LDS-DMA, no conversion in the tile).
+    row_max: ZEROED int32 [M], receives the bit patterns of max |out[m, :]|; col_max = (ZEROED int32 [1], col_lo, col_hi, rows): max |out[:rows,
+    col_lo:col_hi]| - taken in the epilogue (scp_linear_split_f16_max), the scales of the next f16x3 layer without a pass over `out`."""
     if not sw.tiled_layout and WTILE:
         raise ScpError("linear_split_f16: weight planes are not tiled")
     M, N = a.M, sw.N
@@ -883,6 +896,17 @@ def linear_split_f16(a, sw, bias=None, act=ACT_NONE, residual=None, cfg=0, out=N
         r2 = residual.reshape(-1, N)
         if r2.stride(1) != 1:
             r2 = r2.contiguous()
+    if row_max is not None or col_max is not None:
+        if row_max is not None and (row_max.dtype != torch.int32 or row_max.shape[0] != M or not row_max.is_contiguous()):
+            raise ScpError("linear_split_f16: row_max must be a contiguous int32 [M]")
+        cm, lo, hi, rows = col_max if col_max is not None else (None, 0, 0, 0)
+        rc = lib().scp_linear_split_f16_max(a.hi.data_ptr(), a.lo.data_ptr(), a.hi.stride(0), a.isc.data_ptr(), sw.hi.data_ptr(), sw.lo.data_ptr(),
+                                            sw.inv_scale.data_ptr(), sw.Npad, sw.Kpad, _opt(bias), None if r2 is None else r2.data_ptr(),
+                                            0 if r2 is None else r2.stride(0), out.data_ptr(), out.stride(0), M, N, sw.K, act, cfg,
+                                            None if row_max is None else row_max.data_ptr(), None if cm is None else _dev(cm, torch.int32), int(lo), int(hi), int(rows),
+                                            _stream())
+        _check(rc, "scp_linear_split_f16_max")
+        return out
     rc = lib().scp_linear_split_f16(a.hi.data_ptr(), a.lo.data_ptr(), a.hi.stride(0), a.isc.data_ptr(), sw.hi.data_ptr(), sw.lo.data_ptr(),
                                     sw.inv_scale.data_ptr(), sw.Npad, sw.Kpad, _opt(bias), None if r2 is None else r2.data_ptr(),
                                     0 if r2 is None else r2.stride(0), out.data_ptr(), out.stride(0), M, N, sw.K, act, cfg, _stream())
@@ -1257,7 +1281,7 @@ def linear_f32(x, w, bias=None, act=ACT_NONE):
 OCTATTN_MODE = os.environ.get("SCP_OCTATTN", "f16x3")   # "f32": the fp32 MFMA kernel for head width 150 as well
 
 
-def octattn_attention(q_u, k, k_u, v, v_u, heads, out=None, out_u=None):
+def octattn_attention(q_u, k, k_u, v, v_u, heads, out=None, out_u=None, vmax=None):
     """Dual-stream causal attention (models/attention_model.py:58-95).  Head width 150 (the reference configuration) runs on the
     f16x3 kernel (22-bit operands on f16 MFMA, csrc/octattn_f16.hip); SCP_OCTATTN=f32 or any other width: the fp32 kernels.
     k, k_u, v, v_u may be column slices of one key | value projection output (unit channel stride, one common row stride)."""
@@ -1274,6 +1298,11 @@ def octattn_attention(q_u, k, k_u, v, v_u, heads, out=None, out_u=None):
         nb = lib().scp_octattn_f16x3_ws_bytes(B, c, heads)
         ws = torch.empty((nb + 1024,), dtype=torch.uint8, device=q_u.device)
         off = (-ws.data_ptr()) % 1024
+        if vmax is not None:    # max |v| taken by the epilogue of the projection that wrote v (int32 [1]: the bit pattern of the float)
+            rc = lib().scp_octattn_attention_f16x3_vmax(_dev(q_u), k.data_ptr(), k_u.data_ptr(), v.data_ptr(), v_u.data_ptr(), ld, B, c, heads, hd, _dev(out),
+                                                        _dev(out_u), ws.data_ptr() + off, nb, _dev(vmax, torch.int32), _stream())
+            _check(rc, "scp_octattn_attention_f16x3_vmax")
+            return out, out_u
         rc = lib().scp_octattn_attention_f16x3(_dev(q_u), k.data_ptr(), k_u.data_ptr(), v.data_ptr(), v_u.data_ptr(), ld, B, c, heads, hd, _dev(out),
                                                _dev(out_u), ws.data_ptr() + off, nb, _stream())
         _check(rc, "scp_octattn_attention_f16x3")

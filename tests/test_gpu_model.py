@@ -1743,3 +1743,45 @@ def test_decode_expand_kernel_equals_the_torch_construction(dev, polar, last):
     assert torch.equal(occ8, occ.to(torch.uint8)) and torch.equal(gpos.long(), cpos) and torch.equal(ganc, canc.to(torch.uint8))
     assert torch.equal(goct, coct.to(torch.uint8)) and torch.equal(gctx, cctx)
     assert torch.equal(gposn.view(torch.int32), cposn.view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,cfg", [(1, 255, 600, 0), (300, 600, 300, 0), (4100, 2400, 600, 0), (4100, 1280, 600, 1), (513, 240, 80, 2), (70000, 600, 600, 3)])
+@pytest.mark.parametrize("act", [None, "relu"])
+def test_linear_split_f16_epilogue_maxima(dev, M, N, K, cfg, act):
+    """Round 5: scp_linear_split_f16_max takes the maxima the NEXT f16x3 layer scales by in its epilogue - the output is unchanged bit for bit,
+    row_max holds the bit patterns of max |out[m, :]| (so RowScales.from_max equals the scales of a pass over the output: scp_row_scale_f16),
+    col_max the maximum over a row / column range (max |v| of OctAttention's stacked key | value projection)."""
+    from scp_amd import native, ops
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    x = torch.randn((M, K), generator=g) * 25.0 * torch.pow(10.0, torch.randint(-4, 5, (M, 1), generator=g).float())
+    w = torch.randn((N, K), generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    sw, pa, a = ops._split16(wd), native.SplitActF16(xd), ops._ACT[act]
+    want = native.linear_split_f16(pa, sw, bd, a, cfg=cfg)
+    rm = torch.zeros(M, dtype=torch.int32, device=dev)
+    cm = torch.zeros(1, dtype=torch.int32, device=dev)
+    lo, hi, rows = N // 3, N - 5 if N > 8 else N, max(1, M // 2)
+    got = native.linear_split_f16(pa, sw, bd, a, cfg=cfg, row_max=rm, col_max=(cm, lo, hi, rows))
+    assert torch.equal(got, want)
+    assert torch.equal(rm.view(torch.float32), want.abs().amax(1))
+    assert float(cm.view(torch.float32)) == float(want[:rows, lo:hi].abs().max())
+    if N % 4 == 0:                                                     # (scp_row_scale_f16 reads rows as float4)
+        rs, rs2 = native.RowScales(want), native.RowScales.from_max(rm)
+        assert torch.equal(rs.sc, rs2.sc) and torch.equal(rs.isc, rs2.isc)
+    only = torch.zeros(M, dtype=torch.int32, device=dev)
+    assert torch.equal(native.linear_split_f16(pa, sw, bd, a, cfg=cfg, row_max=only), want) and torch.equal(only, rm)
+
+
+@pytest.mark.gpu
+def test_octattn_attention_with_the_value_maximum_given(dev):
+    """scp_octattn_attention_f16x3_vmax (max |v| from the projection's epilogue) = scp_octattn_attention_f16x3 (its own pass over v), bit for bit."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(9)
+    B, c, H, D = 3, 700, 4, 600
+    q, k, ku, v, vu = [(torch.randn((B, c, D), generator=g) * s).to(dev) for s in (1.0, 1.0, 1.0, 3.0, 3.0)]
+    a0, a1 = native.octattn_attention(q, k, ku, v, vu, H)
+    vm = v.abs().max().reshape(1).view(torch.int32)
+    b0, b1 = native.octattn_attention(q, k, ku, v, vu, H, vmax=vm)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
