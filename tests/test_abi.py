@@ -4,6 +4,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 from conftest import ROOT, golden
 
