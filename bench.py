@@ -55,8 +55,8 @@ PMC_PROFILES = ("r5_ehem_L16m_frame_pmc_traffic.json", "r5_octattn_L14_frame_pmc
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed frames per rank (default 24; 3 with --decode)")
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed frames per rank (default 48; 3 with --decode)")
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default="ehem-L16-m", choices=sorted(CONFIGS))
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--tag", default="r4", help="file-name prefix used with --out-dir")
     a = ap.parse_args()
     if a.steps is None:
-        a.steps = 3 if a.decode else 24
+        a.steps = 3 if a.decode else 48      # (four frames are in flight: 24 timed frames left the fill / drain of the pipeline at 2 - 4 % of the figure, 14.7 - 15.2 against 15.3 - 15.4)
     return a
 
 
