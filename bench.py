@@ -12,7 +12,7 @@ The headline `value` is measured in STRICT-IDENTITY mode (round 5): the float ->
 (data_preprocess.py:42-70,171-214) on a prefetch thread, inside the timed region, and the run asserts that 0 points of the seed-0 frame differ
 from the reference's integers (`transform_parity`); the device-transform rate is the extra key `device_transform`.
 After the headline (outside its timed region, N = 1 only) the default run adds short legs, each a child process running this file
-(5 warm-up + 10 timed frames): the other four BASELINE.json workloads and the decoder under `configs`, and a `cli` leg - `.bin` files on disk
+(5 warm-up + 16 timed frames; 32 for the batched L12 workload): the other four BASELINE.json workloads and the decoder under `configs`, and a `cli` leg - `.bin` files on disk
 through the drop-in `encode_mullevel.py` (file read, parse, host -> device copy and the written `.bin` / `.dat` inside) - with `cli_over_bench`;
 `decode_2_procs` / `decode_4_procs`: independent decoder processes sharing the GPU (a decode is a serial chain of short launches: streams scale by process).
 
@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the second timed loop (the other transform mode)")
     ap.add_argument("--no-legs", action="store_true", help="skip the side legs (the other four workloads, the decoder, the CLI), which run as child processes "
                     "after the headline, outside its timed region")
-    ap.add_argument("--leg-steps", type=int, default=10)
+    ap.add_argument("--leg-steps", type=int, default=16)
     ap.add_argument("--leg-warmup", type=int, default=5)
     ap.add_argument("--oa-batch", type=int, default=None, help="OctAttention: windows per forward (OctAttnFrameEncoder.max_batch)")
     ap.add_argument("--decode", action="store_true", help="time the decoder (FrameDecoder) on the configuration's frame instead of the encoder")
@@ -540,7 +540,7 @@ def side_legs(args, out):
                                   roofline=dict(kernel=rf["kernel"].split(":")[0], frac=rf["frac"], valid=rf["valid"], avg_launch_us=rf["avg_launch_us"]),
                                   roofline_frame_frac_mfma=out["roofline_frame"]["frac_mfma"], note="the headline of this line")}
     for name in ("ehem-L12-s", "ehem-F17-m", "octattn-L12-spher", "octattn-L14-cylin"):
-        extra = ["--steps", "16"] if name == "ehem-L12-s" else []      # BASELINE.json configs[1] is a batch of 16 frames
+        extra = ["--steps", "32"] if name == "ehem-L12-s" else []      # BASELINE.json configs[1] is a batch of 16 frames: two of them (four launch sequences of 8)
         configs[name] = brief(_child_line(["--config", name] + common + extra))
     out["configs"] = configs
     z = _child_line(["--decode", "--steps", "3", "--warmup", "1"])

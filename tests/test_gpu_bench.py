@@ -86,7 +86,7 @@ def test_bench_side_legs_fill_configs_decode_and_cli():
     for name, c in out["configs"].items():
         assert "error" not in c, (name, c)
         assert c["fps"] > 0 and c["ms_per_step"] > 0 and 0 < c["roofline"]["frac"] < 1 and c["roofline"]["valid"] is True, (name, c)
-    assert out["configs"]["ehem-L12-s"]["steps"] == 16 and out["configs"]["ehem-L12-s"]["strict_identity_verified"] is True
+    assert out["configs"]["ehem-L12-s"]["steps"] == 32 and out["configs"]["ehem-L12-s"]["strict_identity_verified"] is True
     assert out["configs"]["ehem-L16-m"]["fps"] == out["value"]
     d = out["decode"]
     assert d["decoded_occupancy_equals_encoded"] is True and d["fps"] > 0
