@@ -282,31 +282,53 @@ def pmc_traffic(config):
     return None, None, None
 
 
-def cpu_baseline(cfg, xyz, full=False):
+def last_full_frame_cpu(config):
+    """The last recorded whole-frame run of the CPU port for this configuration (`--cpu-baseline full`, every window run), from profiles/."""
+    for name in ("r6_bench_cpu_full.json", "r5_bench_cpu_full.json", "r3e_bench_cpu_full.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                z = json.loads(f.read().strip().splitlines()[-1])
+        except Exception:
+            continue
+        cb = z.get("cpu_baseline") or {}
+        if z.get("config", {}).get("workload", "").startswith(CONFIGS[config]["workload"]) and cb.get("seconds_per_frame") and "SAMPLED" not in cb.get("sample", ""):
+            return dict(seconds_per_frame=cb["seconds_per_frame"], value=cb["value"], cores=cb.get("cores"), host_cpu=cb.get("host_cpu"), source="profiles/" + name)
+    return None
+
+
+def cpu_baseline(cfg, xyz, full=False, config=None):
     """The CPU oracle (a port of the reference path: C octree / records / CDF / range coder + the functional PyTorch-CPU model,
     oracle/cpu_encode.py) on ONE frame of the bench's own workload, every stage timed.  Bounded sample: all windows shorter than
-    the model's context are run; full windows (identical shapes, data-independent cost) are run three times - one warm-up, the
-    the faster of the other two stands for the rest.  `--cpu-baseline full` runs every window (minutes per frame)."""
+    the model's context are run; full windows (identical shapes, data-independent cost) are run eight times - three warm-ups (the
+    first windows of a run are 20 - 30 % slower than the settled ones: thread pool, allocator, caches), the MEDIAN of the other five
+    stands for the rest.  `--cpu-baseline full` runs every window (minutes per frame); the last recorded such run is printed beside
+    the sample (`full_frame_recorded`)."""
     from cfgs import ehem_cfg, octattn_cfg
     from oracle import cpu_encode
     from scp_amd.models import EHEM, OctAttention
     from scp_amd.weights import fill_weights
     threads = min(os.cpu_count() or 1, 32)   # PyTorch-CPU oversubscribes badly beyond this on 128-core hosts
     torch.set_num_threads(threads)
-    runs = None if full else 3
+    runs, warm = (None, 0) if full else (8, 3)
     if cfg["model"] == "EHEM":
         sd = fill_weights(EHEM(ehem_cfg()), 0).state_dict()
         r = cpu_encode.encode_frame(xyz, sd, cfg["level"], mullevel=cfg["mullevel"], mode=cfg["mode"], full_window_runs=runs,
-                                    data_type=cfg.get("type", "kitti"))
+                                    data_type=cfg.get("type", "kitti"), full_window_warmup=warm)
     else:
         sd = fill_weights(OctAttention(octattn_cfg()), 0).state_dict()
-        r = cpu_encode.encode_frame_octattn(xyz, sd, cfg["level"], mode=cfg["mode"], full_window_runs=runs)
+        r = cpu_encode.encode_frame_octattn(xyz, sd, cfg["level"], mode=cfg["mode"], full_window_runs=runs, full_window_warmup=warm)
     what = (f"one whole frame, all {r['windows']} windows run" if full else
             f"SAMPLED: one frame: quantiser/octree/records/context of the whole frame, all {r['partial_windows']} partial windows, "
-            f"{r['full_windows_run']} of the {r['full_windows']} full windows (first = warm-up, the fastest of the rest x {r['full_windows']}), "
+            f"{r['full_windows_run']} of the {r['full_windows']} full windows (first {warm} = warm-up, the median of the rest x {r['full_windows']}), "
             f"CDF + range coder on the {r['rows_coded']} rows produced, scaled to {r['n_nodes']} nodes")
-    return dict(value=1.0 / r["total_s"], unit="frames/s", cores=threads, kind="port", sample=what, seconds_per_frame=r["total_s"],
-                stage_s=r["stage_s"], full_window_s=r["full_window_s"], host_cpu=cpu_encode.cpu_model_name(), host_cores=os.cpu_count())
+    out = dict(value=1.0 / r["total_s"], unit="frames/s", cores=threads, kind="port", sample=what, seconds_per_frame=r["total_s"],
+               stage_s=r["stage_s"], full_window_s=r["full_window_s"], full_window_cost_s=r.get("full_window_cost_s"),
+               host_cpu=cpu_encode.cpu_model_name(), host_cores=os.cpu_count())
+    rec = None if (full or config is None) else last_full_frame_cpu(config)
+    if rec is not None:
+        out["full_frame_recorded"] = rec
+        out["sampled_over_full_frame_recorded"] = r["total_s"] / rec["seconds_per_frame"]
+    return out
 
 
 CONFIGS = {
@@ -351,13 +373,16 @@ class IntsAhead:
 def differing_points(enc, cfg, dev):
     """Seed-0 frame: points whose quantised integers differ from the REFERENCE's (tests/golden/frame_ints.npz, produced by running the
     reference's proc_pc here): host transform (must be 0) and device transform, per shell."""
+    ford = cfg.get("type") == "ford"
     name = {"spher": "q_spher_L", "cylin": "q_cylin_L", "cart": "q_cart_L"}[cfg["mode"]]
+    if ford:       # tests/golden/make_golden.py facts_ford: the reference's mul_proc_pc on ford_like(synth_frame(0))
+        name = name[:-1] + "ford_L"
     path = os.path.join(ROOT, "tests", "golden", "frame_ints.npz")
-    if cfg.get("type") == "ford" or not os.path.exists(path):
+    if not os.path.exists(path):
         return None
     z = np.load(path)
-    from scp_amd.synth import synth_frame
-    xyz = synth_frame(0)
+    from scp_amd.synth import ford_like, synth_frame
+    xyz = ford_like(synth_frame(0)) if ford else synth_frame(0)
     keys = [f"{name}{lv}" for _, lv in enc.shells()]
     if any(k not in z.files for k in keys):
         return None
@@ -798,7 +823,7 @@ def main():
                 if not out["strict_identity_verified"]:
                     raise SystemExit(f"strict-identity headline, but the host transform's integers differ from the reference's: {tp}")
             elif headline_strict:
-                out["strict_identity_verified"] = None      # no reference integers for this workload's frames (Ford-like) in tests/golden/
+                out["strict_identity_verified"] = None      # no reference integers for this workload's frames in tests/golden/
         if not ehem:
             try:
                 out["transform_parity"] = differing_points(enc, cfg, dev)     # OctAttention legs run the device transform: how many points it misses
@@ -812,7 +837,7 @@ def main():
         mode = "none" if args.no_cpu_baseline else args.cpu_baseline
         if world == 1 and mode != "none":
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, frames_host[-1], full=mode == "full")
+                out["cpu_baseline"] = cpu_baseline(cfg, frames_host[-1], full=mode == "full", config=args.config)
             except Exception as e:   # the baseline is a reported number, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if world == 1 and not args.no_legs and args.config == "ehem-L16-m":

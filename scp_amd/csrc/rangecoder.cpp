@@ -149,7 +149,8 @@ struct scp_ac_dec {
             nwin += 8;
         }
     }
-    inline uint32_t take(int k) {   // the next k (1 .. 31) bits, MSB first
+    inline uint32_t take(int k) {   // the next k (0 .. 31) bits, MSB first
+        if (k <= 0) return 0;       // (tables with zero-width symbols can reach low > high and ask for no bits: win >> 64 is undefined)
         if (nwin < k) refill();
         const uint32_t v = (uint32_t)(win >> (64 - k));
         win <<= k;
@@ -202,6 +203,7 @@ __attribute__((target("avx2,popcnt"))) static inline int ac_search_256_avx2(cons
     }
     const int s = (int)(le >> 1) - 1;
     if (s < 0 || row[s] > count || (s < 254 && row[s + 1] <= count)) return -1;
+    if (s > 0 && row[s - 1] == row[s]) return -1;    // zero-width neighbours: the reference's search decides which of the equal entries it hits
     return s;
 }
 static const bool g_ac_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt");
@@ -222,7 +224,7 @@ static inline int ac_dec_step(scp_ac_dec *d, const uint16_t *row, int max_symbol
     low = low + (uint32_t)((span * (uint64_t)c_low) >> 16);
     const uint32_t diff = low ^ high;
     if (!(diff & 0x80000000u)) {                           // (1) k shared leading bits (k <= 31: low < high)
-        const int k = __builtin_clz(diff);
+        const int k = diff ? __builtin_clz(diff) : 31;   // (diff == 0 only on tables with zero-width symbols)
         low <<= k;
         high = (high << k) | ((1u << k) - 1u);
         value = (value << k) | d->take(k);

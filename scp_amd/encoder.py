@@ -444,10 +444,14 @@ class FrameEncoder:
                 # copy from the PINNED TENSOR itself, as quantize() does: torch's host allocator records the stream use of a tensor it knows,
                 # so the block is not handed to the next frame's host_ints while this asynchronous copy still reads it (a from_numpy view of
                 # the same memory is invisible to the allocator: the next frame's integers could overwrite an earlier frame's in flight)
-                qcat, a = hq.packed.to(self.device, non_blocking=True), 0
-                for q in hq:
-                    qs_all.append(qcat[a:a + q.shape[0]])
-                    a += q.shape[0]
+                packed = getattr(hq, "packed", None)
+                if packed is not None:
+                    qcat, a = packed.to(self.device, non_blocking=True), 0
+                    for q in hq:
+                        qs_all.append(qcat[a:a + q.shape[0]])
+                        a += q.shape[0]
+                else:      # plain per-shell arrays computed elsewhere (as quantize() accepts them): pageable memory, synchronous copies
+                    qs_all += [torch.from_numpy(np.ascontiguousarray(q, np.int32)).to(self.device) for q in hq]
                 infos += inf
             segs, off = [], 0
             for f in range(len(frames)):

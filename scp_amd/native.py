@@ -491,6 +491,10 @@ def decode_expand(sym, pos, anc, octant, L, shift, lv_next, lv_clamp, polar, mn,
     coct = torch.empty(m, dtype=torch.uint8, device=dev)
     cctx = torch.empty((m, 12), dtype=torch.uint8, device=dev)
     cposn = torch.empty((m, 3), dtype=torch.float32, device=dev)
+    if m == 0:
+        # no parent has a child (a multi-level shell whose last level holds only the dropped node): the C entry rejects the null
+        # pointers of empty outputs, and there is nothing to launch - the occupancy bytes of unknown symbols are 0
+        return (sym + 1).clamp_(min=0).to(torch.uint8), cpos, canc, coct, cctx, cposn
     _check(lib().scp_decode_expand(_dev(sym, torch.int64), cum.data_ptr(), _dev(pos, torch.int32), _dev(anc, torch.uint8), _dev(octant, torch.uint8), n,
                                    int(L), int(shift), int(lv_next), int(lv_clamp), 1 if polar else 0, float(mn), float(den), cpos.data_ptr(), canc.data_ptr(),
                                    coct.data_ptr(), cctx.data_ptr(), cposn.data_ptr(), occ8.data_ptr(), _stream()), "scp_decode_expand")

@@ -151,7 +151,12 @@ def split_cat(parts, device=None):
 
 
 def layer_norm(x, ln):
-    return torch.nn.functional.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
+    """LayerNorm over the last axis (256 or 512 channels) on the in-tree kernel (csrc/fused.hip: one wavefront per row)."""
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    return native.layernorm_rows(x2, ln.weight, ln.bias, eps=ln.eps).reshape(x.shape)
 
 
 def gelu_linear(x, w, b):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE in this container.
 
-    python tests/golden/make_golden.py [group ...]      # groups: xform oct kseq ctx e2e logits logits_tiefree logits_full swin cdf ac facts
+    python tests/golden/make_golden.py [group ...]      # groups: xform oct kseq ctx e2e logits logits_tiefree logits_full swin cdf ac facts facts_ford
 
 Only data (inputs + expected outputs) is written; no reference source travels.  Every
 fixture records which reference call produced it.  The script needs
@@ -869,9 +869,52 @@ def gen_logits_full():
          n_rows=np.int32(len(data)))
 
 
+def gen_facts_ford():
+    """BASELINE configs[3] (Ford-like frame = integer millimetres, --spher --mullevel, lidar_level 17): the reference's OWN `mul_proc_pc`
+    (data_preprocess.py:95-167) run with the three (qs, morton_path) pairs of encode_dataset_ehem_mullevel.py:154-186 for data_type 'ford'
+    (qs = 2^(18-L), 2^(17-L), 2^(16-L) = 2, 1, 0.5 mm).  Written: frame_facts.json["F17-m"] (per shell: bin_num, leaves, depth, records,
+    per-level node counts, sha256 of the occupancy codes and of the [N,4,6] records the reference saved) and
+    frame_ints.npz: q_spher_ford_L17/18/19 = the reference quantiser's integers in point order (whose octree is checked here to BE the
+    one mul_proc_pc built: same code stream).  ~4 min (pure-Python octree of 760 k nodes)."""
+    print("[facts_ford]")
+    L = 17
+    xyz = ford_like(synth_frame(0))
+    path_json = os.path.join(HERE, "frame_facts.json")
+    facts = json.load(open(path_json))
+    ints = dict(np.load(os.path.join(HERE, "frame_ints.npz")))
+    shells = []
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "ford0.bin")            # ptread -> loadbin: float32 [P,4] rows, the values are whole millimetres
+        write_kitti_bin(src, xyz)
+        for k, mpath in enumerate(([0, 0], [0, 1], [1])):
+            qs = 2.0 ** (18 - L - k)
+            out_file, quant_pc, ref_pt, bin_num, _ = RDP.mul_proc_pc(src, tmp, "ford0", normalize=False, qs=qs, test=True, spher=True,
+                                                                     morton_path=mpath)
+            assert np.array_equal(ref_pt, xyz)
+            rec = np.load(out_file + ".npy")
+            # the integers in point order, by the same lines (:107-137) through the reference's cart2spher
+            _, bin2, q, _ = quantise_like_proc_pc(xyz, qs, "spher")
+            q = np.asarray(q)
+            assert bin2 == bin_num and np.array_equal(q, q.astype(np.int32))
+            _, idx = np.unique(q, axis=0, return_index=True)
+            codes, tree, lmax, idxs = RO.mullevel_gen_octree(q[np.sort(idx)], morton_path=mpath)
+            rec_d = RO.gen_K_parent_seq_mullevel(tree, 4)
+            rec2 = np.concatenate((rec_d["Seq"][:, :, True], rec_d["Level"], rec_d["Pos"]), axis=2)
+            assert np.array_equal(rec, rec2), "quantise_like_proc_pc does not reproduce mul_proc_pc's records"
+            shells.append(dict(qs=qs, bin_num=float(bin_num), leaves=int(len(idxs)), D=int(lmax), records=int(len(rec)),
+                               codes_sha=sha(np.array(codes, np.uint8)), krec_sha_i32=sha(rec.astype(np.int32)),
+                               per_level=[len(l.node) for l in tree], quant_pc_sha_f64=sha(np.asarray(quant_pc, np.float64))))
+            ints[f"q_spher_ford_L{L + k}"] = np.ascontiguousarray(q.astype(np.int32))
+            print("   F17-m", mpath, shells[-1]["records"], shells[-1]["per_level"])
+    facts["F17-m"] = shells
+    with open(path_json, "w") as f:
+        json.dump(facts, f, indent=1)
+    save("frame_ints", **ints)
+
+
 GROUPS = {"trainset": gen_trainset, "metrics": gen_metrics, "keys": gen_keys, "xform": gen_xform, "oct": gen_oct, "ctx": gen_ctx, "logits": gen_logits, "logits_tiefree": gen_logits_tiefree, "swin": gen_swin,
           "cdf": gen_cdf, "ac": gen_ac, "e2e": gen_e2e, "e2e_octattn_mul": gen_e2e_octattn_mul, "facts": gen_facts, "frame_ints": gen_frame_ints,
-          "logits_full": gen_logits_full}
+          "logits_full": gen_logits_full, "facts_ford": gen_facts_ford}
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

@@ -577,35 +577,59 @@ def test_octattn_sequential_mode_vs_oracle(orc):
 # ----------------------------------------------------------------------------------------------- BASELINE.json configs[3] / [4] at full size
 @pytest.mark.gpu
 def test_ford_like_L17_mullevel_full_frame(enc_parts, orc):
-    """Ford-like frame (integer millimetres), level 17, --spher --mullevel (qs 2, 1, 0.5 mm), 760 k nodes.
-    Stage G on the oracle's integers must reproduce the oracle's three code streams bit for bit; the whole frame encodes
-    deterministically and every shell's node count equals the oracle's."""
+    """SURVEY 8d config (4) = BASELINE configs[3]: Ford-like frame (integer millimetres), level 17, --spher --mullevel (qs 2, 1, 0.5 mm),
+    760 571 coded nodes.  PINNED AGAINST THE REFERENCE (round 6): tests/golden/frame_ints.npz `q_spher_ford_L17/18/19` and
+    frame_facts.json["F17-m"] come from the reference's own `mul_proc_pc` run on this frame (make_golden.py facts_ford).
+    * stage G on the reference's integers: depth, leaves, records, node counts per level, sha256 of the occupancy stream and of the
+      [N,4,6] K-records of all three shells = what the reference's builders produced;
+    * strict-identity mode (host transform) produces exactly those integers from the floats: 0 differing points, same byte stream;
+    * the device transform differs for at most a handful of points; the frame encodes deterministically."""
+    import hashlib
+    import json
+    from conftest import GOLDEN, parity_record
     from scp_amd.encoder import FrameEncoder
     from scp_amd.synth import ford_like, synth_frame
     model, dev = enc_parts
     xyz = ford_like(synth_frame(0))
     L = 17
+    facts = json.load(open(os.path.join(GOLDEN, "frame_facts.json")))["F17-m"]
+    z = golden("frame_ints")
+    ref_q = [np.ascontiguousarray(z[f"q_spher_ford_L{L + k}"]) for k in range(3)]
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
     enc = FrameEncoder(model, "ford", L, spher=True, mullevel=True, device=dev)
-    ints, shells = [], orc.mullevel_shells(xyz, L, "spher", data_type="ford")
-    for k in range(3):
-        _, bin_num, _, _, pt = orc.quantise(xyz, orc.ford_qs(L + k), "spher", cart_offset=0)
-        ints.append(torch.from_numpy(pt.astype(np.int32)).to(dev))
-        if k == 0:
-            bin0 = bin_num
+    ints = [torch.from_numpy(q).to(dev) for q in ref_q]
+    bin0 = facts[0]["bin_num"]
     pre = enc.preprocess_ints(ints, bin0, 0.0, xyz.shape[0])
     occ = enc.geom.nodes(("occ",))["occ"].cpu().numpy()
     total = 0
-    for k, sh in enumerate(shells):
+    for k, f in enumerate(facts):
         i = enc.geom.info[k]
-        assert i.n_nodes == sh["tree"].n and enc.geom.rows(k) == sh["records"].shape[0]
-        assert np.array_equal(occ[i.node_base:i.node_base + i.n_nodes], sh["tree"].codes)
-        total += sh["records"].shape[0]
-    assert pre["ctx"].shape[0] == total and total > 700_000
-    print("F17-m nodes per shell:", [s["records"].shape[0] for s in shells])
+        assert i.depth == f["D"] and i.n_leaves == f["leaves"] and enc.geom.rows(k) == f["records"] and i.n_nodes == f["records"] + 1, k
+        assert enc.geom.level_counts(k) == f["per_level"], k
+        assert sha(occ[i.node_base:i.node_base + i.n_nodes]) == f["codes_sha"], k
+        assert sha(enc.geom.krecords(k).cpu().numpy().astype(np.int32)) == f["krec_sha_i32"], k
+        total += f["records"]
+    assert pre["ctx"].shape[0] == total == 760571
+    # the oracle agrees with the reference on this frame too (its integers from the floats: same shells)
+    shells = orc.mullevel_shells(xyz, L, "spher", data_type="ford")
+    assert [s["records"].shape[0] for s in shells] == [f["records"] for f in facts]
     r1 = enc.encode_ints(ints, bin0, 0.0, xyz.shape[0])
     r2 = enc.encode_ints(ints, bin0, 0.0, xyz.shape[0])
     assert r1["bytes"] == r2["bytes"] and r1["n_nodes"] == total and 0 < r1["bpp"] < 64
+    # strict-identity mode: the reference's float -> integer arithmetic on the host, from the floats
+    encs = FrameEncoder(model, "ford", L, spher=True, mullevel=True, device=dev, host_transform=True)
+    hq, infos = encs.host_ints(xyz)
+    ndiff = [int((np.asarray(a) != b).any(1).sum()) for a, b in zip(hq, ref_q)]
+    parity_record("host_transform/F17-m", points=len(xyz), points_differing_from_reference_ints=sum(ndiff))
+    assert ndiff == [0, 0, 0] and infos[0].bin_num == bin0
+    rs = encs.encode(xyz)
+    assert rs["bytes"] == r1["bytes"] and rs["n_nodes"] == total
     # the device quantiser on the same frame: same shells up to the float -> int boundary points
+    dq = enc.quantize(torch.from_numpy(xyz).to(dev))[0]
+    ddiff = [int((q.cpu().numpy() != b).any(1).sum()) for q, b in zip(dq, ref_q)]
+    parity_record("device_transform/F17-m", points=len(xyz), points_differing_from_reference_ints=sum(ddiff))
+    print("F17-m nodes per shell:", [f["records"] for f in facts], "device-transform points differing per shell:", ddiff)
+    assert sum(ddiff) <= 64, ddiff
     r3 = enc.encode(xyz)
     assert abs(r3["n_nodes"] - total) < 0.01 * total
 
@@ -720,6 +744,28 @@ def test_degenerate_frames_roundtrip(enc_parts, case, spher):
     assert np.array_equal(torch.cat(codes).cpu().numpy(), occ)
     assert np.array_equal(leaves.cpu().numpy(), enc.geom.leaves(0).cpu().numpy())
     assert res["n_points"] == len(xyz) and res["bits"] == 8 * len(res["bytes"])
+
+
+@pytest.mark.gpu
+def test_mullevel_one_leaf_shells_roundtrip(enc_parts):
+    """Three points, one per rho shell: every shell's octree is one chain whose last level holds only the dropped node (n == 1,
+    symbol unknown, no children: `native.decode_expand` with m == 0).  The decoder regenerates the leaves of all three shells."""
+    from oracle import scp_oracle as orc
+    from scp_amd.decoder import FrameDecoder
+    from scp_amd.encoder import FrameEncoder
+    model, dev = enc_parts
+    xyz = np.array([[r * 0.8, r * 0.6, -1.0] for r in (5, 30, 70)], np.float32)
+    shells = orc.mullevel_shells(xyz, 12, "spher")
+    assert [s["tree"].n - s["records"].shape[0] for s in shells] == [1, 1, 1] and all(s["tree"].n == s["tree"].depth for s in shells)
+    enc = FrameEncoder(model, "kitti", 12, spher=True, mullevel=True, device=dev)
+    res = enc.encode(xyz)
+    out = FrameDecoder(model, 12, mullevel=True, polar=True, device=dev).decode(res["bytes"], res["n_levels"], res["pos_mm"])
+    assert len(out) == 3
+    for k, (codes, leaves) in enumerate(out):
+        occ = shells[k]["tree"].occ
+        got = torch.cat(codes).cpu().numpy()
+        assert np.array_equal(got[:-1], occ[:-1]) and got[-1] == 0            # the dropped node's occupancy is never coded
+        assert leaves.shape[0] == 0                                            # ... so its leaf is not regenerated (decode_ehem_mullevel.py:100-130)
 
 
 @pytest.mark.gpu

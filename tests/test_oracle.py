@@ -75,6 +75,32 @@ def test_full_size_frames_vs_reference_checksums(orc):
         assert sha(t.occ) == f["codes_sha"] and sha(t.krecords(True).astype(np.int32)) == f["krec_sha_i32"]
 
 
+def test_ford_L17_mullevel_frame_vs_reference_checksums(orc):
+    """BASELINE configs[3] at full size: the Ford-like frame (integer millimetres), level 17 --spher --mullevel (qs 2 / 1 / 0.5 mm).
+    frame_facts.json["F17-m"] / frame_ints.npz q_spher_ford_L17..19 were written by running the reference's own `mul_proc_pc`
+    (data_preprocess.py:95-167 with the arguments of encode_dataset_ehem_mullevel.py:154-186, data_type 'ford'; make_golden.py facts_ford).
+    The oracle's quantiser must produce those integers from the floats (0 differing points: the Ford values are whole millimetres, the
+    square root is exact up to float32 rounding and only arctan2 / arccos carry numpy's SIMD behaviour of the generating container - the
+    count is asserted), and from the reference's integers the oracle's octree gives the reference's code streams and records."""
+    from scp_amd.synth import ford_like, synth_frame
+    facts = json.load(open(os.path.join(GOLDEN, "frame_facts.json")))["F17-m"]
+    z = golden("frame_ints")
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    xyz = ford_like(synth_frame(0))
+    for k, path in enumerate(([0, 0], [0, 1], [1])):
+        f = facts[k]
+        q = z[f"q_spher_ford_L{17 + k}"]
+        assert f["qs"] == orc.ford_qs(17 + k)
+        _, bin_num, _, _, pt = orc.quantise(xyz, orc.ford_qs(17 + k), "spher", cart_offset=0)
+        assert bin_num == f["bin_num"]
+        ndiff = int((pt.astype(np.int32) != q).any(1).sum())
+        assert ndiff <= 8, (k, ndiff)                  # numpy float32 arctan2 / arccos are CPU dependent (DESIGN 2.1); 0 in the build container
+        _, idx = np.unique(q, axis=0, return_index=True)
+        t = orc.octree_build(q[np.sort(idx)], path)
+        assert t.n == f["records"] + 1 and t.depth == f["D"] and np.bincount(t.level)[1:].tolist() == f["per_level"]
+        assert sha(t.occ) == f["codes_sha"] and sha(t.krecords(True).astype(np.int32)) == f["krec_sha_i32"]
+
+
 def test_octree_depth0_is_an_error(orc):
     with pytest.raises(ValueError):
         orc.octree_build(np.zeros((1, 3), np.int64))
