@@ -291,6 +291,15 @@ SCP_API int scp_linear_split(const void *Ahi, const void *Alo, int64_t lda, cons
 SCP_API int scp_linear_split_gather(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
                             const float *bias, const float *residual, int64_t ldr, const int64_t *res_map, float *C, int64_t ldc, void *Ohi,
                             void *Olo, int64_t ldo, int32_t M, int32_t N, int32_t K, int32_t act, int32_t cfg, void *stream);
+/* round 6: the two FINEST stages of such a layer in one launch (models/ehem.py:75-86,100-136: concat_states feeding ancient_mlp / prob_pred_mlp2):
+ *   out[m] = act(A0[m] . W0^T + A1[parent[m]] . W1^T + bias + res[res_map[m]])  as split planes,
+ * parent[m] = the stage-1 row of stage-0 row m (token t -> token t >> 1 of the same window; consecutive inside a 256-row tile), A1 with 256 columns,
+ * M % 256 == 0, N % 4 == 0, weights as tiled planes.  The stage-1 product never exists in memory (it is computed per tile and stays in the
+ * accumulators); summation order of an element: stage-1 k ascending, stage-0 k ascending, + bias, + residual. */
+SCP_API int scp_linear_split_hier2(const void *A0hi, const void *A0lo, int64_t lda0, int32_t K0pad, const void *A1hi, const void *A1lo, int64_t lda1,
+                                   int64_t M1, const void *W0hi, const void *W0lo, const void *W1hi, const void *W1lo, int32_t Npad,
+                                   const int64_t *parent, const float *bias, const float *res, int64_t ldr, const int64_t *res_map, void *Ohi,
+                                   void *Olo, int64_t ldo, int32_t M, int32_t N, int32_t act, void *stream);
 /* scp_linear_split with SCATTERED fp32 output rows: row m goes to C row out_map[m] (negative: dropped). */
 SCP_API int scp_linear_split_scatter(const void *Ahi, const void *Alo, int64_t lda, const void *Whi, const void *Wlo, int32_t Npad, int32_t Kpad,
                              const float *bias, const int64_t *out_map, float *C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act,

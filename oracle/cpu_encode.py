@@ -30,11 +30,10 @@ def cpu_model_name():
 def _full_window_cost(full_times, sampled, warmup):
     """The cost that stands for every full window of a SAMPLED run: the first `warmup` runs are dropped (thread pool, allocator and
     caches settle over the first windows: 2.1 - 2.2 s against 1.6 - 1.8 s later in a full-frame run, profiles/r5_bench_cpu_full.json);
-    with five or more timed runs left the MEDIAN is used, with fewer the fastest (the choice that favours the CPU)."""
+    the FASTEST of the remaining runs is used (the choice that favours the CPU: window times keep falling over the first dozen windows of
+    a run, so even the minimum of windows 5 - 10 is above the settled cost of a whole-frame run)."""
     use = full_times[warmup:] if sampled and len(full_times) > warmup else full_times
-    if not use:
-        return 0.0
-    return float(np.median(use)) if len(use) >= 5 else float(np.min(use))
+    return float(np.min(use)) if use else 0.0
 
 
 def encode_frame(xyz, sd, level, mullevel=True, mode="spher", full_window_runs=None, context_size=8192, data_type="kitti", full_window_warmup=1):

@@ -373,6 +373,272 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The two FINEST stages of a layer over concat_states (ehem.py:75-86,100-136) in ONE launch (round 6).
+//
+//     out[t] = act(A0[t] . W0^T + A1[t >> 1] . W1^T + bias + res[res_map[t]])
+//
+// Until round 5 the stage-1 product left as an fp32 [M / 2][N] partial sum that the stage-0 launch read back through the parent map:
+// both launches were HBM-bound on that intermediate (4 KB written per stage-1 row, 2 KB read per stage-0 row, N = 1024).  Here a
+// 256-token tile computes the products of its OWN 128 parents first and keeps them in the accumulators:
+//   * the tile's tokens are dealt to the MFMA rows so that a parent and its two children share (lane, register): token tau of a
+//     wave's 128 (tau = 4 rr + i) sits in row rr of row tile i = tau & 3; parent p = tau >> 1 = 2 rr + (i >> 1) sits in row rr of
+//     parent tile i >> 1.  The permutation costs nothing: LDS-DMA takes a per-lane source address, the epilogue computes the row.
+//   * coarse phase (K = 256 of stage 1): row tiles 0, 1 of the wave = its parent tiles, 24 MFMAs per k-step;
+//   * acc[3] = acc[2] = parent tile 1, acc[1] = acc[0] = parent tile 0 (register copies), then the stage-0 product continues the
+//     four chains.  Summation order of an output element: stage-1 k ascending, then stage-0 k ascending (+ bias, + residual): the
+//     same for every row whatever the launch holds (batch invariance).
+// 6 block-products per tile instead of 4 + 2 in two launches, no intermediate, one epilogue; K depth 512 - 768 instead of 256.
+// Rows of window padding (parent map entry arbitrary) produce finite garbage nobody reads, as before.
+struct GemmHierArgs {
+    const __bf16 *A0hi, *A0lo; int64_t lda0; int K0pad;     // stage-0 planes [M][lda0] (K0pad % 32 == 0)
+    const __bf16 *A1hi, *A1lo; int64_t lda1; int64_t M1;    // stage-1 planes [M1][lda1], K = 256
+    const __bf16 *W0hi, *W0lo, *W1hi, *W1lo;                // tiled weight planes [Npad][K0pad], [Npad][256]
+    const int64_t *parent;                                  // [M]: stage-1 row of stage-0 row m
+    const float *bias;                                      // [N] or null
+    const float *res; int64_t ldr; const int64_t *res_map;  // optional fp32 residual rows res[res_map[m]] (the coarser stages' partial sum)
+    __bf16 *Ohi, *Olo; int64_t ldo;                         // split output planes [M][ldo]
+    int M, N;
+};
+
+template <int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_hier2_kernel(const GemmHierArgs a) {
+    constexpr int WN = 4, TM = 4, TN = 2, NW = 8, HM = 2;
+    constexpr int BM = 256, BN = 256;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int MAPOFF = 2 * STAGE;
+    constexpr int OFF_AL = BM * 64, OFF_BH = 2 * BM * 64, OFF_BL = 2 * BM * 64 + BN * 64;
+    constexpr int NK1 = 8;                                  // k-steps of the coarse phase (K = 256)
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w / WN, wn = w % WN;
+    const int nk0 = a.K0pad >> 5, nkt = NK1 + nk0;
+    const int tn = (a.N + BN - 1) / BN, tm = (a.M + BM - 1) / BM;
+    const int ntiles = tn * tm;
+    const int d_row = lane >> 2;
+    const int d_q = (lane & 3) ^ ((lane >> 4) & 3);
+    const int f_pos0 = (h ^ ((lane >> 2) & 3)) << 4;
+
+    auto tile_coords = [&](int t, int &m0, int &n0) {       // the XCD-aware order of gemm_split_kernel
+        const int g = gridDim.x;
+        const int round = t / g, b = t - round * g;
+        int lin = t;
+        if ((g & 7) == 0 && (round + 1) * g <= ntiles) lin = round * g + (b & 7) * (g >> 3) + (b >> 3);
+        m0 = (lin / tn) * BM;
+        n0 = (lin % tn) * BN;
+    };
+    // LDS row R of the A tile (row tile i = (R >> 5) & 3 of wave-row group R >> 7, row rr = R & 31):
+    //   fine phase: token m0 + 128 (R >> 7) + 4 rr + i;   coarse phase (i < 2): parent row pb + 64 (R >> 7) + 2 rr + i
+    auto stage_issue = [&](int st, int m0, int n0, int64_t pb, int kt) {
+        char *base = smem + st * STAGE;
+        const bool coarse = kt < NK1;
+        const int ks = coarse ? kt : kt - NK1;
+        const int k0 = ks * 32 + 8 * d_q;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cr = w + NW * j;                      // 16-row chunk of the plane; its row tile: (cr >> 1) & 3 = (w >> 1) & 3
+            const int R = 16 * cr + d_row, rr = R & 31, it = (R >> 5) & 3, g = R >> 7;
+            if (coarse) {
+                if (w < 4) {                                // wave-uniform: only the parent tiles are filled
+                    int64_t r1 = pb + 64 * g + 2 * rr + it;
+                    r1 = r1 < a.M1 ? r1 : a.M1 - 1;
+                    const int64_t off = r1 * a.lda1 + k0;
+                    dma16(a.A1hi + off, base + cr * 1024);
+                    dma16(a.A1lo + off, base + OFF_AL + cr * 1024);
+                }
+            } else {
+                int m = m0 + 128 * g + 4 * rr + it;
+                m = m < a.M ? m : a.M - 1;
+                const int64_t off = (int64_t)m * a.lda0 + k0;
+                dma16(a.A0hi + off, base + cr * 1024);
+                dma16(a.A0lo + off, base + OFF_AL + cr * 1024);
+            }
+        }
+        const __bf16 *Wh = coarse ? a.W1hi : a.W0hi, *Wl = coarse ? a.W1lo : a.W0lo;
+        const int nks = coarse ? NK1 : nk0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cr = w + NW * j;
+            const int64_t off = ((int64_t)((n0 >> 4) + cr) * nks + ks) * 512 + lane * 8;
+            dma16(Wh + off, base + OFF_BH + cr * 1024);
+            dma16(Wl + off, base + OFF_BL + cr * 1024);
+        }
+    };
+    auto parent_of = [&](int m0) { return a.parent[m0 < a.M ? m0 : a.M - 1]; };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int m0, n0;
+    tile_coords(tile, m0, n0);
+    int64_t pb = parent_of(m0);
+    stage_issue(0, m0, n0, pb, 0);
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        bf16x8 Ah[2][HM], Al[2][HM], Bh[2][TN], Bl[2][TN];
+        const int fa = (wm * (TM * 32) + col) * 64, fb = OFF_BH + (wn * 64 + col) * 64;
+        auto load_b = [&](int buf, int sbo, int kc) {
+            const int ob = sbo + fb + (f_pos0 ^ (kc * 32));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                Bh[buf][j] = *(const bf16x8 *)(smem + ob + j * 2048);
+                Bl[buf][j] = *(const bf16x8 *)(smem + ob + (OFF_BL - OFF_BH) + j * 2048);
+            }
+        };
+        auto load_a = [&](int buf, int sbo, int kc, int p) {
+            const int oa = sbo + fa + (f_pos0 ^ (kc * 32)) + p * (HM * 2048);
+#pragma unroll
+            for (int i = 0; i < HM; ++i) {
+                Ah[buf][i] = *(const bf16x8 *)(smem + oa + i * 2048);
+                Al[buf][i] = *(const bf16x8 *)(smem + oa + OFF_AL + i * 2048);
+            }
+        };
+        auto mfma_sub = [&](int ab, int bb, int p) {         // same order of the three partial products as gemm_split_kernel: lo.hi, hi.lo, hi.hi
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[p * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[ab][i], Bh[bb][j], acc[p * HM + i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[p * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ab][i], Bl[bb][j], acc[p * HM + i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[p * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[ab][i], Bh[bb][j], acc[p * HM + i][j], 0, 0, 0);
+        };
+        // step kt is in stage kt & 1; behind its barrier the DMA of step kt + 1 has landed, step kt + 2 may overwrite the current stage and the
+        // first fragments of step kt + 1 are read ((kc 0, row tiles 0 - 1): the first sub-phase of either kind of step)
+        auto turn = [&](int kt) {
+            if (kt + 1 < nkt) {
+                SCP_WAIT_DMA(0);
+                __syncthreads();
+                if (kt + 2 < nkt) stage_issue(kt & 1, m0, n0, pb, kt + 2);
+                const int sbn = STAGE - (kt & 1) * STAGE;
+                load_b(0, sbn, 0);
+                load_a(0, sbn, 0, 0);
+            }
+        };
+
+        SCP_WAIT_DMA(0);
+        __syncthreads();   // DMA of step 0 landed; every wave is past the previous tile's epilogue
+        stage_issue(1, m0, n0, pb, 1);
+        {   // the tile's residual row map -> LDS (latency hidden by the k loop), indexed by token offset
+            int64_t *mapbuf = (int64_t *)(smem + MAPOFF);
+            if (tid < BM && a.res_map) mapbuf[tid] = a.res_map[m0 + tid < a.M ? m0 + tid : a.M - 1];
+        }
+        load_b(0, 0, 0);
+        load_a(0, 0, 0, 0);
+        // ---- coarse phase: the tile's 128 parents (two row tiles per wave), K = 256 of stage 1 ---------------------------
+        for (int kt = 0; kt < NK1; ++kt) {
+            const int sbo = (kt & 1) * STAGE;
+            load_b(1, sbo, 1);
+            load_a(1, sbo, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_sub(0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            turn(kt);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_sub(1, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // parent tile 1 -> row tiles 2, 3; parent tile 0 -> row tiles 0, 1
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { acc[3][j] = acc[1][j]; acc[2][j] = acc[1][j]; acc[1][j] = acc[0][j]; }
+        // ---- fine phase: the stage-0 product continues the four chains (the k loop of gemm_split_kernel) ---------------------
+        for (int kt = NK1; kt < nkt; ++kt) {
+            const int sbo = (kt & 1) * STAGE;
+            load_a(1, sbo, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_sub(0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(1, sbo, 1);
+            load_a(0, sbo, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_sub(1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(1, sbo, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_sub(0, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            turn(kt);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_sub(1, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        SCP_WAIT_DMA(0);
+        __syncthreads();   // every wave is done with both stages
+        const int cm0 = m0, cn0 = n0;
+        if (tile + (int)gridDim.x < ntiles) {   // first step of the next tile: in flight during the epilogue (stage 0)
+            tile_coords(tile + gridDim.x, m0, n0);
+            pb = parent_of(m0);
+            stage_issue(0, m0, n0, pb, 0);
+        }
+
+        // ---- epilogue through this wave's private 8 KiB slice of stage 1: act(acc + bias + residual) -> hi / lo planes ---------
+        float *stg = (float *)(smem + STAGE + w * 8192);
+        float bv[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = cn0 + wn * 64 + j * 32 + col;
+            bv[j] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+        }
+        const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+        const int nb = cn0 + wn * 64 + c4;
+        const bool colsok = nb < a.N;                        // N % 4 == 0 (launcher): a lane's four columns are real or not together
+        const bool has_res = a.res != nullptr;
+        const int64_t *mapbuf = (const int64_t *)(smem + MAPOFF);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int tb = wm * 128 + i;                     // token offset of row rr of this row tile: tb + 4 rr
+            f32x4 rr4[8];
+            if (has_res && colsok) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int t = tb + 4 * (4 * it + rsub);
+                    const int m = cm0 + t < a.M ? cm0 + t : a.M - 1;
+                    const int64_t rrow = a.res_map ? mapbuf[m - cm0] : (int64_t)m;
+                    rr4[it] = *(const f32x4 *)(a.res + rrow * a.ldr + nb);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    stg[ml * 64 + j * 32 + col] = acc[i][j][r] + bv[j];
+                }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int m = cm0 + tb + 4 * (4 * it + rsub);
+                f32x4 y = *(const f32x4 *)(stg + (4 * it + rsub) * 64 + c4);
+                if (has_res && colsok) y += rr4[it];
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float v = colsok ? apply_act_s<ACT>(y[u]) : 0.f;
+                    const __bf16 hh = (__bf16)v;
+                    hi[u] = hh;
+                    lo[u] = (__bf16)(v - (float)hh);
+                }
+                if (m < a.M && nb < a.ldo) {
+                    *(bf16x4 *)(a.Ohi + (int64_t)m * a.ldo + nb) = hi;
+                    *(bf16x4 *)(a.Olo + (int64_t)m * a.ldo + nb) = lo;
+                }
+            }
+        }
+        // the next tile's first barrier orders these LDS reads before the DMA that refills stage 1
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // fp32 rows -> hi/lo planes, optionally gathered: out[r][0:C] = split(src[idx ? idx[r] : r][0:C]); idx == n_src -> zero row
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ src, int64_t lds_, int64_t n_src, const int64_t *__restrict__ idx,
                                                         int C4, int Cp4, __bf16 *__restrict__ hi, __bf16 *__restrict__ lo, int64_t ldo, int64_t total) {
@@ -605,4 +871,49 @@ extern "C" SCP_API int scp_linear_split_scatter(const void *Ahi, const void *Alo
     if (!out_map || !C) return SCP_EINVAL;
     return linear_split_impl(Ahi, Alo, lda, Whi, Wlo, Npad, Kpad, bias, nullptr, 0, nullptr, 0, out_map, C, ldc, nullptr, nullptr, 0, M, N, K, act, cfg,
                              stream);
+}
+
+// out = act(A0 . W0^T + A1[parent] . W1^T + bias + res[res_map]) as split planes: the two finest stages of a layer over concat_states in one launch
+// (gemm_hier2_kernel).  A0: planes [M][lda0] with K0pad in {256, 512} columns, A1: planes [M1][lda1] with 256 columns, W0 / W1: tiled weight planes
+// [Npad][K0pad] / [Npad][256] (scp_split_weight_bf16 + scp_tile_weight_bf16), parent: int64 [M], res: fp32 rows (optional, gathered through res_map when given),
+// act: 0 none, 1 LeakyReLU(0.01).  M % 256 == 0 (rows of the packed layout come in 512s), N % 4 == 0, Npad % 256 == 0.
+extern "C" SCP_API int scp_linear_split_hier2(const void *A0hi, const void *A0lo, int64_t lda0, int32_t K0pad, const void *A1hi, const void *A1lo, int64_t lda1,
+                                              int64_t M1, const void *W0hi, const void *W0lo, const void *W1hi, const void *W1lo, int32_t Npad,
+                                              const int64_t *parent, const float *bias, const float *res, int64_t ldr, const int64_t *res_map, void *Ohi,
+                                              void *Olo, int64_t ldo, int32_t M, int32_t N, int32_t act, void *stream) {
+    if (!A0hi || !A0lo || !A1hi || !A1lo || !W0hi || !W0lo || !W1hi || !W1lo || !parent || !Ohi || !Olo || M <= 0 || (M & 255) || M1 <= 0 || N <= 0 || (N & 3) ||
+        (Npad & 255) || Npad < N || K0pad < 32 || (K0pad & 31) || lda0 < K0pad || (lda0 & 7) || lda1 < 256 || (lda1 & 7) || ldo < N || (ldo & 7) ||
+        (act != ACT_NONE && act != ACT_LEAKY) || (res && (ldr < N || (ldr & 3) || ((uintptr_t)res & 15))) || (!res && res_map) ||
+        (((uintptr_t)A0hi | (uintptr_t)A0lo | (uintptr_t)A1hi | (uintptr_t)A1lo | (uintptr_t)W0hi | (uintptr_t)W0lo | (uintptr_t)W1hi | (uintptr_t)W1lo) & 15) ||
+        (((uintptr_t)Ohi | (uintptr_t)Olo) & 7))
+        return SCP_EINVAL;
+    if (!g_num_cu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipGetDeviceProperties(&p, dev));
+        g_num_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }
+    constexpr int LDS = 2 * (256 + 256) * 128 + 256 * 8;
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_hier2_kernel<ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIP_TRY(hipFuncSetAttribute((const void *)gemm_hier2_kernel<ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        configured = true;
+    }
+    GemmHierArgs a;
+    a.A0hi = (const __bf16 *)A0hi; a.A0lo = (const __bf16 *)A0lo; a.lda0 = lda0; a.K0pad = K0pad;
+    a.A1hi = (const __bf16 *)A1hi; a.A1lo = (const __bf16 *)A1lo; a.lda1 = lda1; a.M1 = M1;
+    a.W0hi = (const __bf16 *)W0hi; a.W0lo = (const __bf16 *)W0lo; a.W1hi = (const __bf16 *)W1hi; a.W1lo = (const __bf16 *)W1lo;
+    a.parent = parent; a.bias = bias; a.res = res; a.ldr = ldr; a.res_map = res ? res_map : nullptr;
+    a.Ohi = (__bf16 *)Ohi; a.Olo = (__bf16 *)Olo; a.ldo = ldo; a.M = M; a.N = N;
+    const int64_t ntiles = cdiv64(M, 256) * cdiv64(N, 256);
+    const unsigned grid = (unsigned)(ntiles < g_num_cu ? ntiles : g_num_cu);
+    hipStream_t st = (hipStream_t)stream;
+    // algorithmic flops: the stage-0 product at M rows + the stage-1 product at M / 2 rows
+    SCP_PROF(SCP_PROF_GEMM_SPLIT, st, 2.0 * M * (double)N * (K0pad + 128.0));
+    if (act == ACT_LEAKY) hipLaunchKernelGGL(gemm_hier2_kernel<ACT_LEAKY>, dim3(grid), dim3(512), LDS, st, a);
+    else hipLaunchKernelGGL(gemm_hier2_kernel<ACT_NONE>, dim3(grid), dim3(512), LDS, st, a);
+    LAUNCH_CHECK();
+    return SCP_OK;
 }

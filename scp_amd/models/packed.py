@@ -258,7 +258,11 @@ def _concat(hs, cmaps, extra=None):
 HIER = True
 
 
-def _concat_layer(lin, hs, parents, extra=None):
+# False (tests, A/B): stages 0 and 1 of a layer over concat_states as two launches with an fp32 partial sum between them (rounds 1 - 5)
+FUSE2 = True
+
+
+def _concat_layer(lin, hs, parents, extra=None, grand=None):
     """LeakyReLU(Linear(concat_states(hs))) (ehem.py:75-86 + the first layer of the MLP that consumes it) WITHOUT building the
     concatenation: the layer's weight is cut into one 256-column slab per Swin stage, stage s contributes h_s . W_s^T at its OWN
     resolution (rows / 2^s), and the partial sums flow from the coarsest stage down through the parent-row maps (token t of stage s
@@ -273,17 +277,25 @@ def _concat_layer(lin, hs, parents, extra=None):
             slabs[0] = torch.cat((slabs[0], W[:, 256 * n:256 * (n + 1)]), 1).contiguous()
         return slabs
     cache = derived(lin, "slabs+" if extra is not None else "slabs", (lin.weight,), build)
+    fused = FUSE2 and n >= 3 and grand is not None and native.WTILE and hs[1].shape[0] % 256 == 0
     z = None
-    for s in range(n - 1, 0, -1):
+    for s in range(n - 1, 1 if fused else 0, -1):
         z = linear_s(native.split_rows(hs[s + 1]), cache[s], None, residual=z, res_map=None if z is None else parents[s], res_first=z is not None)
     a0 = native.split_rows(hs[1]) if extra is None else split_cat((hs[1], extra))
+    if fused:
+        # round 6: stages 0 and 1 in ONE launch - the stage-1 product of a 256-token tile's own 128 parents stays in the accumulators
+        # (csrc/gemm_split.hip: gemm_hier2_kernel); z = the partial sum of stages 2 .. n - 1 at stage-2 resolution, gathered through `grand`
+        from ..ops import _split
+        return native.linear_split_hier2(a0, _split(cache[0]), native.split_rows(hs[2]), _split(cache[1]), parents[0], lin.bias, native.ACT_LEAKY,
+                                         residual=z, res_map=grand)
     return linear_s(a0, cache[0], lin.bias, act="leaky", residual=z, res_map=None if z is None else parents[0], res_first=z is not None,
                     want="split")
 
 
-def _mlp_over_concat(seq, hs, parents, extra=None):
-    """leaky_mlp3 over concat_states: hierarchical first layer, then the two remaining layers on split activations."""
-    a = _concat_layer(seq[0], hs, parents, extra)
+def _mlp_over_concat(seq, hs, parents, extra=None, grand=None):
+    """leaky_mlp3 over concat_states: hierarchical first layer, then the two remaining layers on split activations.
+    grand: stage-2 row of every stage-0 row (plan `self_concat[1]` / `cross_concat[1]`) - enables the fused two-stage launch."""
+    a = _concat_layer(seq[0], hs, parents, extra, grand)
     a = linear_s(a, seq[2].weight, seq[2].bias, act="leaky", want="split")
     return linear_s(a, seq[4].weight, seq[4].bias)
 
@@ -336,7 +348,7 @@ def ehem_phase1_packed(model, ctx, pos, plan, table=None):
                  lambda: native.EdgeMlpWeights(g.edge_mlp1, g.edge_mlp2))
     native.geo_edge_mlps(pos1, pos2, pos3, ew, feat[:, nx:])
     hs = _encoder(model.swin_self_transformer, feat, d["self_valid"], d["self_tab"], d["self_merge"], tiles=d.get("self_tiles"))
-    feat_a = _mlp_over_concat(model.ancient_mlp, hs, d["self_parent"]) if HIER else leaky_mlp3_s(model.ancient_mlp, _concat(hs, d["self_concat"]))
+    feat_a = _mlp_over_concat(model.ancient_mlp, hs, d["self_parent"], grand=d["self_concat"][1]) if HIER else leaky_mlp3_s(model.ancient_mlp, _concat(hs, d["self_concat"]))
     Q0 = d["a1map"].shape[0]
     a1 = native.split_rows(feat_a, idx=d["a1map"])
     a2 = native.gather_rows(feat_a, d["a2map"], torch.empty((Q0, 256), dtype=torch.float32, device=dev))
@@ -400,12 +412,12 @@ def ehem_phase2_packed(model, st, plan, pre_occ=None, table=None, prep=None):
     hc = _encoder(model.swin_cross_transformer, pre, d["cross_valid"], d["cross_tab"], d["cross_merge"], query=a2, tiles=d.get("cross_tiles"),
                   q_pre=None if prep is None else prep["q"])
     if table is not None:
-        a = _concat_layer(model.prob_pred_mlp2[0], hc, d["cross_parent"], a2) if HIER else linear_s(_concat(hc, d["cross_concat"], extra=(a2, None)), model.prob_pred_mlp2[0].weight, model.prob_pred_mlp2[0].bias, act="leaky", want="split")
+        a = _concat_layer(model.prob_pred_mlp2[0], hc, d["cross_parent"], a2, d["cross_concat"][1]) if HIER else linear_s(_concat(hc, d["cross_concat"], extra=(a2, None)), model.prob_pred_mlp2[0].weight, model.prob_pred_mlp2[0].bias, act="leaky", want="split")
         from ..ops import _split
         a = linear_s(a, model.prob_pred_mlp2[2].weight, model.prob_pred_mlp2[2].bias, act="leaky", want="split")
         native.linear_split_scatter(a, _split(model.prob_pred_mlp2[4].weight), model.prob_pred_mlp2[4].bias, d["odd_out"], table)
         return None
-    prob2 = (_mlp_over_concat(model.prob_pred_mlp2, hc, d["cross_parent"], extra=a2) if HIER
+    prob2 = (_mlp_over_concat(model.prob_pred_mlp2, hc, d["cross_parent"], extra=a2, grand=d["cross_concat"][1]) if HIER
              else leaky_mlp3_s(model.prob_pred_mlp2, _concat(hc, d["cross_concat"], extra=(a2, None))))
     return prob2[d["odd_rows"]]
 

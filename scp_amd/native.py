@@ -132,6 +132,7 @@ def lib():
         "scp_split_rows": (C.c_int, [_vp, i64, i64, _vp, i32, _vp, _vp, i64, i64, _vp]),
         "scp_linear_split_scatter": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
         "scp_linear_split_gather": (C.c_int, [_vp, _vp, i64, _vp, _vp, i32, i32, _vp, _vp, i64, _vp, _vp, i64, _vp, _vp, i64, i32, i32, i32, i32, i32, _vp]),
+        "scp_linear_split_hier2": (C.c_int, [_vp, _vp, i64, i32, _vp, _vp, i64, i64, _vp, _vp, _vp, _vp, i32, _vp, _vp, _vp, i64, _vp, _vp, _vp, i64, i32, i32, i32, _vp]),
         "scp_layernorm_rows": (C.c_int, [_vp, i64, i64, _vp, _vp, i32, _vp, _vp, _vp, C.c_float, _vp, i64, i64, _vp]),
         "scp_layernorm_rows_split": (C.c_int, [_vp, i64, i64, _vp, _vp, i32, _vp, _vp, _vp, C.c_float, _vp, _vp, i64, i64, _vp]),
         "scp_gather_rows": (C.c_int, [_vp, i64, _vp, i32, _vp, i64, i64, _vp]),
@@ -1046,6 +1047,28 @@ def linear_split(a, sw, bias=None, act=ACT_NONE, residual=None, out=None, out_sp
                                 0 if o is None else o.t.stride(1), M, N, K, act, cfg, _stream())
     _check(rc, "scp_linear_split")
     return c if want == "f32" else (o if want == "split" else (c, o))
+
+
+def linear_split_hier2(a0, sw0, a1, sw1, parent, bias=None, act=ACT_NONE, residual=None, res_map=None, out_split=None):
+    """act(a0 . W0^T + a1[parent] . W1^T + bias + residual[res_map]) -> SplitAct [M, N]: the two finest stages of a layer over concat_states
+    (ehem.py:75-86) in ONE launch (csrc/gemm_split.hip: gemm_hier2_kernel) - the stage-1 product is computed for the tile's own parents and
+    stays in the accumulators, no fp32 partial sum of it exists.  a0: SplitAct [M, K0] (stage-0 rows, M % 256 == 0), a1: SplitAct [M1, 256]
+    (stage-1 rows), parent: int64 [M] (stage-1 row of every stage-0 row; consecutive token pairs of a window share consecutive parents),
+    residual: fp32 [*, N] rows gathered through res_map (int64 [M]) - the coarser stages' partial sum."""
+    if not WTILE:
+        raise ScpError("linear_split_hier2 reads tiled weight planes (SCP_WTILE=0 is not supported by it)")
+    M, N = a0.M, sw0.N
+    if a0.K != sw0.K or a1.K != sw1.K or sw1.K != 256 or sw1.N != N or sw1.Npad != sw0.Npad or parent.shape[0] != M:
+        raise ScpError("linear_split_hier2: operand shapes do not match")
+    o = out_split if out_split is not None else SplitAct.empty(M, N, a0.t.device)
+    t0, t1 = a0.t, a1.t
+    rc = lib().scp_linear_split_hier2(t0[0].data_ptr(), t0[1].data_ptr(), t0.stride(1), sw0.Kpad, t1[0].data_ptr(), t1[1].data_ptr(), t1.stride(1), a1.M,
+                                      sw0.tiled()[0].data_ptr(), sw0.tiled()[1].data_ptr(), sw1.tiled()[0].data_ptr(), sw1.tiled()[1].data_ptr(), sw0.Npad,
+                                      _dev(parent, torch.int64), _opt(bias), None if residual is None else residual.data_ptr(),
+                                      0 if residual is None else residual.stride(0), None if (residual is None or res_map is None) else _dev(res_map, torch.int64),
+                                      o.t[0].data_ptr(), o.t[1].data_ptr(), o.t.stride(1), M, N, act, _stream())
+    _check(rc, "scp_linear_split_hier2")
+    return o
 
 
 class LnFoldedWeight:

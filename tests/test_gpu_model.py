@@ -1106,6 +1106,67 @@ def test_hierarchical_concat_layers_equal_direct_form(dev, ehem):
     assert worst < 5e-5
 
 
+@pytest.mark.gpu
+def test_fused_two_stage_concat_layer_equals_the_two_launch_form(dev, ehem):
+    """Round 6 (csrc/gemm_split.hip: gemm_hier2_kernel): stages 0 and 1 of a layer over concat_states in one launch - the stage-1 product of a
+    256-token tile's own parents stays in the accumulators - against the two-launch form with an fp32 partial sum between them
+    (packed.FUSE2 = False): the logits differ only by fp32 summation order; and the fused form is deterministic and batch-invariant (a window's
+    rows do not depend on what else is in the launch)."""
+    from scp_amd.models import packed
+    z = golden("logits_ehem_c1024")
+    ctx = torch.from_numpy(z["data"].astype(np.int64)).to(dev).reshape(1024, 12).to(torch.uint8)
+    p = torch.from_numpy(z["pos"]).to(dev).T.contiguous()
+    lengths = [1, 7, 2, 300, 513, 1, 200]
+    try:
+        packed.FUSE2 = True
+        a = ehem.forward_packed(ctx, p, lengths)
+        a2 = ehem.forward_packed(ctx, p, lengths)
+        packed.FUSE2 = False
+        b = ehem.forward_packed(ctx, p, lengths)
+    finally:
+        packed.FUSE2 = True
+    assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
+    worst = max((a[0] - b[0]).abs().max().item(), (a[1] - b[1]).abs().max().item())
+    print(f"fused two-stage vs two-launch concat layers: max|dlogit| = {worst:.3e}")
+    assert worst < 5e-5
+    # batch invariance: the 513-token window alone gives the bits it has inside the packed launch
+    s0 = sum(lengths[:4])
+    c = ehem.forward_packed(ctx[s0:s0 + 513], p[s0:s0 + 513], [513])
+    e0 = sum((l + 1) // 2 for l in lengths[:4])
+    o0 = sum(l // 2 for l in lengths[:4])
+    assert torch.equal(c[0], a[0][e0:e0 + 257]) and torch.equal(c[1], a[1][o0:o0 + 256])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K0,N,with_res", [(256, 256, 1024, True), (512, 512, 768, True), (1024, 256, 256, False), (2560, 256, 1024, True)])
+def test_linear_split_hier2_vs_float64(dev, M, K0, N, with_res):
+    """scp_linear_split_hier2 against float64: out[m] = leaky(A0[m] . W0^T + A1[parent[m]] . W1^T + bias + res[res_map[m]]), parents of a 256-row
+    tile consecutive (token t -> t >> 1), residual rows gathered; error of a bf16x3 product chain."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(M + K0 + N)
+    a0 = torch.randn((M, K0), generator=g).to(dev)
+    M1 = M // 2 + 300
+    a1 = torch.randn((M1, 256), generator=g).to(dev)
+    w0 = (torch.randn((N, K0), generator=g) / K0 ** 0.5).to(dev)
+    w1 = (torch.randn((N, 256), generator=g) / 16).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    # every 256-row tile is a run of tokens of one window: parents consecutive from an arbitrary base
+    base = torch.randint(0, 300, (M // 256,), generator=g)
+    parent = (base[:, None] + (torch.arange(256)[None, :] >> 1)).reshape(-1).to(dev)
+    res = torch.randn((M // 4 + 7, N), generator=g).to(dev) if with_res else None
+    rmap = torch.randint(0, M // 4 + 7, (M,), generator=g).to(dev) if with_res else None
+    out = native.linear_split_hier2(native.split_rows(a0), native.SplitWeight(w0), native.split_rows(a1), native.SplitWeight(w1), parent, b,
+                                    native.ACT_LEAKY, residual=res, res_map=rmap)
+    got = out.t[0].float()[:, :N].double() + out.t[1].float()[:, :N].double()
+    want = a0.double() @ w0.double().T + a1.double()[parent] @ w1.double().T + b.double()
+    if with_res:
+        want = want + res.double()[rmap]
+    want = torch.where(want > 0, want, 0.01 * want)
+    err = (got - want).abs().max().item()
+    print(f"hier2 M={M} K0={K0} N={N}: max err {err:.3e}")
+    assert err < 2e-4          # the split output itself carries 2^-17 relative; products 1e-5 relative of sum |a||w|
+
+
 # ---------------------------------------------------------------------------------------------------------------- row-chain kernels
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N", [(1, 256), (31, 768), (128, 768), (129, 512), (1000, 256), (70001, 768)])

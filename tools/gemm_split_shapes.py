@@ -1,4 +1,5 @@
-"""The frame's gemm_split launches by shape, with the launch brackets' times: python tools/gemm_split_shapes.py"""
+"""The frame's gemm_split launches by shape, with the launch brackets' times: python tools/gemm_split_shapes.py [cfg]
+(cfg 1 / 2 / 3 forces the 256 x 256 / 256 x 128 / 128 x 128 tile on every launch that has such a variant: identical bits, different time)"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from cfgs import ehem_cfg
@@ -12,13 +13,16 @@ enc = FrameEncoder(fill_weights(EHEM(ehem_cfg()), 0).to(dev), "kitti", 16, spher
 xyz = torch.from_numpy(synth_frame(0)).to(dev)
 enc.encode(xyz); torch.cuda.synchronize()
 shapes = []
+FORCE = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 o1, o2 = native.linear_split, native.linear_split_scatter
 def w1(a, sw, bias=None, act=0, residual=None, out=None, out_split=None, want="f32", cfg=0, res_map=None, res_first=False):
     shapes.append((a.M, sw.N, sw.K, act, want, residual is not None, res_map is not None))
-    return o1(a, sw, bias, act, residual, out, out_split, want, cfg, res_map, res_first)
+    ext = res_map is not None or res_first
+    c = FORCE if FORCE and not (ext and FORCE == 3) else cfg
+    return o1(a, sw, bias, act, residual, out, out_split, want, c, res_map, res_first)
 def w2(a, sw, bias, out_map, table, act=0, cfg=0):
     shapes.append((a.M, sw.N, sw.K, act, "scatter", False, False))
-    return o2(a, sw, bias, out_map, table, act, cfg)
+    return o2(a, sw, bias, out_map, table, act, FORCE if FORCE in (1, 2) else cfg)
 native.linear_split, native.linear_split_scatter = w1, w2
 import scp_amd.ops as ops
 best = None
