@@ -76,10 +76,16 @@ __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ 
                                                      const float *__restrict__ v, int64_t ldkv, int c, int H, int nt, const float *__restrict__ vpart, int npart,
                                                      unsigned *__restrict__ vmax_out, _Float16 *__restrict__ qp, float *__restrict__ isq, float2 *__restrict__ diag,
                                                      char *__restrict__ kimg, char *__restrict__ vimg) {
-    __shared__ float vt[32][FHD + 1];
+    // Round 6: ONE 22 KiB LDS buffer, used three times in turn - the scaled V rows (19 KiB), the 32 Q rows (20 KiB), the K image (22 KiB) -
+    // instead of three buffers side by side (61 KiB: two workgroups per CU, two waves per SIMD, and the kernel is latency-bound: 61 % of its
+    // wave cycles instruction-stalled, profiles/r5_octattn_L14_frame_sq_wave_states.txt).  The converted q / k values wait in registers (they did
+    // before, too); three more barriers per workgroup buy twice the resident waves.  Same arithmetic, same bits.
+    __shared__ __attribute__((aligned(16))) char stage[FK_IMG];
     __shared__ float vred[4];
-    __shared__ __attribute__((aligned(16))) char kst[FK_IMG];              // the K image of this (tile, head), as it will lie in memory
-    __shared__ __attribute__((aligned(16))) _Float16 qst[32][2 * FHP];     // the 32 Q rows (hi plane | lo plane)
+    float (*vt)[FHD + 1] = (float (*)[FHD + 1])stage;                      // phase V: the 32 scaled V rows
+    _Float16 (*qst)[2 * FHP] = (_Float16 (*)[2 * FHP])stage;               // phase Q: the 32 Q rows (hi plane | lo plane)
+    char *kst = stage;                                                      // phase K: the K image of this (tile, head), as it will lie in memory
+    static_assert(32 * (FHD + 1) * 4 <= FK_IMG && 32 * 2 * FHP * 2 <= FK_IMG, "one buffer holds every phase");
     const int tid = threadIdx.x, t = tid >> 3, s = tid & 7;
     const int tile = blockIdx.x % nt, b = blockIdx.x / nt, head = blockIdx.y;
     const int D = H * FHD, cpad = nt * 32;
@@ -133,36 +139,43 @@ __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ 
     float qs, iqs, ks, iks;
     oa_pow2_scale(qm, qs, iqs);
     oa_pow2_scale(km, ks, iks);
-
     const size_t th = ((size_t)b * cpad + tok) * H + head;
-    _Float16 *qrow = qst[t];
-    _Float16 *krow = (_Float16 *)kst + t * FKLD;
-    if (s == 0) { isq[th] = iqs; diag[th] = make_float2(sii, dz); ((float *)(kst + FK_ISK))[t] = iks; }
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const int p = s + 8 * i;                      // float2 piece; pieces 75..79 are the zero padding (dims 150..159)
-        h16x2 qh, ql, kh, kl;
-        const float x[4] = {qv[i].x * qs, qv[i].y * qs, kv[i].x * ks, kv[i].y * ks};
-        qh[0] = (_Float16)x[0]; ql[0] = (_Float16)(x[0] - (float)qh[0]);
-        qh[1] = (_Float16)x[1]; ql[1] = (_Float16)(x[1] - (float)qh[1]);
-        kh[0] = (_Float16)x[2]; kl[0] = (_Float16)(x[2] - (float)kh[0]);
-        kh[1] = (_Float16)x[3]; kl[1] = (_Float16)(x[3] - (float)kh[1]);
-        *(h16x2 *)(qrow + 2 * p) = qh;
-        *(h16x2 *)(qrow + FHP + 2 * p) = ql;
-        *(h16x2 *)(krow + 2 * p) = kh;
-        *(h16x2 *)(krow + FK_PLANE + 2 * p) = kl;
-    }
-    // the bytes of the K image no row writes (dims 160 .. 167 of every row, the tail behind the scales) go out as zeros: the attention kernel
-    // copies the image as a whole and never reads them, but the workspace stays deterministic
-    if (s == 0) {
-        *(uint4 *)(krow + FHP) = make_uint4(0, 0, 0, 0);
-        *(uint4 *)(krow + FK_PLANE + FHP) = make_uint4(0, 0, 0, 0);
-    }
-    for (int e = FK_ISK + 128 + 16 * tid; e < FK_IMG; e += 16 * 256) *(uint4 *)(kst + e) = make_uint4(0, 0, 0, 0);
+    if (s == 0) { isq[th] = iqs; diag[th] = make_float2(sii, dz); }
     __syncthreads();
-    {   // K image: one linear block; Q rows: 640 contiguous bytes per token, H x 640 bytes apart
-        char *kbase = kimg + (((size_t)b * nt + tile) * H + head) * FK_IMG;
-        for (int e = tid; e < FK_IMG / 16; e += 256) *(uint4 *)(kbase + 16 * e) = *(const uint4 *)(kst + 16 * e);
+    // ---- phase V.  V^T: thread = (dim d, group g of 8 permuted key positions): position 8 g + j holds key 16 (g >> 1) + 4 (g & 1) + (j & 3) + 8 (j >> 2)
+    {
+        _Float16 *vbase = (_Float16 *)(vimg + (((size_t)b * nt + tile) * H + head) * FV_IMG);
+        for (int e = tid; e < FHP * 4; e += 256) {
+            const int d = e >> 2, g = e & 3;
+            h16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int key = 16 * (g >> 1) + 4 * (g & 1) + (j & 3) + 8 * (j >> 2);
+                const float x = d < FHD ? vt[key][d] : 0.f;
+                hi[j] = (_Float16)x;
+                lo[j] = (_Float16)(x - (float)hi[j]);
+            }
+            *(h16x8 *)(vbase + d * FVLD + 8 * g) = hi;
+            *(h16x8 *)(vbase + FV_PLANE + d * FVLD + 8 * g) = lo;
+        }
+    }
+    __syncthreads();
+    // ---- phase Q: the 32 Q rows assembled in LDS, out as 16-byte stores of whole rows (640 contiguous bytes per token, H x 640 bytes apart)
+    {
+        _Float16 *qrow = qst[t];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int p = s + 8 * i;                  // float2 piece; pieces 75..79 are the zero padding (dims 150..159)
+            h16x2 qh, ql;
+            const float x[2] = {qv[i].x * qs, qv[i].y * qs};
+            qh[0] = (_Float16)x[0]; ql[0] = (_Float16)(x[0] - (float)qh[0]);
+            qh[1] = (_Float16)x[1]; ql[1] = (_Float16)(x[1] - (float)qh[1]);
+            *(h16x2 *)(qrow + 2 * p) = qh;
+            *(h16x2 *)(qrow + FHP + 2 * p) = ql;
+        }
+    }
+    __syncthreads();
+    {
         constexpr int QV = 2 * FHP * 2 / 16;          // 16-byte pieces per Q row (40)
         for (int e = tid; e < 32 * QV; e += 256) {
             const int r = e / QV, pce = e - r * QV;
@@ -170,20 +183,33 @@ __global__ __launch_bounds__(256) void oa_prep_kernel(const float *__restrict__ 
             *(uint4 *)((char *)(qp + thr * (2 * FHP)) + 16 * pce) = *(const uint4 *)((const char *)qst[r] + 16 * pce);
         }
     }
-    // V^T: thread = (dim d, group g of 8 permuted key positions): position 8 g + j holds key 16 (g >> 1) + 4 (g & 1) + (j & 3) + 8 (j >> 2)
-    _Float16 *vbase = (_Float16 *)(vimg + (((size_t)b * nt + tile) * H + head) * FV_IMG);
-    for (int e = tid; e < FHP * 4; e += 256) {
-        const int d = e >> 2, g = e & 3;
-        h16x8 hi, lo;
+    __syncthreads();
+    // ---- phase K: the K image (planes [2][32 keys][168] + 32 inverse scales), one linear 22 KiB block
+    {
+        _Float16 *krow = (_Float16 *)kst + t * FKLD;
+        if (s == 0) ((float *)(kst + FK_ISK))[t] = iks;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int key = 16 * (g >> 1) + 4 * (g & 1) + (j & 3) + 8 * (j >> 2);
-            const float x = d < FHD ? vt[key][d] : 0.f;
-            hi[j] = (_Float16)x;
-            lo[j] = (_Float16)(x - (float)hi[j]);
+        for (int i = 0; i < 10; ++i) {
+            const int p = s + 8 * i;
+            h16x2 kh, kl;
+            const float x[2] = {kv[i].x * ks, kv[i].y * ks};
+            kh[0] = (_Float16)x[0]; kl[0] = (_Float16)(x[0] - (float)kh[0]);
+            kh[1] = (_Float16)x[1]; kl[1] = (_Float16)(x[1] - (float)kh[1]);
+            *(h16x2 *)(krow + 2 * p) = kh;
+            *(h16x2 *)(krow + FK_PLANE + 2 * p) = kl;
         }
-        *(h16x8 *)(vbase + d * FVLD + 8 * g) = hi;
-        *(h16x8 *)(vbase + FV_PLANE + d * FVLD + 8 * g) = lo;
+        // the bytes of the K image no row writes (dims 160 .. 167 of every row, the tail behind the scales) go out as zeros: the attention kernel
+        // copies the image as a whole and never reads them, but the workspace stays deterministic
+        if (s == 0) {
+            *(uint4 *)(krow + FHP) = make_uint4(0, 0, 0, 0);
+            *(uint4 *)(krow + FK_PLANE + FHP) = make_uint4(0, 0, 0, 0);
+        }
+        for (int e = FK_ISK + 128 + 16 * tid; e < FK_IMG; e += 16 * 256) *(uint4 *)(kst + e) = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    {
+        char *kbase = kimg + (((size_t)b * nt + tile) * H + head) * FK_IMG;
+        for (int e = tid; e < FK_IMG / 16; e += 256) *(uint4 *)(kbase + 16 * e) = *(const uint4 *)(kst + 16 * e);
     }
 }
 

@@ -23,7 +23,11 @@ def w1(a, sw, bias=None, act=0, residual=None, out=None, out_split=None, want="f
 def w2(a, sw, bias, out_map, table, act=0, cfg=0):
     shapes.append((a.M, sw.N, sw.K, act, "scatter", False, False))
     return o2(a, sw, bias, out_map, table, act, FORCE if FORCE in (1, 2) else cfg)
-native.linear_split, native.linear_split_scatter = w1, w2
+o3 = native.linear_split_hier2
+def w3(a0, sw0, a1, sw1, parent, bias=None, act=0, residual=None, res_map=None, out_split=None):
+    shapes.append((a0.M, sw0.N, sw0.K + 128, act, "hier2", residual is not None, res_map is not None))      # algorithmic K: stage 0 + stage 1 at half the rows
+    return o3(a0, sw0, a1, sw1, parent, bias, act, residual, res_map, out_split)
+native.linear_split, native.linear_split_scatter, native.linear_split_hier2 = w1, w2, w3
 import scp_amd.ops as ops
 best = None
 for _ in range(3):
