@@ -65,7 +65,21 @@ struct GemmSplitArgs {
     unsigned *row_max;                           // [M]: max |C[m][:]| or null
     unsigned *col_max;                           // one word: max |C[m][n]| over m < cm_rows, cm_lo <= n < cm_hi, or null
     int cm_lo, cm_hi, cm_rows;
+    int stagger;                                 // start stagger of the persistent workgroups in units of s_sleep(127) (see gemm_stagger_start)
 };
+
+// Start stagger (round 6).  The persistent workgroups of a launch do equal work, so all 256 CUs run their k loops together (matrix pipe busy, HBM
+// idle but for the operand stream) and then their epilogues together (every CU stores its 256 x 256 tile and reads its residual rows at the same
+// moment: HBM-bound, matrix pipe idle): a launch lasts the SUM of its MFMA time and its output time (the K = 256 layers: ~0.25 of the roof, "HBM-bound" at
+// 3 TB/s although neither resource is busy half the time).  Delaying three quarters of the workgroups by 1, 2, 3 x `stagger` x ~4 us once, at the
+// start, puts the groups' epilogues into each other's k loops for the rest of the launch: a group's stores then have the memory system (mostly)
+// to themselves.  Results do not depend on it (same tiles, same arithmetic); SCP_GEMM_STAGGER=0 is the A/B switch.
+__device__ __forceinline__ void gemm_stagger_start(int stagger) {
+    if (stagger > 0) {
+        const int g = (blockIdx.x >> 3) & 3;            // blockIdx & 7 = the XCD: every XCD gets all four groups
+        for (int i = 0; i < g * stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+}
 
 // EXT: the epilogue extensions (gathered residual before the activation, scattered output rows) are compiled only into the
 // variant that needs them - as run-time options they cost every dense layer ~12 % (measured)
@@ -141,6 +155,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
     int m0, n0;
     tile_coords(tile, m0, n0);
     stage_issue(0, m0, n0, 0);
+    gemm_stagger_start(a.stagger);
 
     for (; tile < ntiles; tile += gridDim.x) {
         f32x16 acc[TM][TN];
@@ -398,6 +413,7 @@ struct GemmHierArgs {
     const float *res; int64_t ldr; const int64_t *res_map;  // optional fp32 residual rows res[res_map[m]] (the coarser stages' partial sum)
     __bf16 *Ohi, *Olo; int64_t ldo;                         // split output planes [M][ldo]
     int M, N;
+    int stagger;                                            // gemm_stagger_start
 };
 
 template <int ACT>
@@ -473,6 +489,7 @@ __global__ __launch_bounds__(512, 2) void gemm_hier2_kernel(const GemmHierArgs a
     tile_coords(tile, m0, n0);
     int64_t pb = parent_of(m0);
     stage_issue(0, m0, n0, pb, 0);
+    gemm_stagger_start(a.stagger);
 
     for (; tile < ntiles; tile += gridDim.x) {
         f32x16 acc[TM][TN];
@@ -702,6 +719,11 @@ extern "C" SCP_API int scp_split_rows(const float *src, int64_t ld_src, int64_t 
 }
 
 static int g_num_cu = 0;
+static int gemm_stagger_units() {
+    static int u = -1;
+    if (u < 0) { const char *e = getenv("SCP_GEMM_STAGGER"); u = e ? atoi(e) : 1; if (u < 0 || u > 16) u = 1; }
+    return u;
+}
 
 template <int WM, int WN, int TM, bool EXT, bool F16 = false>
 static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st, double work) {
@@ -722,8 +744,10 @@ static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st, double w
     const int64_t ntiles = cdiv64(ga.M, BM) * cdiv64(ga.N, BN);
     const int64_t slots = (int64_t)g_num_cu * (WM * WN == 4 ? 2 : 1);
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    GemmSplitArgs gs = ga;
+    gs.stagger = ntiles >= 4 * slots ? gemm_stagger_units() : 0;     // long launches only: the stagger costs up to 3 units (~13 us) once
     SCP_PROF(SCP_PROF_GEMM_SPLIT, st, work);
-#define GOS(ACT, F) hipLaunchKernelGGL((gemm_split_kernel<WM, WN, TM, ACT, EXT, F>), dim3(grid), dim3(WM * WN * 64), LDS, st, ga)
+#define GOS(ACT, F) hipLaunchKernelGGL((gemm_split_kernel<WM, WN, TM, ACT, EXT, F>), dim3(grid), dim3(WM * WN * 64), LDS, st, gs)
     if (F16) { if (act == ACT_RELU) GOS(ACT_RELU, F16); else GOS(ACT_NONE, F16); }
     else switch (act) { case ACT_LEAKY: GOS(ACT_LEAKY, false); break; case ACT_GELU: GOS(ACT_GELU, false); break; case ACT_RELU: GOS(ACT_RELU, false); break; default: GOS(ACT_NONE, false); }
 #undef GOS
@@ -909,6 +933,7 @@ extern "C" SCP_API int scp_linear_split_hier2(const void *A0hi, const void *A0lo
     a.Ohi = (__bf16 *)Ohi; a.Olo = (__bf16 *)Olo; a.ldo = ldo; a.M = M; a.N = N;
     const int64_t ntiles = cdiv64(M, 256) * cdiv64(N, 256);
     const unsigned grid = (unsigned)(ntiles < g_num_cu ? ntiles : g_num_cu);
+    a.stagger = ntiles >= 4 * (int64_t)g_num_cu ? gemm_stagger_units() : 0;
     hipStream_t st = (hipStream_t)stream;
     // algorithmic flops: the stage-0 product at M rows + the stage-1 product at M / 2 rows
     SCP_PROF(SCP_PROF_GEMM_SPLIT, st, 2.0 * M * (double)N * (K0pad + 128.0));
