@@ -499,6 +499,13 @@ SCP_API int scp_swin_merge(const float *x, int64_t ldx, int64_t n_src, const int
  * bias: the six bias vectors back to back (1408 floats); out: fp32 [M][ldo], 128 columns written. */
 SCP_API int scp_geo_edge_mlps(const float *pos1, int64_t ld1, const float *pos2, int64_t ld2, const float *pos3, int64_t ld3, const void *W,
                               const float *bias, float *out, int64_t ldo, int32_t M, void *stream);
+/* round 6: a three-layer head Sequential(Linear, LeakyReLU(0.01), Linear, LeakyReLU, Linear) on 256-channel rows in ONE launch (models/ehem.py:113-121:
+ * prob_pred_mlp1 256 -> 256 -> 256 -> 255 and pre_attn_mlp 256 -> 256 -> 240 -> 240): out[out_map ? out_map[m] : m][0 .. N) = head(x[in_map ? in_map[m] : m]),
+ * rows with out_map[m] < 0 dropped.  x: fp32 [n_src][ldx]; W: scp_swin_post_attn_weight_bytes() bytes with three tiled [256][256] matrices (hi planes at
+ * m * 131072 bytes, lo planes at the same offsets in the second half; layers 2, 3: columns in accumulator order; unused rows / columns zero); bias [768];
+ * N % 4 == 0, N <= 256, 16-byte aligned output rows.  Every row's result is independent of what else is in the launch. */
+SCP_API int scp_mlp3_rows(const float *x, int64_t ldx, int64_t n_src, const int64_t *in_map, const void *W, const float *bias, float *out, int64_t ldo,
+                          const int64_t *out_map, int32_t M, int32_t N, void *stream);
 
 /* Keys and values handed from the projection to the window attention as bf16 hi / lo PLANES in the layout of the attention kernel's own
  * LDS tiles (swin_transformer.py:443-501; round 3).  planes: [4][Tp][256] bf16 = K hi, K lo, V^T hi, V^T lo for Tp rows of the packed

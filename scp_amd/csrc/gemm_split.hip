@@ -65,21 +65,7 @@ struct GemmSplitArgs {
     unsigned *row_max;                           // [M]: max |C[m][:]| or null
     unsigned *col_max;                           // one word: max |C[m][n]| over m < cm_rows, cm_lo <= n < cm_hi, or null
     int cm_lo, cm_hi, cm_rows;
-    int stagger;                                 // start stagger of the persistent workgroups in units of s_sleep(127) (see gemm_stagger_start)
 };
-
-// Start stagger (round 6).  The persistent workgroups of a launch do equal work, so all 256 CUs run their k loops together (matrix pipe busy, HBM
-// idle but for the operand stream) and then their epilogues together (every CU stores its 256 x 256 tile and reads its residual rows at the same
-// moment: HBM-bound, matrix pipe idle): a launch lasts the SUM of its MFMA time and its output time (the K = 256 layers: ~0.25 of the roof, "HBM-bound" at
-// 3 TB/s although neither resource is busy half the time).  Delaying three quarters of the workgroups by 1, 2, 3 x `stagger` x ~4 us once, at the
-// start, puts the groups' epilogues into each other's k loops for the rest of the launch: a group's stores then have the memory system (mostly)
-// to themselves.  Results do not depend on it (same tiles, same arithmetic); SCP_GEMM_STAGGER=0 is the A/B switch.
-__device__ __forceinline__ void gemm_stagger_start(int stagger) {
-    if (stagger > 0) {
-        const int g = (blockIdx.x >> 3) & 3;            // blockIdx & 7 = the XCD: every XCD gets all four groups
-        for (int i = 0; i < g * stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-}
 
 // EXT: the epilogue extensions (gathered residual before the activation, scattered output rows) are compiled only into the
 // variant that needs them - as run-time options they cost every dense layer ~12 % (measured)
@@ -155,7 +141,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
     int m0, n0;
     tile_coords(tile, m0, n0);
     stage_issue(0, m0, n0, 0);
-    gemm_stagger_start(a.stagger);
 
     for (; tile < ntiles; tile += gridDim.x) {
         f32x16 acc[TM][TN];
@@ -404,6 +389,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_split_kernel(const GemmS
 //     same for every row whatever the launch holds (batch invariance).
 // 6 block-products per tile instead of 4 + 2 in two launches, no intermediate, one epilogue; K depth 512 - 768 instead of 256.
 // Rows of window padding (parent map entry arbitrary) produce finite garbage nobody reads, as before.
+// Measured (profiles/r6_gemm_split_shapes.txt): ancient_mlp 1 413 + 658 -> 1 816 us, prob_pred_mlp2 792 + 285 -> 941 us per L16-m frame.  Also measured
+// and dropped in round 6: a start stagger of the persistent workgroups (a quarter of them delayed by 1, 2, 3 x 4 - 16 us once, so that the groups'
+// epilogues fall into each other's k loops): no change on any shape (8.93 / 8.91 / 8.93 / 9.20 ms for 0 / 4 / 8 / 16 us units).
 struct GemmHierArgs {
     const __bf16 *A0hi, *A0lo; int64_t lda0; int K0pad;     // stage-0 planes [M][lda0] (K0pad % 32 == 0)
     const __bf16 *A1hi, *A1lo; int64_t lda1; int64_t M1;    // stage-1 planes [M1][lda1], K = 256
@@ -413,7 +401,6 @@ struct GemmHierArgs {
     const float *res; int64_t ldr; const int64_t *res_map;  // optional fp32 residual rows res[res_map[m]] (the coarser stages' partial sum)
     __bf16 *Ohi, *Olo; int64_t ldo;                         // split output planes [M][ldo]
     int M, N;
-    int stagger;                                            // gemm_stagger_start
 };
 
 template <int ACT>
@@ -489,7 +476,6 @@ __global__ __launch_bounds__(512, 2) void gemm_hier2_kernel(const GemmHierArgs a
     tile_coords(tile, m0, n0);
     int64_t pb = parent_of(m0);
     stage_issue(0, m0, n0, pb, 0);
-    gemm_stagger_start(a.stagger);
 
     for (; tile < ntiles; tile += gridDim.x) {
         f32x16 acc[TM][TN];
@@ -719,12 +705,6 @@ extern "C" SCP_API int scp_split_rows(const float *src, int64_t ld_src, int64_t 
 }
 
 static int g_num_cu = 0;
-static int gemm_stagger_units() {
-    static int u = -1;
-    if (u < 0) { const char *e = getenv("SCP_GEMM_STAGGER"); u = e ? atoi(e) : 1; if (u < 0 || u > 16) u = 1; }
-    return u;
-}
-
 template <int WM, int WN, int TM, bool EXT, bool F16 = false>
 static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st, double work) {
     constexpr int BM = WM * TM * 32, BN = WN * 64;
@@ -744,10 +724,8 @@ static int launch_cfg(const GemmSplitArgs &ga, int act, hipStream_t st, double w
     const int64_t ntiles = cdiv64(ga.M, BM) * cdiv64(ga.N, BN);
     const int64_t slots = (int64_t)g_num_cu * (WM * WN == 4 ? 2 : 1);
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
-    GemmSplitArgs gs = ga;
-    gs.stagger = ntiles >= 4 * slots ? gemm_stagger_units() : 0;     // long launches only: the stagger costs up to 3 units (~13 us) once
     SCP_PROF(SCP_PROF_GEMM_SPLIT, st, work);
-#define GOS(ACT, F) hipLaunchKernelGGL((gemm_split_kernel<WM, WN, TM, ACT, EXT, F>), dim3(grid), dim3(WM * WN * 64), LDS, st, gs)
+#define GOS(ACT, F) hipLaunchKernelGGL((gemm_split_kernel<WM, WN, TM, ACT, EXT, F>), dim3(grid), dim3(WM * WN * 64), LDS, st, ga)
     if (F16) { if (act == ACT_RELU) GOS(ACT_RELU, F16); else GOS(ACT_NONE, F16); }
     else switch (act) { case ACT_LEAKY: GOS(ACT_LEAKY, false); break; case ACT_GELU: GOS(ACT_GELU, false); break; case ACT_RELU: GOS(ACT_RELU, false); break; default: GOS(ACT_NONE, false); }
 #undef GOS
@@ -933,7 +911,6 @@ extern "C" SCP_API int scp_linear_split_hier2(const void *A0hi, const void *A0lo
     a.Ohi = (__bf16 *)Ohi; a.Olo = (__bf16 *)Olo; a.ldo = ldo; a.M = M; a.N = N;
     const int64_t ntiles = cdiv64(M, 256) * cdiv64(N, 256);
     const unsigned grid = (unsigned)(ntiles < g_num_cu ? ntiles : g_num_cu);
-    a.stagger = ntiles >= 4 * (int64_t)g_num_cu ? gemm_stagger_units() : 0;
     hipStream_t st = (hipStream_t)stream;
     // algorithmic flops: the stage-0 product at M rows + the stage-1 product at M / 2 rows
     SCP_PROF(SCP_PROF_GEMM_SPLIT, st, 2.0 * M * (double)N * (K0pad + 128.0));

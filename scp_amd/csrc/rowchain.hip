@@ -1670,6 +1670,142 @@ __global__ __launch_bounds__(256, 1) void rc_edge_mlp_kernel(const RcEdgeArgs a)
     SCP_WAIT_DMA(0);
 }
 
+// =================================================================================================================================
+// scp_mlp3_rows: a three-layer head Sequential(Linear, LeakyReLU, Linear, LeakyReLU, Linear) on 256-channel rows in ONE launch (round 6):
+// prob_pred_mlp1 (256 -> 256 -> 256 -> 255, ehem.py:113-115: even-node logits) and pre_attn_mlp (256 -> 256 -> 240 -> 240, ehem.py:117-121).
+// As three split-GEMM launches these layers are HBM-bound (K = N = 256: 2 KB of planes moved per row and layer for 0.39 MFLOP, 0.20 - 0.24 of
+// the matrix roof at 3 TB/s); chained through the accumulators (rc_edge_mlp_kernel's scheme) a row is read once (1 KB, fp32, optionally
+// gathered: the even tokens of the self branch) and its result written once (optionally scattered: logits straight to their coding-order rows).
+// 12 steps of rc_gemm_step per 128-row tile.  Weights: three tiled [256][256] matrices (rows / columns beyond the layer's zero; hi planes at
+// m * 128 KiB, lo planes RC_W_PLANE bytes behind; layers 2, 3 with their columns in accumulator order, rc_perm16); bias: 3 x 256 (zero padded).
+// Results per row: independent of what else is in the launch.
+struct RcMlp3Args {
+    const float *x; int64_t ldx; const int64_t *in_map; int64_t n_src;   // row m reads x[in_map ? in_map[m] : m] (clamped to n_src - 1)
+    const void *W; const float *bias;
+    float *out; int64_t ldo; const int64_t *out_map;                     // row m -> out[out_map ? out_map[m] : m]; negative: dropped
+    int M, N;                                                            // N: output columns written (<= 256, % 4 == 0)
+};
+
+__global__ __launch_bounds__(256, 1) void rc_mlp3_kernel(const RcMlp3Args a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const RcLane L = rc_lane();
+    const int ntiles = (a.M + RC_ROWS - 1) / RC_ROWS;
+    float *sb = (float *)(smem + RC_OFF_BIAS);
+    for (int i = threadIdx.x; i < 3 * 256; i += 256) sb[i] = a.bias[i];
+    __syncthreads();
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    char *bounce = smem + RC_OFF_BOUNCE + L.w * RC_BOUNCE;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.W, 0, 2 * RC_W_PLANE, 0x00020000);
+    // step t = 4 m + g: rows [64 g, +64) of matrix m; the step behind the last is the next tile's first
+    auto src = [&](int t, int k) {
+        RcSlotSrc r = {(t >> 2) * 131072 + (2 * (t & 3) + k) * 16384, 1024};
+        return r;
+    };
+    {
+        const RcSlotSrc s0 = src(0, 0), s1 = src(0, 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) { rc_dma_piece(L, wr, s0, smem, q, plane); rc_dma_piece(L, wr, s1, smem + RC_SLOT, q, plane); }
+    }
+    rbf16x8 A[2][4];
+    {
+        SCP_BARRIER_DMA(0);
+        const RcFragAddr f = rc_frag_addr(L, smem);
+        RC_DS_READ4_WAIT(A[0][1], f.r0, 16384, A[0][3], f.r0, RC_SLOT + 16384, A[0][0], f.r0, 0, A[0][2], f.r0, RC_SLOT);
+    }
+    int gstep = 0, t = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * RC_ROWS;
+        const int row = m0 + 32 * L.w + L.col;
+        int64_t srow = row < a.M ? row : a.M - 1;
+        if (a.in_map) srow = a.in_map[srow];
+        srow = srow < a.n_src ? (srow < 0 ? 0 : srow) : a.n_src - 1;
+        const float *q0 = a.x + srow * a.ldx + 8 * L.h;
+        rbf16x8 Xh[16], Xl[16];
+        rf32x16 Y[8];
+        auto to_frags = [&]() {   // LeakyReLU(Y) (accumulator layout) -> B fragments of the next layer
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    float fr[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) fr[i] = rc_leaky(Y[b][8 * tt + i]);
+                    rc_split8(fr, Xh[2 * b + tt], Xl[2 * b + tt]);
+                }
+        };
+#define RC_STEP3() { const int tn = t + 1 < 12 ? t + 1 : 0; rc_gemm_step<false>(L, smem, gstep & 1, c0, c1, Xh, Xl, A, wr, src(tn, 0), src(tn, 1)); ++gstep; t = tn; }
+#define RC_BIAS3(LAYER)                                                                                                                        \
+            rf32x16 c0, c1;                                                                                                                    \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                                    \
+                const rf32x4 b0 = *(const rf32x4 *)(sb + 256 * (LAYER) + 64 * g + 8 * q + 4 * L.h), b1 = *(const rf32x4 *)(sb + 256 * (LAYER) + 64 * g + 32 + 8 * q + 4 * L.h); \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) { c0[4 * q + u] = b0[u]; c1[4 * q + u] = b1[u]; }                                 \
+            }                                                                                                                                  \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define RC_LAYER3(LAYER)                                                                                                                       \
+        for (int g = 0; g < 4; ++g) {                                                                                                          \
+            RC_BIAS3(LAYER)                                                                                                                    \
+            RC_STEP3()                                                                                                                         \
+            switch (g) { case 0: Y[0] = c0; Y[1] = c1; break; case 1: Y[2] = c0; Y[3] = c1; break; case 2: Y[4] = c0; Y[5] = c1; break; default: Y[6] = c0; Y[7] = c1; break; } \
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const rf32x4 v0 = *(const rf32x4 *)(q0 + 16 * s), v1 = *(const rf32x4 *)(q0 + 16 * s + 4);
+            const float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            rc_split8(f, Xh[s], Xl[s]);
+        }
+        RC_LAYER3(0)
+        to_frags();
+        RC_LAYER3(1)
+        to_frags();
+        // the rows this lane stores (4 groups of 8 rows of the wave's 32) and where they go
+        const int kap = L.lane & 7;
+        float *orow[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = m0 + 32 * L.w + 8 * it + (L.lane >> 3);
+            const int64_t o = r < a.M ? (a.out_map ? a.out_map[r] : (int64_t)r) : -1;
+            orow[it] = o >= 0 ? a.out + o * a.ldo + 4 * kap : nullptr;
+        }
+        // one block (32 output channels x the wave's 32 rows, accumulator layout) -> fp32 rows, columns [ch0, ch0 + 32) below N: through the wave's
+        // bounce buffer (rc_store_block's exchange), stored by row pointer
+        auto store_block = [&](const rf32x16 &c, int ch0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rf32x4 v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = c[4 * q + u];
+                *(rf32x4 *)(bounce + L.col * 128 + (((2 * q + L.h) ^ (L.col & 7)) << 4)) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            rf32x4 y[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rho = 8 * it + (L.lane >> 3);
+                y[it] = *(const rf32x4 *)(bounce + rho * 128 + ((kap ^ (rho & 7)) << 4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if (orow[it] && ch0 + 4 * kap < a.N) *(rf32x4 *)(orow[it] + ch0) = y[it];
+        };
+        // last layer: every pair of blocks leaves as soon as its step is done (kept in Y until the end of the layer, the 128 accumulator registers stay
+        // live beside the 128 fragment registers through four steps: the compiler spilled 240 of them)
+        for (int g = 0; g < 4; ++g) {
+            RC_BIAS3(2)
+            RC_STEP3()
+            store_block(c0, 64 * g);
+            store_block(c1, 64 * g + 32);
+        }
+#undef RC_LAYER3
+#undef RC_BIAS3
+#undef RC_STEP3
+    }
+    SCP_WAIT_DMA(0);
+}
+
 extern "C" SCP_API double scp_gelu_prescale(void) { return (double)SCP_GELU_S; }
 
 // workgroups per tile of a short rc_ln_linear launch (RcLnLinArgs.ngroups): the largest divisor g of nsteps / 2 with ntiles * g <= the CU count
@@ -1828,6 +1964,29 @@ extern "C" SCP_API int scp_geo_edge_mlps(const float *pos1, int64_t ld1, const f
     const int ntiles = (M + RC_ROWS - 1) / RC_ROWS, ncu = rc_num_cu();
     SCP_PROF(SCP_PROF_EDGE_MLP, stream, 2.0 * M * (448.0 * 256 + 2.0 * 256 * 256 + 512.0 * 256 + 256.0 * 256 + 256.0 * 128));
     hipLaunchKernelGGL(rc_edge_mlp_kernel, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
+    LAUNCH_CHECK();
+    return SCP_OK;
+}
+
+// out[out_map ? out_map[m] : m][0 .. N) = W3 . leaky(W2 . leaky(W1 . x[in_map ? in_map[m] : m] + b1) + b2) + b3 for M rows (see rc_mlp3_kernel).
+// x: fp32 [n_src][ldx] (256 channels), W: scp_swin_post_attn_weight_bytes() bytes with three tiled [256][256] matrices at m * 131072 bytes (lo planes
+// RC_W_PLANE behind; layers 2, 3: columns in rc_perm16 order; unused rows / columns zero), bias [768], out: fp32 rows of ldo floats, N columns written
+// (N % 4 == 0, N <= 256, 16-byte aligned rows); rows with out_map[m] < 0 are dropped.
+extern "C" SCP_API int scp_mlp3_rows(const float *x, int64_t ldx, int64_t n_src, const int64_t *in_map, const void *W, const float *bias, float *out, int64_t ldo,
+                                     const int64_t *out_map, int32_t M, int32_t N, void *stream) {
+    if (!x || !W || !bias || !out || M <= 0 || n_src <= 0 || N <= 0 || N > 256 || (N & 3) || ldx < 256 || (ldx & 3) || ldo < N || (ldo & 3) ||
+        (((uintptr_t)x | (uintptr_t)out | (uintptr_t)W) & 15))
+        return SCP_EINVAL;
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute((const void *)rc_mlp3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
+        configured = true;
+    }
+    RcMlp3Args a;
+    a.x = x; a.ldx = ldx; a.in_map = in_map; a.n_src = n_src; a.W = W; a.bias = bias; a.out = out; a.ldo = ldo; a.out_map = out_map; a.M = M; a.N = N;
+    const int ntiles = (M + RC_ROWS - 1) / RC_ROWS, ncu = rc_num_cu();
+    SCP_PROF(SCP_PROF_EDGE_MLP, stream, 2.0 * M * 3.0 * 256.0 * 256.0);
+    hipLaunchKernelGGL(rc_mlp3_kernel, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;
 }

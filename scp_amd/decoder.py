@@ -272,7 +272,7 @@ class FrameDecoder:
             sym[row0:row0 + c:2] = even
             if c > 1:
                 pw = self._plan1(c)
-                stw = dict(a1=native.SplitAct(st["a1"].t[:, q0:q0 + qp], st["a1"].K), a2=st["a2"][q0:q0 + qp],
+                stw = dict(a1=st["a1"][q0:q0 + qp], a2=st["a2"][q0:q0 + qp],
                            pre_occ=st["pre_occ"][q0:q0 + qp])
                 po = self._even_to_device(even, qp)
                 t = self._stamp("index_ops", t)

@@ -300,12 +300,41 @@ def _mlp_over_concat(seq, hs, parents, extra=None, grand=None):
     return linear_s(a, seq[4].weight, seq[4].bias)
 
 
-def _head_to_table(seq, a, out_map, table):
-    """leaky_mlp3 whose last layer writes its rows straight to their coding-order positions in `table` (rows out_map[m] >= 0)."""
+# False (tests, A/B): the 256-wide heads as three split-GEMM launches each (rounds 1 - 5) instead of one row-chain launch
+CHAIN_HEADS = True
+
+
+def _mlp3_weights(owner, name, seq):
+    """native.Mlp3Weights of a three-layer head, cached on the model and rebuilt when a parameter changes."""
+    return derived(owner, "mlp3_" + name, [seq[i].weight for i in (0, 2, 4)] + [seq[i].bias for i in (0, 2, 4)], lambda: native.Mlp3Weights(seq))
+
+
+def _head3(model, name, a, out=None, out_map=None, ncols=None):
+    """A 256 -> .. -> .. three-layer head (ehem.py:113-121) on fp32 rows `a` [M, 256]: ONE row-chain launch (csrc/rowchain.hip: rc_mlp3_kernel; the
+    hidden activations never leave the registers) - or, with CHAIN_HEADS off, three split-GEMM launches.  out: fp32 rows (may be a column-offset
+    view); out_map: scatter rows (negative = dropped), then `out` is the table."""
+    seq = getattr(model, name)
+    N = seq[4].weight.shape[0]
+    if CHAIN_HEADS:
+        if out is None:
+            out = torch.empty((a.shape[0], -(-N // 4) * 4), dtype=torch.float32, device=a.device)
+        native.mlp3_rows(a, _mlp3_weights(model, name, seq), out, out_map=out_map, ncols=ncols)
+        return out[:, :N] if out_map is None else None
     from ..ops import _split
-    a = linear_s(a, seq[0].weight, seq[0].bias, act="leaky", want="split")
-    a = linear_s(a, seq[2].weight, seq[2].bias, act="leaky", want="split")
-    native.linear_split_scatter(a, _split(seq[4].weight), seq[4].bias, out_map, table)
+    sa = native.split_rows(a)
+    if out_map is not None:
+        sa = linear_s(sa, seq[0].weight, seq[0].bias, act="leaky", want="split")
+        sa = linear_s(sa, seq[2].weight, seq[2].bias, act="leaky", want="split")
+        native.linear_split_scatter(sa, _split(seq[4].weight), seq[4].bias, out_map, out)
+        return None
+    return leaky_mlp3_s(seq, sa, out=out)
+
+
+def _head_to_table(model, a, out_map, table):
+    """prob_pred_mlp1 whose last layer writes its rows straight to their coding-order positions in `table` (rows out_map[m] >= 0)."""
+    if CHAIN_HEADS and table.stride(0) < 256:
+        raise native.ScpError("the coding-order table must have rows of at least 256 floats")
+    _head3(model, "prob_pred_mlp1", a, out=table, out_map=out_map)
 
 
 @torch.no_grad()
@@ -350,13 +379,14 @@ def ehem_phase1_packed(model, ctx, pos, plan, table=None):
     hs = _encoder(model.swin_self_transformer, feat, d["self_valid"], d["self_tab"], d["self_merge"], tiles=d.get("self_tiles"))
     feat_a = _mlp_over_concat(model.ancient_mlp, hs, d["self_parent"], grand=d["self_concat"][1]) if HIER else leaky_mlp3_s(model.ancient_mlp, _concat(hs, d["self_concat"]))
     Q0 = d["a1map"].shape[0]
-    a1 = native.split_rows(feat_a, idx=d["a1map"])
+    # round 6: the even tokens' features travel as fp32 rows (like the odd tokens'): the one-launch heads read rows, not planes
+    a1 = native.gather_rows(feat_a, d["a1map"], torch.empty((Q0, 256), dtype=torch.float32, device=dev))
     a2 = native.gather_rows(feat_a, d["a2map"], torch.empty((Q0, 256), dtype=torch.float32, device=dev))
     st = dict(a1=a1, a2=a2, pre_occ=occ_self[d["a1map"]])
     if table is not None:
-        _head_to_table(model.prob_pred_mlp1, a1, d["even_out"], table)
+        _head_to_table(model, a1, d["even_out"], table)
         return None, st
-    prob1 = leaky_mlp3_s(model.prob_pred_mlp1, a1)
+    prob1 = _head3(model, "prob_pred_mlp1", a1)
     return prob1[d["even_rows"]], st
 
 
@@ -371,7 +401,7 @@ def ehem_phase2_prepare(model, st, plan):
     a1, a2 = st["a1"], st["a2"]
     no = model.pre_occ_mlp[4].weight.shape[0]
     pre = torch.empty((a2.shape[0], no + model.pre_attn_mlp[4].weight.shape[0]), dtype=torch.float32, device=a2.device)
-    leaky_mlp3_s(model.pre_attn_mlp, a1, out=pre[:, no:])
+    _head3(model, "pre_attn_mlp", a1, out=pre[:, no:])
     enc = model.swin_cross_transformer
     qs, query = [], a2
     for s, stage in enumerate(enc.layers):
@@ -408,7 +438,7 @@ def ehem_phase2_packed(model, st, plan, pre_occ=None, table=None, prep=None):
     else:
         pre = torch.empty((a2.shape[0], no + model.pre_attn_mlp[4].weight.shape[0]), dtype=torch.float32, device=a2.device)
         pre[:, :no] = occ_feat
-        leaky_mlp3_s(model.pre_attn_mlp, a1, out=pre[:, no:])
+        _head3(model, "pre_attn_mlp", a1, out=pre[:, no:])
     hc = _encoder(model.swin_cross_transformer, pre, d["cross_valid"], d["cross_tab"], d["cross_merge"], query=a2, tiles=d.get("cross_tiles"),
                   q_pre=None if prep is None else prep["q"])
     if table is not None:

@@ -58,6 +58,7 @@ def lib():
     sig = {
         "scp_version": (C.c_int, []),
         "scp_geo_edge_mlps": (C.c_int, [_vp, i64, _vp, i64, _vp, i64, _vp, _vp, _vp, i64, i32, _vp]),
+        "scp_mlp3_rows": (C.c_int, [_vp, i64, i64, _vp, _vp, _vp, _vp, i64, _vp, i32, i32, _vp]),
         "scp_swin_merge": (C.c_int, [_vp, i64, i64, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, i32, _vp]),
         "scp_swin_ln_qkv": (C.c_int, [_vp, i64, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, i64, _vp, i64, i32, i32, _vp]),
         "scp_swin_kv_planes": (C.c_int, [_vp, _vp, i64, i64, _vp, _vp, _vp, _vp, _vp]),
@@ -665,9 +666,13 @@ def numeric_profile(model_name, profile="current"):
     # ehem/3: patch merging and the geometry generator's edge MLPs on row-chain kernels (other last bits than ehem/2)
     # ehem/4: the bf16x3 attention sweeps against the fixed reference 0 with the bias as the products' start value (csrc/attn.hip: attn_tile)
     # ehem/5: GELU as max(y, 0) - |y| exp(-beta y^2) / P4(|y|) (csrc/scp_internal.h) instead of the degree-12 erf polynomial
+    # ehem/6: stages 0 and 1 of the layers over concat_states in one launch (the stage-1 product starts the accumulators: gemm_hier2_kernel), the two
+    #         256-wide heads as one row-chain launch each (bias as the accumulators' start value: rc_mlp3_kernel)
     L = lib()
     attnv = "" if L.scp_get_attention_variant() == 1 else f",attnv={L.scp_get_attention_variant()}"     # process-wide test bracket (scp_debug.h)
-    return f"ehem/5:gemm={ops.MODE},knn={knn},attn={attn},concat={'hier' if packed.HIER else 'direct'},swin=rowchain{attnv}"
+    concat = ("hier2" if packed.FUSE2 else "hier") if packed.HIER else "direct"
+    heads = "" if packed.CHAIN_HEADS else ",heads=split"
+    return f"ehem/6:gemm={ops.MODE},knn={knn},attn={attn},concat={concat},swin=rowchain{heads}{attnv}"
 
 
 def edge_gather_max(u, v, idx, scale, shift, out=None):
@@ -1152,6 +1157,52 @@ def geo_edge_mlps(pos1, pos2, pos3, ew, out):
     rc = lib().scp_geo_edge_mlps(pos1.data_ptr(), pos1.stride(0), pos2.data_ptr(), pos2.stride(0), pos3.data_ptr(), pos3.stride(0), ew.packed.data_ptr(),
                                  ew.bias.data_ptr(), out.data_ptr(), out.stride(0), M, _stream())
     _check(rc, "scp_geo_edge_mlps")
+    return out
+
+
+class Mlp3Weights:
+    """A three-layer head Sequential(Linear, LeakyReLU, Linear, LeakyReLU, Linear) with 256 inputs and layers of <= 256 outputs in the form
+    scp_mlp3_rows streams (csrc/rowchain.hip: rc_mlp3_kernel): three tiled [256, 256] matrices (unused rows / columns zero; layers 2, 3 with their
+    columns in accumulator order) in a scp_swin_post_attn_weight_bytes() buffer, the three biases zero padded to 256 back to back."""
+
+    def __init__(self, seq):
+        ws = [seq[i].weight.detach().float() for i in (0, 2, 4)]
+        bs = [seq[i].bias.detach().float() for i in (0, 2, 4)]
+        if ws[0].shape[1] != 256 or any(w.shape[0] > 256 or w.shape[1] > 256 for w in ws) or ws[1].shape[1] != ws[0].shape[0] or ws[2].shape[1] != ws[1].shape[0]:
+            raise ScpError("Mlp3Weights: a 256 -> (<= 256) -> (<= 256) -> (<= 256) head expected")
+        dev = ws[0].device
+        P = rc_perm16(256, dev)
+        nbytes = lib().scp_swin_post_attn_weight_bytes()
+        buf = torch.zeros((nbytes // 2,), dtype=torch.bfloat16, device=dev)
+        half = nbytes // 4
+        bias = torch.zeros((3, 256), dtype=torch.float32, device=dev)
+        for m, (w, b) in enumerate(zip(ws, bs)):
+            full = torch.zeros((256, 256), dtype=torch.float32, device=dev)
+            full[:w.shape[0], :w.shape[1]] = w
+            if m:
+                full = full[:, P]
+            hi, lo = _tiled_planes_always(SplitWeight(full.contiguous()))
+            buf[m * 65536:(m + 1) * 65536] = hi.reshape(-1)[:65536]
+            buf[half + m * 65536:half + (m + 1) * 65536] = lo.reshape(-1)[:65536]
+            bias[m, :b.shape[0]] = b
+        self.packed, self.bias, self.N = buf, bias.reshape(-1).contiguous(), int(ws[2].shape[0])
+        note_cache_fill()
+
+
+def mlp3_rows(x, mw, out, in_map=None, out_map=None, ncols=None):
+    """out[out_map[m] or m, :ncols] = head(x[in_map[m] or m]) in one launch (scp_mlp3_rows): x fp32 [n, 256] rows (unit channel stride), mw = Mlp3Weights,
+    out fp32 rows with unit column stride and 16-byte aligned rows (a column-offset view of a wider buffer is fine); in_map / out_map int64 (rows with
+    out_map < 0 are dropped); ncols = columns written (default: the head's outputs rounded up to a multiple of 4 - padding columns receive 0)."""
+    M = x.shape[0] if in_map is None else in_map.shape[0]
+    if out_map is not None and out_map.shape[0] != M:
+        raise ScpError("mlp3_rows: out_map must have one entry per row")
+    if x.shape[1] != 256 or x.stride(1) != 1 or out.stride(1) != 1:
+        raise ScpError("mlp3_rows: [n, 256] rows with unit channel stride expected")
+    N = -(-mw.N // 4) * 4 if ncols is None else int(ncols)
+    if out_map is None and out.shape[0] < M:
+        raise ScpError("mlp3_rows: output has too few rows")
+    _check(lib().scp_mlp3_rows(x.data_ptr(), x.stride(0), x.shape[0], None if in_map is None else _dev(in_map, torch.int64), mw.packed.data_ptr(), mw.bias.data_ptr(),
+                               out.data_ptr(), out.stride(0), None if out_map is None else _dev(out_map, torch.int64), M, N, _stream()), "scp_mlp3_rows")
     return out
 
 

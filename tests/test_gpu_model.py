@@ -1167,6 +1167,88 @@ def test_linear_split_hier2_vs_float64(dev, M, K0, N, with_res):
     assert err < 2e-4          # the split output itself carries 2^-17 relative; products 1e-5 relative of sum |a||w|
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,dims,gather,scatter", [(1, (256, 256, 255), False, False), (300, (256, 240, 240), False, False), (1000, (256, 256, 255), True, True),
+                                                   (33000, (256, 240, 240), True, False), (129, (256, 256, 128), False, True)])
+def test_mlp3_rows_vs_float64(dev, M, dims, gather, scatter):
+    """scp_mlp3_rows (csrc/rowchain.hip: rc_mlp3_kernel): Sequential(Linear, LeakyReLU, Linear, LeakyReLU, Linear) on 256-channel rows in one
+    launch against float64 - ragged layer widths (240, 255), gathered input rows, scattered output rows with dropped rows, output as a
+    column-offset view - and every row independent of what else is in the launch (bit-identical to a launch of a prefix)."""
+    from scp_amd import native
+    g = torch.Generator().manual_seed(M + sum(dims))
+    seq = torch.nn.Sequential(torch.nn.Linear(256, dims[0]), torch.nn.LeakyReLU(), torch.nn.Linear(dims[0], dims[1]), torch.nn.LeakyReLU(),
+                              torch.nn.Linear(dims[1], dims[2]))
+    with torch.no_grad():
+        for p_ in seq.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.08 if p_.dim() == 2 else 0.5))
+    seq = seq.to(dev)
+    n_src = M + 17
+    x = (torch.randn((n_src, 256), generator=g) * 2.0).to(dev)
+    in_map = torch.randint(0, n_src, (M,), generator=g).to(dev) if gather else None
+    mw = native.Mlp3Weights(seq)
+    N = dims[2]
+    Np = -(-N // 4) * 4
+    rows_out = M + 5
+    wide = torch.full((rows_out, 16 + 256), 7.0, dtype=torch.float32, device=dev)
+    out = wide[:, 16:]
+    if scatter:
+        perm = torch.randperm(rows_out, generator=g)[:M]
+        out_map = perm.clone()
+        out_map[::7] = -1                                   # dropped rows
+        out_map = out_map.to(dev)
+    else:
+        out_map = None
+    native.mlp3_rows(x if gather else x[:M], mw, out, in_map=in_map, out_map=out_map)
+    xin = (x[in_map] if gather else x[:M]).double()
+    h = xin
+    for i in (0, 2, 4):
+        h = h @ seq[i].weight.double().T + seq[i].bias.double()
+        if i < 4:
+            h = torch.where(h > 0, h, 0.01 * h)
+    if scatter:
+        keep = out_map >= 0
+        got = out[out_map[keep]][:, :N].double()
+        want = h[keep]
+        untouched = torch.ones(rows_out, dtype=torch.bool, device=dev)
+        untouched[out_map[keep]] = False
+        assert (wide[untouched] == 7.0).all()               # dropped rows and rows nobody maps to are not written
+    else:
+        got, want = out[:M, :N].double(), h
+        assert (wide[M:] == 7.0).all()
+    err = (got - want).abs().max().item()
+    print(f"mlp3 M={M} dims={dims}: max err {err:.3e}")
+    assert err < 2e-4
+    assert (wide[:, :16] == 7.0).all() and (wide[:, 16 + Np:] == 7.0).all()     # nothing outside the head's columns
+    if Np > N:
+        rows = out_map[out_map >= 0] if scatter else torch.arange(M, device=dev)
+        assert (out[rows][:, N:Np] == 0).all()                                  # padding columns of a ragged head: zeros
+    if not gather and not scatter and M > 40:
+        out2 = torch.empty((40, 256), dtype=torch.float32, device=dev)
+        native.mlp3_rows(x[:40], mw, out2)
+        assert torch.equal(out2[:, :Np], out[:40, :Np])
+
+
+@pytest.mark.gpu
+def test_one_launch_heads_equal_three_launch_heads(dev, ehem):
+    """Round 6: prob_pred_mlp1 / pre_attn_mlp as one row-chain launch each against the three split-GEMM launches per head of rounds 1 - 5
+    (packed.CHAIN_HEADS = False): the logits differ only by fp32 summation order."""
+    from scp_amd.models import packed
+    z = golden("logits_ehem_c1024")
+    ctx = torch.from_numpy(z["data"].astype(np.int64)).to(dev).reshape(1024, 12).to(torch.uint8)
+    p = torch.from_numpy(z["pos"]).to(dev).T.contiguous()
+    lengths = [1, 7, 2, 300, 513, 1, 200]
+    try:
+        packed.CHAIN_HEADS = True
+        a = ehem.forward_packed(ctx, p, lengths)
+        packed.CHAIN_HEADS = False
+        b = ehem.forward_packed(ctx, p, lengths)
+    finally:
+        packed.CHAIN_HEADS = True
+    worst = max((a[0] - b[0]).abs().max().item(), (a[1] - b[1]).abs().max().item())
+    print(f"one-launch vs three-launch heads: max|dlogit| = {worst:.3e}")
+    assert worst < 5e-5
+
+
 # ---------------------------------------------------------------------------------------------------------------- row-chain kernels
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N", [(1, 256), (31, 768), (128, 768), (129, 512), (1000, 256), (70001, 768)])
@@ -1757,7 +1839,7 @@ def test_phase2_prepared_ahead_has_the_bits_of_the_plain_phase2(dev, ehem):
             L = (L + 1) // 2
         if c > 1:
             pw = PackedPlan([c], device=dev)
-            stw = dict(a1=native.SplitAct(st["a1"].t[:, q0:q0 + rows[0]], st["a1"].K), a2=st["a2"][q0:q0 + rows[0]], pre_occ=st["pre_occ"][q0:q0 + rows[0]])
+            stw = dict(a1=st["a1"][q0:q0 + rows[0]], a2=st["a2"][q0:q0 + rows[0]], pre_occ=st["pre_occ"][q0:q0 + rows[0]])
             one = ehem_phase2_packed(ehem, stw, pw, prep=phase2_prep_window(prep, bases, rows))
             assert torch.equal(one, want[o0:o0 + c // 2])
         q0 += rows[0]
