@@ -48,7 +48,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md: aggregate L2 bandwidth
-PMC_PROFILES = ("r5_ehem_L16m_frame_pmc_traffic.json", "r5_octattn_L14_frame_pmc_traffic.json",     # profiles/: HBM bytes per launch / per frame from separate rocprofv3 --pmc passes
+PMC_PROFILES = ("r6_ehem_L16m_frame_pmc_traffic.json", "r6_octattn_L14_frame_pmc_traffic.json", "r5_ehem_L16m_frame_pmc_traffic.json", "r5_octattn_L14_frame_pmc_traffic.json",     # profiles/: HBM bytes per launch / per frame from separate rocprofv3 --pmc passes
                 "r4_pmc_traffic.json", "r4_pmc_traffic_octattn_L14_cylin.json")                       # (tools/r5_profiles.sh), one file per configuration; the newest that exists is used
 
 
@@ -178,8 +178,9 @@ KERNEL_OF = {   # launch-bracket tag -> (kernel name as rocprofv3 prints it, bou
     "attention": ("swin_attn_planes_kernel", "mfma", "window attention, K / V tiles staged by LDS-DMA from pre-split planes"),
     "knn_feat": ("knn_f16x3_wg256_kernel", "mfma", "fused distance + top-20 selection on 144 / 192 features, 256-query workgroups on the XCD-affine schedule"),
     "knn_pos": ("knn_mfma_kernel<2,16> (positions)", "valu", "exact fp32 chain on 3 features with tile skipping: selection-bound"),
-    "gemm_split": ("gemm_split_kernel", "mfma", "the remaining dense layers (geometry MLPs, concat layers, probability heads; OctAttention: every layer on planes)"),
+    "gemm_split": ("gemm_split_kernel", "mfma", "the remaining dense layers (geometry MLPs, concat layers incl. the fused two-stage gemm_hier2_kernel, the 512 / 768-wide head layers; OctAttention: every layer on planes)"),
     "edge_mlp": ("rc_edge_mlp_kernel", "mfma", "both edge MLPs of the geometry generator, six layers chained through the accumulators"),
+    "mlp3": ("rc_mlp3_kernel", "mfma", "the 256-wide three-layer heads (prob_pred_mlp1, pre_attn_mlp), one row-chain launch each (round 6)"),
     "merge": ("rc_merge_kernel", "mfma", "patch merging: gather + LayerNorm(512) + reduction"),
     "gemm_f32": ("gemm_f32_kernel", "mfma_f32", "exact k-ordered fp32 layers feeding a kNN search"),
     "gemm_rows": ("gemm_bf16x3_kernel", "mfma", "dense layers reading fp32 rows (split in the tile)"),

@@ -67,7 +67,8 @@ enum {
     SCP_PROF_OA_ATTENTION = 15,/* oa_attn_f16x3_kernel: B x 3 x 2 c^2 D flop; its preparation: OTHER     */
     SCP_PROF_GEOM = 16,        /* scp_quantize / scp_geom_build / context kernels: the call's algorithmic bytes         */
     SCP_PROF_OTHER = 17,
-    SCP_PROF_NTAGS = 18
+    SCP_PROF_MLP3 = 18,        /* rc_mlp3_kernel (the 256-wide heads, one launch each): 2 M 3 x 256 x 256 flop                    */
+    SCP_PROF_NTAGS = 19
 };
 SCP_API int scp_prof_enable(int32_t on);     /* 1: drop old records and start recording; 0: stop (records stay readable)   */
 SCP_API int scp_prof_count(void);            /* records taken since the last enable(1)                                     */

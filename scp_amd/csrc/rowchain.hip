@@ -1985,7 +1985,7 @@ extern "C" SCP_API int scp_mlp3_rows(const float *x, int64_t ldx, int64_t n_src,
     RcMlp3Args a;
     a.x = x; a.ldx = ldx; a.in_map = in_map; a.n_src = n_src; a.W = W; a.bias = bias; a.out = out; a.ldo = ldo; a.out_map = out_map; a.M = M; a.N = N;
     const int ntiles = (M + RC_ROWS - 1) / RC_ROWS, ncu = rc_num_cu();
-    SCP_PROF(SCP_PROF_EDGE_MLP, stream, 2.0 * M * 3.0 * 256.0 * 256.0);
+    SCP_PROF(SCP_PROF_MLP3, stream, 2.0 * M * 3.0 * 256.0 * 256.0);
     hipLaunchKernelGGL(rc_mlp3_kernel, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(256), RC_LDS, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return SCP_OK;

@@ -195,7 +195,7 @@ def _opt(t):
 # ------------------------------------------------------------------------------------------------- launch brackets (scp_debug.h)
 PROF_TAGS = {1: "post_attn", 2: "ln_linear", 3: "attention", 4: "knn_feat", 5: "knn_pos", 6: "gemm_split", 7: "edge_mlp", 8: "merge",
              9: "edge_gather", 10: "cdf", 11: "gemm_f32", 12: "gemm_rows", 13: "split_rows", 14: "layernorm", 15: "oa_attention", 16: "geom",
-             17: "other"}
+             17: "other", 18: "mlp3"}
 
 
 class launch_profile:

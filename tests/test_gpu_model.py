@@ -276,18 +276,47 @@ class _KnnLists:
         self.lists = []
         k1, k2 = native.knn_topk, native.knn_topk_packed
 
+        self.inputs = []          # what every search was asked: (kind, features on the host, k or window table)
+
         def topk(x, k):
             idx = k1(x, k)
             self.lists.append(("window", idx.cpu().long()))
+            self.inputs.append(("window", x.detach().cpu(), k))
             return idx
 
         def topk_packed(x, ctab, thr0=None):
             idx = k2(x, ctab, thr0)
             self.lists.append(("packed", idx.cpu().long()))
+            self.inputs.append(("packed", x.detach().cpu(), ctab.cpu()))
             return idx
 
         monkeypatch.setattr(native, "knn_topk", topk)
         monkeypatch.setattr(native, "knn_topk_packed", topk_packed)
+
+    def check(self, max_windows=3):
+        """The recorded lists are NEAREST-neighbour lists of the features each search was given - checked independently of the kernels, by a
+        float64 brute force on the host (replaying the product's lists into the oracle cannot notice a wrong list; this can): for
+        every query the farthest listed neighbour is no farther than the true k-th nearest (up to float32 rounding of the distance: exact ties
+        and candidates within rounding may be exchanged), and a list holds no duplicates."""
+        def one(feat, idx, k):
+            f = feat.double()
+            n = f.shape[0]
+            kk = min(k, n)
+            d = (f * f).sum(1)[:, None] + (f * f).sum(1)[None, :] - 2.0 * (f @ f.T)
+            kth = torch.topk(d, kk, dim=1, largest=False)[0][:, -1]
+            got = torch.gather(d, 1, idx[:, :kk])
+            scale = (f * f).sum(1).max().clamp_min(1e-30)
+            assert (got.max(1)[0] <= kth + 4e-6 * scale).all(), "a listed neighbour is farther than the k-th nearest"
+            srt = torch.sort(idx[:, :kk], 1)[0]
+            assert (srt[:, 1:] != srt[:, :-1]).all() or kk < 2, "duplicate neighbour in a list"
+        for (kind, idx), (_, x, aux) in zip(self.lists, self.inputs):
+            if kind == "window":
+                for b in range(min(x.shape[0], max_windows)):
+                    one(x[b], idx[b], aux)
+            else:
+                seqs = sorted({(int(b), int(n)) for b, n in aux.tolist() if n > 0})
+                for base, n in seqs[:max_windows]:
+                    one(x[base:base + n], idx[base:base + n] - base, idx.shape[1])
 
     def replay(self, B, c):
         """-> a KNN_OVERRIDE for models_ref.ehem_forward on B windows of c nodes (ce = c rounded up to even, ehem.py:92-99)."""
@@ -578,6 +607,7 @@ def test_ehem_logits_vs_reference_packed_path(dev, ehem, monkeypatch, name):
     data, pos = _ehem_case(z)
     rec = _KnnLists(monkeypatch)
     o1, o2 = _run_packed(ehem, data, pos, dev)
+    rec.check()
     st, w1, w2 = _want_rows(z)
     e = _row_err(o1, o2, st, w1, w2)
     rows_ok = (e.max(1) <= LOGIT_TOL).mean()
@@ -613,6 +643,7 @@ def test_ehem_logits_vs_reference(dev, ehem, monkeypatch, name):
         data, pos = data[None], pos[None]
     rec = _KnnLists(monkeypatch)
     o1, o2 = ehem(data.to(dev), pos.to(dev), enc=True)
+    rec.check()
     o1, o2 = o1.cpu().numpy(), o2.cpu().numpy()
     if "out1_sub" in z:
         st = int(z["stride"])
