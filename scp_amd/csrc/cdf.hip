@@ -55,9 +55,17 @@ __global__ __launch_bounds__(256) void cdf_kernel(const float *__restrict__ in, 
         m = fmaxf(fmaxf(part[lane], part[ROWS + lane]), fmaxf(part[2 * ROWS + lane], part[3 * ROWS + lane]));
         if (lane < nrow) for (int j = c0; j < c1; ++j) row[j] = expf(row[j] - m);
         __syncthreads();
-        if (wq == 0 && lane < nrow) {   // serial float32 sum in column order
+        if (wq == 0 && lane < nrow) {   // serial float32 sum in column order; eight LDS reads in flight, then their eight dependent additions
             float sum = 0.f;
-            for (int j = 0; j < nsym; ++j) sum += row[j];
+            int j = 0;
+            for (; j + 8 <= nsym; j += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = row[j + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum = __fadd_rn(sum, v[u]);
+            }
+            for (; j < nsym; ++j) sum = __fadd_rn(sum, row[j]);
             part[lane] = sum;
         }
         __syncthreads();
@@ -75,14 +83,22 @@ __global__ __launch_bounds__(256) void cdf_kernel(const float *__restrict__ in, 
     if (wq == 0 && lane < nrow) {
         const int s = sym ? (int)sym[row0 + lane] : 0;
         // numpyAc.py:111 serial float32 cumsum; keep F[s] and F[s+1] (F[0] = 0, F[k] = c[k-1])
-        float c = 0.f, c_lo = 0.f, c_hi = 0.f;
-        for (int j = 0; j < nsym; ++j) {
-            c = __fadd_rn(c, row[j]);
-            if (cdf_full) row[j] = c;
-            if (j == s - 1) c_lo = c;
-            if (j == s) c_hi = c;
+        // (round 6: the prefix sums go back into the row - eight reads in flight, eight dependent additions, eight writes - and F[s], F[s + 1] are
+        // read from it afterwards: two instructions per element instead of the add + two compare / select pairs of the first version)
+        float c = 0.f;
+        int j = 0;
+        for (; j + 8 <= nsym; j += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { c = __fadd_rn(c, v[u]); v[u] = c; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) row[j + u] = v[u];
         }
+        for (; j < nsym; ++j) { c = __fadd_rn(c, row[j]); row[j] = c; }
         const float c_last = c;
+        const float c_lo = s > 0 ? row[s - 1] : 0.f, c_hi = row[s < nsym ? s : nsym - 1];
         if (lohi) {
             // :112 c / c[-1] in float32, :113 -> float64, :101-103 * 65281, rint, wrap, :106 + arange
             const double scale = (double)(65536 - nsym);
