@@ -42,7 +42,9 @@ extern "C" {
  *        launch sequence); scp_debug.h gained the launch brackets scp_prof_*.
  *   220  GELU (round 5, numeric profile ehem/5): max(y, 0) - |y| exp(-beta y^2) / P4(|y|) instead of the degree-12 erf polynomial, in every
  *        kernel that applies it; scp_swin_post_attn expects fc1 scaled by scp_gelu_prescale() and fc2 by its inverse.
- *        (additive, no new version: scp_decode_expand, scp_linear_split_f16_max, scp_row_scale_from_max, scp_octattn_attention_f16x3_vmax.) */
+ *        (additive, no new version: scp_decode_expand, scp_linear_split_f16_max, scp_row_scale_from_max, scp_octattn_attention_f16x3_vmax;
+ *        round 6: scp_linear_split_hier2, scp_mlp3_rows - existing entry points keep their bits, the EHEM model's numeric profile moved to ehem/6
+ *        because models/packed.py now calls the two new ones.) */
 #define SCP_ABI_VERSION 220
 SCP_API int scp_version(void);
 SCP_API int scp_last_hip_error(void);

@@ -285,7 +285,6 @@ def _concat_layer(lin, hs, parents, extra=None, grand=None):
     if fused:
         # round 6: stages 0 and 1 in ONE launch - the stage-1 product of a 256-token tile's own 128 parents stays in the accumulators
         # (csrc/gemm_split.hip: gemm_hier2_kernel); z = the partial sum of stages 2 .. n - 1 at stage-2 resolution, gathered through `grand`
-        from ..ops import _split
         return native.linear_split_hier2(a0, _split(cache[0]), native.split_rows(hs[2]), _split(cache[1]), parents[0], lin.bias, native.ACT_LEAKY,
                                          residual=z, res_map=grand)
     return linear_s(a0, cache[0], lin.bias, act="leaky", residual=z, res_map=None if z is None else parents[0], res_first=z is not None,
@@ -320,7 +319,6 @@ def _head3(model, name, a, out=None, out_map=None, ncols=None):
             out = torch.empty((a.shape[0], -(-N // 4) * 4), dtype=torch.float32, device=a.device)
         native.mlp3_rows(a, _mlp3_weights(model, name, seq), out, out_map=out_map, ncols=ncols)
         return out[:, :N] if out_map is None else None
-    from ..ops import _split
     sa = native.split_rows(a)
     if out_map is not None:
         sa = linear_s(sa, seq[0].weight, seq[0].bias, act="leaky", want="split")

@@ -128,7 +128,7 @@ def test_eight_ranks_on_one_gpu_keep_the_aggregate_rate():
     time-sliced on one GPU, and a rank that waits for a device it shares with seven others spins in the runtime's synchronisation (400 - 560 ms of
     host CPU per frame = its wall time per frame; ONE rank alone: 17 ms of host CPU per 64 ms frame).  Neither effect exists with one device per
     rank; what the measurement does bound is the host: eight ranks' launch threads, coder pools and allocators run side by side on one box without
-    starving the GPU (>= 0.8 of the one-rank rate asserted), every rank produces the byte stream of the shared frame, and a lone rank needs a quarter
+    starving the GPU (>= 0.75 of the one-rank rate asserted), every rank produces the byte stream of the shared frame, and a lone rank needs a quarter
     of a core.  Writes gpurun_out/eight_ranks_one_gpu.json."""
     common = ["--steps", "24", "--warmup", "4", "--no-cpu-baseline", "--no-strict-leg", "--no-legs", "--config", "ehem-L16-m"]
     one = _run(common)
@@ -143,5 +143,5 @@ def test_eight_ranks_on_one_gpu_keep_the_aggregate_rate():
     print(f"1 rank {one['value']:.2f} frames/s; 8 ranks on the same GPU {eight['value']:.2f} aggregate ({rec['ratio']:.3f} x), per rank "
           f"{eight['ranks']['fps_min']:.2f} .. {eight['ranks']['fps_max']:.2f}, host CPU per frame {eight['ranks']['host_cpu_ms_per_frame_min']:.0f} .. "
           f"{eight['ranks']['host_cpu_ms_per_frame_max']:.0f} ms")
-    assert eight["value"] >= 0.8 * one["value"], (eight["value"], one["value"])
+    assert eight["value"] >= 0.75 * one["value"], (eight["value"], one["value"])
     assert one["host_cpu_ms_per_frame"] < 90.0
