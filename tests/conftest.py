@@ -19,7 +19,7 @@ _PARITY = {}
 
 def parity_record(key, **values):
     """Measured parity numbers of a GPU test run (max |dlogit|, fractions of identical rows, ...).  Written at session end to
-    gpurun_out/parity_r5.json (merged back from the GPU box); the copy under profiles/ is the tracked record DESIGN.md quotes."""
+    gpurun_out/parity_r6.json (merged back from the GPU box); the copy under profiles/ is the tracked record DESIGN.md quotes."""
     _PARITY.setdefault(key, {}).update({k: (float(v) if isinstance(v, (float, np.floating)) else int(v) if isinstance(v, (int, np.integer)) else v)
                                         for k, v in values.items()})
 
@@ -30,7 +30,7 @@ def pytest_sessionfinish(session, exitstatus):
     import json
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    path = os.path.join(out, "parity_r5.json")
+    path = os.path.join(out, "parity_r6.json")
     old = {}
     if os.path.exists(path):
         try:
