@@ -258,8 +258,8 @@ def _concat(hs, cmaps, extra=None):
 HIER = True
 
 
-# False (tests, A/B): stages 0 and 1 of a layer over concat_states as two launches with an fp32 partial sum between them (rounds 1 - 5)
-FUSE2 = True
+# False (tests, A/B; SCP_CONCAT_FUSE2=0): stages 0 and 1 of a layer over concat_states as two launches with an fp32 partial sum between them (rounds 1 - 5)
+FUSE2 = __import__("os").environ.get("SCP_CONCAT_FUSE2", "1")[:1] != "0"
 
 
 def _concat_layer(lin, hs, parents, extra=None, grand=None):
@@ -300,7 +300,7 @@ def _mlp_over_concat(seq, hs, parents, extra=None, grand=None):
 
 
 # False (tests, A/B): the 256-wide heads as three split-GEMM launches each (rounds 1 - 5) instead of one row-chain launch
-CHAIN_HEADS = True
+CHAIN_HEADS = __import__("os").environ.get("SCP_HEADS", "chain") != "split"      # (SCP_HEADS=split: A/B bracket)
 
 
 def _mlp3_weights(owner, name, seq):
