@@ -700,10 +700,13 @@ class OctAttnFrameEncoder:
         return chunks, sym, int(sym.shape[0])
 
     def _chunk_rows(self, chunks, table):
-        """Default mode: consecutive windows of context_size over every padded chunk; all FULL windows of the frame (whatever chunk
-        they belong to) share batched forwards, each chunk's shorter tail window runs on its own."""
+        """Default mode: consecutive windows of context_size over every padded chunk; all windows of the frame (whatever chunk they belong to)
+        share batched forwards.  Round 6: a chunk's shorter TAIL window rides in the same forwards, padded behind its last row to a full window
+        - the model is causal (attention_model.py:58-95: row i attends to rows <= i; everything else is per row), so the rows in front of the
+        padding come out as in a forward of the short window alone, and the frame saves that forward's ~45 launches on one window (1 ms of a
+        15 ms L12 frame)."""
         cs = self.context_size
-        full_c, full_p, dst = [], [], []       # full windows + (table row of the window's first real node, leading pad rows)
+        full_c, full_p, dst = [], [], []       # windows + (table row of the window's first real node, leading pad rows, real rows in the window)
         row = 0
         for seq_ctx, seq_pos, n in chunks:
             total = n + cs - 1
@@ -712,19 +715,23 @@ class OctAttnFrameEncoder:
                 full_c.append(seq_ctx[w * cs:(w + 1) * cs])
                 full_p.append(seq_pos[w * cs:(w + 1) * cs])
                 lo = max(w * cs - (cs - 1), 0)
-                dst.append((row + lo, lo + (cs - 1) - w * cs))
-            if total % cs:
-                out = self.model(seq_ctx[n_full * cs:].reshape(1, -1, 4, 3), seq_pos[n_full * cs:].reshape(1, -1, 4, 3))[0]
+                dst.append((row + lo, lo + (cs - 1) - w * cs, cs))
+            k = total - n_full * cs
+            if k:
+                # (padding rows: the front padding's rows - valid embedding indices - and zero positions)
+                full_c.append(torch.cat((seq_ctx[n_full * cs:], seq_ctx[:cs - k])))
+                full_p.append(torch.cat((seq_pos[n_full * cs:], torch.zeros_like(seq_pos[:cs - k]))))
                 lo = n_full * cs - (cs - 1)
-                table[row + max(lo, 0):row + n] = out[max(-lo, 0):]
+                dst.append((row + max(lo, 0), max(-lo, 0), k))
             row += n
-        # the full windows in forwards of EQUAL size (round 6): 286 windows under max_batch = 128 ran as 128 + 128 + 30 - the short third forward
-        # fills the chip badly (26.4 - 26.7 frames/s at L14 --cylin) - and run as 96 + 95 + 95 (27.2); a window's rows do not depend on its batch
+        # forwards of EQUAL size (round 6): 286 windows under max_batch = 128 ran as 128 + 128 + 30 - the short third forward fills the chip
+        # badly (26.4 - 26.7 frames/s at L14 --cylin) - and run as 96 + 96 + 94 (27.2)
         nfw = -(-len(dst) // self.max_batch) if dst else 0
         step = -(-len(dst) // nfw) if nfw else 1
         for b0 in range(0, len(dst), step):
             b1 = min(len(dst), b0 + step)
-            if len(chunks) == 1:               # one sequence: its full windows are one contiguous block (no copy)
+            contiguous = len(chunks) == 1 and all(d[2] == cs for d in dst[b0:b1])
+            if contiguous:                     # one sequence: its full windows are one contiguous block (no copy)
                 d = chunks[0][0][b0 * cs:b1 * cs].reshape(b1 - b0, cs, 4, 3)
                 p = chunks[0][1][b0 * cs:b1 * cs].reshape(b1 - b0, cs, 4, 3)
             else:
@@ -732,14 +739,16 @@ class OctAttnFrameEncoder:
                 p = torch.stack(full_p[b0:b1])
             out = self.model(d, p).reshape(-1, 255)
             # consecutive full windows of one chunk cover consecutive table rows: one copy per run (the first window of a chunk
-            # starts with its cs - 1 pad rows)
+            # starts with its cs - 1 pad rows; a tail window ends its run with its real rows)
             i = 0
             while i < b1 - b0:
                 j = i + 1
-                while j < b1 - b0 and dst[b0 + j][1] == 0 and dst[b0 + j][0] == dst[b0 + j - 1][0] + cs - dst[b0 + j - 1][1]:
+                while (j < b1 - b0 and dst[b0 + j - 1][2] == cs and dst[b0 + j][1] == 0 and
+                       dst[b0 + j][0] == dst[b0 + j - 1][0] + cs - dst[b0 + j - 1][1]):
                     j += 1
-                r0, skip = dst[b0 + i]
-                table[r0:r0 + (j - i) * cs - skip] = out[i * cs + skip:j * cs]
+                r0, skip, _ = dst[b0 + i]
+                rows = (j - 1 - i) * cs + dst[b0 + j - 1][2] - skip
+                table[r0:r0 + rows] = out[i * cs + skip:i * cs + skip + rows]
                 i = j
 
     def encode_ints(self, q, bin_num, n_points, t0=None, sequential=False, defer=False, front=None):
