@@ -159,14 +159,15 @@ def _edge_conv(conv, feat, k, feeds_knn=True):
     return native.edge_gather_max(u, v, idx, scale, shift)
 
 
-def _edge_conv_packed(conv, feat, ktab, feeds_knn=True):
-    """packed layout: feat [T,C] (all windows back to back, padded to x512 rows), ktab int32 [T/512,2] -> [T,C']."""
+def _edge_conv_packed(conv, feat, ktab, feeds_knn=True, out=None):
+    """packed layout: feat [T,C] (all windows back to back, padded to x512 rows), ktab int32 [T/512,2] -> [T,C'] (into `out` when given: a column
+    view of the next search's feature buffer)."""
     Cout = conv[0].weight.shape[0]
     Wuv, scale, shift = _edge_fold(conv)
     feat = feat.contiguous()
     idx = native.knn_topk_packed(feat, ktab)
     uv = linear(feat, Wuv, None, exact=feeds_knn)
-    return native.edge_gather_max_rows(uv[:, :Cout], uv[:, Cout:], idx, scale, shift)
+    return native.edge_gather_max_rows(uv[:, :Cout], uv[:, Cout:], idx, scale, shift, out=out)
 
 
 def geo_feat_forward(g, ctx, pos):

@@ -358,10 +358,17 @@ def ehem_phase1_packed(model, ctx, pos, plan, table=None):
                        F.embedding(ctx0[:, 1::3], g.octant_enc.weight).reshape(P0, -1)), 1)
         occ_self = ctx0[:, 11]
     ktab = d["knn_tab"]
-    pos1 = _edge_conv_packed(g.conv1, pos0, ktab)
-    pos2 = _edge_conv_packed(g.conv2, torch.cat((pos1, x), 1), ktab)
+    # the feature rows of the second and third search, cat(pos1, x) and cat(pos2, mlp2(x)) (dgcnn.py:136,142): the edge convolutions write their
+    # columns in place (round 6: two [P0, 144 | 192] concatenation copies per frame less); pos1 / pos2 stay views of these buffers
+    c1, c2 = g.conv1[0].weight.shape[0], g.conv2[0].weight.shape[0]
+    f2 = torch.empty((P0, c1 + x.shape[1]), dtype=torch.float32, device=dev)
+    f2[:, c1:] = x
+    pos1 = _edge_conv_packed(g.conv1, pos0, ktab, out=f2[:, :c1])
     x = leaky_mlp3(g.mlp2, x, exact=True)
-    pos3 = _edge_conv_packed(g.conv3, torch.cat((pos2, x), 1), ktab, feeds_knn=False)
+    f3 = torch.empty((P0, c2 + x.shape[1]), dtype=torch.float32, device=dev)
+    f3[:, c2:] = x
+    pos2 = _edge_conv_packed(g.conv2, f2, ktab, out=f3[:, :c2])
+    pos3 = _edge_conv_packed(g.conv3, f3, ktab, feeds_knn=False)
     # dense part on the split-operand GEMM: fp32 tensors are split once, the MLP chains stay in the split format, the two
     # halves of `feat` are written straight into their column slots
     nx = g.mlp3[4].weight.shape[0]

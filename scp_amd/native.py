@@ -566,12 +566,16 @@ def real_tiles(lengths, device, n_self=5, n_cross=4):
     return views[:n_self], views[n_self:]
 
 
-def edge_gather_max_rows(u, v, idx, scale, shift):
-    """packed form: u, v f32 [n, C'] VIEWS with unit channel stride (any row stride), idx int32 [n, k] -> out f32 [n, C']."""
+def edge_gather_max_rows(u, v, idx, scale, shift, out=None):
+    """packed form: u, v f32 [n, C'] VIEWS with unit channel stride (any row stride), idx int32 [n, k] -> out f32 [n, C'] (`out`: an [n, C'] view with
+    unit channel stride, e.g. the leading columns of the next search's feature buffer: no concatenation afterwards)."""
     n, Co = u.shape
-    out = torch.empty((n, Co), dtype=torch.float32, device=u.device)
+    if out is None:
+        out = torch.empty((n, Co), dtype=torch.float32, device=u.device)
+    elif out.shape != (n, Co) or out.stride(1) != 1 or out.dtype != torch.float32 or out.stride(0) % 4 or out.data_ptr() % 16:
+        raise ScpError("edge_gather_max_rows: out must be a float32 [n, C'] view with unit channel stride and 16-byte aligned rows")
     _check(lib().scp_edge_gather_max_ld(u.data_ptr(), u.stride(0), v.data_ptr(), v.stride(0), _dev(idx, torch.int32), _dev(scale), _dev(shift),
-                                        1, n, Co, idx.shape[1], out.data_ptr(), Co, _stream()), "scp_edge_gather_max_ld")
+                                        1, n, Co, idx.shape[1], out.data_ptr(), out.stride(0), _stream()), "scp_edge_gather_max_ld")
     return out
 
 
