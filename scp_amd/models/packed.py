@@ -435,7 +435,12 @@ def ehem_phase2_packed(model, st, plan, pre_occ=None, table=None, prep=None):
     g = model.geo_feat_generator
     a1, a2 = st["a1"], st["a2"]
     po = st["pre_occ"] if pre_occ is None else pre_occ
-    occ_feat = leaky_mlp3(model.pre_occ_mlp, F.embedding(po, g.occ_enc.weight))
+    # pre_occ_mlp(embed_occ(symbol)) (ehem.py:117-119) is a function of the symbol alone: a 256-row table, made once per weight by the same exact
+    # fp32 kernels (their rows do not depend on the batch: same bits as evaluating the three layers on the gathered embeddings), then one gather per
+    # call instead of an embedding lookup and three dense launches - the decoder calls this once per window
+    lut = derived(model, "pre_occ_lut", [g.occ_enc.weight] + [model.pre_occ_mlp[i].weight for i in (0, 2, 4)] + [model.pre_occ_mlp[i].bias for i in (0, 2, 4)],
+                  lambda: leaky_mlp3(model.pre_occ_mlp, g.occ_enc.weight.detach()).contiguous())
+    occ_feat = F.embedding(po, lut)
     no = occ_feat.shape[1]
     if prep is not None:
         pre = prep["pre"]
