@@ -262,7 +262,7 @@ HIER = True
 FUSE2 = __import__("os").environ.get("SCP_CONCAT_FUSE2", "1")[:1] != "0"
 
 
-def _concat_layer(lin, hs, parents, extra=None, grand=None):
+def _concat_layer(lin, hs, parents, extra=None, grand=None, a0_pre=None):
     """LeakyReLU(Linear(concat_states(hs))) (ehem.py:75-86 + the first layer of the MLP that consumes it) WITHOUT building the
     concatenation: the layer's weight is cut into one 256-column slab per Swin stage, stage s contributes h_s . W_s^T at its OWN
     resolution (rows / 2^s), and the partial sums flow from the coarsest stage down through the parent-row maps (token t of stage s
@@ -281,7 +281,11 @@ def _concat_layer(lin, hs, parents, extra=None, grand=None):
     z = None
     for s in range(n - 1, 1 if fused else 0, -1):
         z = linear_s(native.split_rows(hs[s + 1]), cache[s], None, residual=z, res_map=None if z is None else parents[s], res_first=z is not None)
-    a0 = native.split_rows(hs[1]) if extra is None else split_cat((hs[1], extra))
+    if a0_pre is not None:           # the operand's `extra` columns were written ahead (ehem_phase2_prepare): only stage 0's own columns are left
+        native.split_rows(hs[1], out=a0_pre.cols(0, 256))
+        a0 = a0_pre
+    else:
+        a0 = native.split_rows(hs[1]) if extra is None else split_cat((hs[1], extra))
     if fused:
         # round 6: stages 0 and 1 in ONE launch - the stage-1 product of a 256-token tile's own 128 parents stays in the accumulators
         # (csrc/gemm_split.hip: gemm_hier2_kernel); z = the partial sum of stages 2 .. n - 1 at stage-2 resolution, gathered through `grand`
@@ -291,10 +295,10 @@ def _concat_layer(lin, hs, parents, extra=None, grand=None):
                     want="split")
 
 
-def _mlp_over_concat(seq, hs, parents, extra=None, grand=None):
+def _mlp_over_concat(seq, hs, parents, extra=None, grand=None, a0_pre=None):
     """leaky_mlp3 over concat_states: hierarchical first layer, then the two remaining layers on split activations.
     grand: stage-2 row of every stage-0 row (plan `self_concat[1]` / `cross_concat[1]`) - enables the fused two-stage launch."""
-    a = _concat_layer(seq[0], hs, parents, extra, grand)
+    a = _concat_layer(seq[0], hs, parents, extra, grand, a0_pre)
     a = linear_s(a, seq[2].weight, seq[2].bias, act="leaky", want="split")
     return linear_s(a, seq[4].weight, seq[4].bias)
 
@@ -418,13 +422,17 @@ def ehem_phase2_prepare(model, st, plan):
         qs.append(row)
         if s < len(enc.layers) - 1:
             query = _merge(stage.downsample, query, d["cross_merge"][s])
-    return dict(pre=pre, q=qs)
+    # the odd tokens' half of prob_pred_mlp2's first operand (ehem.py:124: cat(concat_states, a2)) as planes, in its columns of the [Q0, 512] operand
+    a0 = native.SplitAct.empty(a2.shape[0], 512, a2.device)
+    native.split_rows(a2, out=a0.cols(256, 512))
+    return dict(pre=pre, q=qs, a0=a0)
 
 
 def phase2_prep_window(prep, bases, rows):
     """The rows of ONE window inside a level-wide ehem_phase2_prepare result: bases[s] / rows[s] = first row / padded row count of the window in
     cross stage s (a one-window plan has exactly these rows)."""
-    return dict(pre=prep["pre"][bases[0]:bases[0] + rows[0]], q=[[q[bases[s]:bases[s] + rows[s]] for q in qs] for s, qs in enumerate(prep["q"])])
+    return dict(pre=prep["pre"][bases[0]:bases[0] + rows[0]], q=[[q[bases[s]:bases[s] + rows[s]] for q in qs] for s, qs in enumerate(prep["q"])],
+                a0=native.SplitAct(prep["a0"].t[:, bases[0]:bases[0] + rows[0]], prep["a0"].K))
 
 
 @torch.no_grad()
@@ -440,24 +448,22 @@ def ehem_phase2_packed(model, st, plan, pre_occ=None, table=None, prep=None):
     # call instead of an embedding lookup and three dense launches - the decoder calls this once per window
     lut = derived(model, "pre_occ_lut", [g.occ_enc.weight] + [model.pre_occ_mlp[i].weight for i in (0, 2, 4)] + [model.pre_occ_mlp[i].bias for i in (0, 2, 4)],
                   lambda: leaky_mlp3(model.pre_occ_mlp, g.occ_enc.weight.detach()).contiguous())
-    occ_feat = F.embedding(po, lut)
-    no = occ_feat.shape[1]
+    no = lut.shape[1]
     if prep is not None:
         pre = prep["pre"]
-        pre[:, :no] = occ_feat
     else:
         pre = torch.empty((a2.shape[0], no + model.pre_attn_mlp[4].weight.shape[0]), dtype=torch.float32, device=a2.device)
-        pre[:, :no] = occ_feat
         _head3(model, "pre_attn_mlp", a1, out=pre[:, no:])
+    native.gather_rows(lut, po, pre[:, :no])                # the table's rows straight into their columns of `pre`
     hc = _encoder(model.swin_cross_transformer, pre, d["cross_valid"], d["cross_tab"], d["cross_merge"], query=a2, tiles=d.get("cross_tiles"),
                   q_pre=None if prep is None else prep["q"])
     if table is not None:
-        a = _concat_layer(model.prob_pred_mlp2[0], hc, d["cross_parent"], a2, d["cross_concat"][1]) if HIER else linear_s(_concat(hc, d["cross_concat"], extra=(a2, None)), model.prob_pred_mlp2[0].weight, model.prob_pred_mlp2[0].bias, act="leaky", want="split")
+        a = _concat_layer(model.prob_pred_mlp2[0], hc, d["cross_parent"], a2, d["cross_concat"][1], None if prep is None else prep.get("a0")) if HIER else linear_s(_concat(hc, d["cross_concat"], extra=(a2, None)), model.prob_pred_mlp2[0].weight, model.prob_pred_mlp2[0].bias, act="leaky", want="split")
         from ..ops import _split
         a = linear_s(a, model.prob_pred_mlp2[2].weight, model.prob_pred_mlp2[2].bias, act="leaky", want="split")
         native.linear_split_scatter(a, _split(model.prob_pred_mlp2[4].weight), model.prob_pred_mlp2[4].bias, d["odd_out"], table)
         return None
-    prob2 = (_mlp_over_concat(model.prob_pred_mlp2, hc, d["cross_parent"], extra=a2, grand=d["cross_concat"][1]) if HIER
+    prob2 = (_mlp_over_concat(model.prob_pred_mlp2, hc, d["cross_parent"], extra=a2, grand=d["cross_concat"][1], a0_pre=None if prep is None else prep.get("a0")) if HIER
              else leaky_mlp3_s(model.prob_pred_mlp2, _concat(hc, d["cross_concat"], extra=(a2, None))))
     return prob2[d["odd_rows"]]
 
